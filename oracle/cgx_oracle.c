@@ -1,0 +1,1569 @@
+/*
+ * cgx_oracle.c -- TEST INFRASTRUCTURE ONLY (see cgx_oracle.h).
+ *
+ * Plain-C, single-thread restatement of the reference pipeline.  The CUDA kernels are
+ * restated as "one call per CUDA thread" loops so that per-thread early exits (the
+ * reference's `printf(...); return;` guards) keep their meaning.  Wherever the real
+ * program's result depends on atomicAdd arrival order or on thrust's handling of equal
+ * keys, the oracle takes the canonical order defined in SURVEY.md section 7:
+ *   hit lists     : (pattern id, str_position, length[, length2])
+ *   rule arrays   : full-record order (id, target start, end, gap fields)
+ * which is one of the reference's legal behaviours and the only reproducible one.
+ */
+#define _GNU_SOURCE
+#include "cgx_oracle.h"
+#include <stdlib.h>
+#include <string.h>
+#include <ctype.h>
+#include <math.h>
+#include <time.h>
+#include <assert.h>
+
+#define DIE(...) do { fprintf(stderr, "oracle: " __VA_ARGS__); fprintf(stderr, "\n"); exit(2); } while (0)
+
+static void *xmalloc(size_t n) { void *p = malloc(n ? n : 1); if (!p) DIE("out of memory (%zu)", n); return p; }
+static void *xcalloc(size_t n, size_t s) { void *p = calloc(n ? n : 1, s ? s : 1); if (!p) DIE("out of memory"); return p; }
+static void *xrealloc(void *q, size_t n) { void *p = realloc(q, n ? n : 1); if (!p) DIE("out of memory"); return p; }
+static char *xstrdup(const char *s) { size_t n = strlen(s) + 1; char *p = xmalloc(n); memcpy(p, s, n); return p; }
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; }
+
+/* growable array */
+#define VEC(T) struct { T *v; size_t n, cap; }
+#define VPUSH(a, x) do { if ((a).n == (a).cap) { (a).cap = (a).cap ? (a).cap * 2 : 64; \
+        (a).v = xrealloc((a).v, (a).cap * sizeof *(a).v); } (a).v[(a).n++] = (x); } while (0)
+
+/* ------------------------------------------------------------------ */
+/* string -> id map (replaces the reference's uthash tables)           */
+/* ------------------------------------------------------------------ */
+typedef struct { char **key; int32_t *val; size_t cap, n; } strmap;
+static uint64_t fnv1a(const char *s) { uint64_t h = 1469598103934665603ull; for (; *s; s++) { h ^= (unsigned char)*s; h *= 1099511628211ull; } return h; }
+static strmap *strmap_new(void) { strmap *m = xcalloc(1, sizeof *m); m->cap = 1024; m->key = xcalloc(m->cap, sizeof *m->key); m->val = xcalloc(m->cap, sizeof *m->val); return m; }
+static void strmap_free(strmap *m) { if (!m) return; free(m->key); free(m->val); free(m); }
+static int32_t strmap_get(const strmap *m, const char *k) {
+    size_t i = fnv1a(k) & (m->cap - 1);
+    while (m->key[i]) { if (!strcmp(m->key[i], k)) return m->val[i]; i = (i + 1) & (m->cap - 1); }
+    return -1;
+}
+static void strmap_put(strmap *m, char *k, int32_t v) {
+    if ((m->n + 1) * 2 > m->cap) {
+        size_t oc = m->cap; char **ok = m->key; int32_t *ov = m->val;
+        m->cap *= 2; m->key = xcalloc(m->cap, sizeof *m->key); m->val = xcalloc(m->cap, sizeof *m->val); m->n = 0;
+        for (size_t j = 0; j < oc; j++) if (ok[j]) strmap_put(m, ok[j], ov[j]);
+        free(ok); free(ov);
+    }
+    size_t i = fnv1a(k) & (m->cap - 1);
+    while (m->key[i]) i = (i + 1) & (m->cap - 1);
+    m->key[i] = k; m->val[i] = v; m->n++;
+}
+
+/* ------------------------------------------------------------------ */
+/* corpus loaders: Start.cu:142-238 (target), 240-380 (source)          */
+/* ------------------------------------------------------------------ */
+typedef struct { int32_t *str; uint32_t n; uint8_t *P; int32_t *sentind; int32_t nsent; char **vocab; int32_t nvocab; strmap *map; } side_t;
+
+/* Tokenise one line the way the reference does: strip one trailing '\n', strtok on ' ',
+ * stop at the first token that starts with white space (Start.cu:273-305). */
+static void load_side(const char *path, side_t *o, int want_P) {
+    FILE *f = fopen(path, "r");
+    if (!f) DIE("cannot open %s", path);
+    VEC(int32_t) toks = {0}; VEC(uint8_t) pos = {0}; VEC(int32_t) sent = {0}; VEC(char *) voc = {0};
+    strmap *map = strmap_new();
+    VPUSH(voc, NULL); VPUSH(voc, NULL);              /* ids 0,1 have no spelling */
+    VPUSH(sent, 0);
+    char *line = NULL; size_t cap = 0; int32_t last = -1;
+    while (getline(&line, &cap, f) != -1) {
+        size_t L = strlen(line);
+        if (L && line[L - 1] == '\n') line[L - 1] = 0;
+        char *save = NULL; uint8_t local = 0;
+        for (char *tok = strtok_r(line, " ", &save); tok && !isspace((unsigned char)*tok); tok = strtok_r(NULL, " ", &save)) {
+            size_t tl = strlen(tok);
+            if (tl && tok[tl - 1] == '\n') tok[tl - 1] = 0;
+            int32_t id = strmap_get(map, tok);
+            if (id < 0) {                            /* first-seen ids start at 2 (Start.cu:288) */
+                id = (int32_t)map->n + 2; last = id;
+                char *k = xstrdup(tok); strmap_put(map, k, id); VPUSH(voc, k);
+            }
+            VPUSH(toks, id); VPUSH(pos, local); local++;
+        }
+        VPUSH(toks, 1); VPUSH(pos, 0);               /* sentence delimiter (Start.cu:306) */
+        VPUSH(sent, (int32_t)toks.n);
+    }
+    free(line); fclose(f);
+    VPUSH(toks, 1); VPUSH(pos, 0);                   /* trailing "1,last" sentinels (Start.cu:321-327) */
+    last++;
+    VPUSH(toks, last); VPUSH(pos, 0);
+    o->n = (uint32_t)toks.n;
+    o->str = xcalloc(toks.n + 3, sizeof(int32_t));   /* three 0 pads for DC3 (Start.cu:354) */
+    memcpy(o->str, toks.v, toks.n * sizeof(int32_t));
+    o->P = want_P ? pos.v : NULL; if (!want_P) free(pos.v);
+    o->sentind = sent.v; o->nsent = (int32_t)sent.n - 1;
+    o->vocab = voc.v; o->nvocab = (int32_t)map->n + 2; o->map = map;
+    free(toks.v);
+}
+
+/* ------------------------------------------------------------------ */
+/* suffix array.  The reference builds it with DC3 (SuffixArray.c:51-129); a suffix array
+ * is unique, so any correct builder is parity-safe.  oracle/_ref runs the real
+ * suffixArrayConstruct and tests compare.  Here: prefix doubling with qsort.             */
+/* ------------------------------------------------------------------ */
+static const int32_t *g_rk; static uint32_t g_h, g_n;
+static int cmp_sfx(const void *a, const void *b) {
+    uint32_t x = *(const uint32_t *)a, y = *(const uint32_t *)b;
+    if (g_rk[x] != g_rk[y]) return g_rk[x] < g_rk[y] ? -1 : 1;
+    int32_t rx = x + g_h < g_n ? g_rk[x + g_h] : -1, ry = y + g_h < g_n ? g_rk[y + g_h] : -1;
+    return rx < ry ? -1 : rx > ry;
+}
+void orc_build_sa(const int32_t *str, uint32_t n, int32_t *sa) {
+    int32_t *rk = xmalloc(n * sizeof *rk), *tmp = xmalloc(n * sizeof *tmp);
+    for (uint32_t i = 0; i < n; i++) { sa[i] = (int32_t)i; rk[i] = str[i]; }
+    g_n = n;
+    for (uint32_t h = 0;; h = h ? h * 2 : 1) {
+        g_rk = rk; g_h = h;
+        if (h == 0) { /* first pass: sort by first token only */ g_h = n; }
+        qsort(sa, n, sizeof *sa, cmp_sfx);
+        tmp[sa[0]] = 0; int32_t r = 0;
+        for (uint32_t i = 1; i < n; i++) { if (cmp_sfx(&sa[i - 1], &sa[i]) != 0) r++; tmp[sa[i]] = r; }
+        memcpy(rk, tmp, n * sizeof *rk);
+        if ((uint32_t)r == n - 1) break;
+        if (h > n) DIE("suffix array: ranks did not become unique");
+    }
+    free(rk); free(tmp);
+}
+
+/* ------------------------------------------------------------------ */
+/* alignment: initAlignment, ExtractPair.cu:2639-2739                   */
+/* ------------------------------------------------------------------ */
+static void pack_rlp(orc_index *ix, const uint8_t *Ls, const uint8_t *Rs) {
+    ix->rlp = xcalloc(ix->n, sizeof(uint32_t));
+    int q = 1;
+    for (uint32_t i = 0; i + 1 < ix->n; i++) {       /* the last entry stays unset in the reference */
+        if (q <= ix->nsent && (int32_t)i == ix->sentind[q] - 1) {
+            ix->rlp[i] = (uint32_t)ix->tsentind[q];  /* delimiter slot: target offset of the NEXT sentence (:2722-2724) */
+            q++;
+        } else {
+            ix->rlp[i] = ((uint32_t)Ls[i] << 24) | ((uint32_t)Rs[i] << 16) | ((uint32_t)ix->P[i] << 8);
+        }
+    }
+}
+static void load_alignment(orc_index *ix, const char *path) {
+    FILE *f = fopen(path, "r");
+    if (!f) DIE("cannot open %s", path);
+    uint8_t *Ls = xmalloc(ix->n), *Rs = xmalloc(ix->n);
+    memset(Ls, 255, ix->n); memset(Rs, 255, ix->n);
+    ix->ltar = xmalloc(ix->nt); ix->rtar = xmalloc(ix->nt);
+    memset(ix->ltar, 255, ix->nt); memset(ix->rtar, 255, ix->nt);
+    char *line = NULL; size_t cap = 0; int q = -1;
+    while (getline(&line, &cap, f) != -1) {
+        q++;
+        size_t L = strlen(line);
+        if (L && line[L - 1] == '\n') line[L - 1] = 0;
+        if (q >= ix->nsent) DIE("alignment file has more lines than the corpus");
+        char *save = NULL;
+        for (char *tok = strtok_r(line, " -", &save); tok && !isspace((unsigned char)*tok); tok = strtok_r(NULL, " -", &save)) {
+            int s = atoi(tok);
+            tok = strtok_r(NULL, " -", &save);
+            if (!tok) { printf("Not possible!\n"); exit(0); }
+            int t = atoi(tok);
+            if (s >= 255 || t >= 255 || s < 0 || t < 0) { printf("Not possible, too long sentence\n"); exit(1); } /* :2683 */
+            uint32_t si = (uint32_t)(ix->sentind[q] + s), ti = (uint32_t)(ix->tsentind[q] + t);
+            if (si >= ix->n || ti >= ix->nt) DIE("alignment index outside corpus");
+            if (Ls[si] == 255 || Rs[si] == 255) Ls[si] = Rs[si] = (uint8_t)t;
+            else if (t > Rs[si]) Rs[si] = (uint8_t)t;
+            else if (t < Ls[si]) Ls[si] = (uint8_t)t;
+            if (ix->ltar[ti] == 255 || ix->rtar[ti] == 255) ix->ltar[ti] = ix->rtar[ti] = (uint8_t)s;
+            else if (s > ix->rtar[ti]) ix->rtar[ti] = (uint8_t)s;
+            else if (s < ix->ltar[ti]) ix->ltar[ti] = (uint8_t)s;
+        }
+    }
+    free(line); fclose(f);
+    pack_rlp(ix, Ls, Rs);
+    free(Ls); free(Rs);
+}
+
+/* ------------------------------------------------------------------ */
+/* lexical table: initWordPossibilityIntKey, ExtractPair.cu:2442-2554   */
+/* ------------------------------------------------------------------ */
+typedef struct { orc_lexkey k; orc_lexval v; uint32_t ord; } lexrow;
+static int cmp_lexrow(const void *a, const void *b) {
+    const lexrow *x = a, *y = b;
+    if (x->k.src != y->k.src) return x->k.src < y->k.src ? -1 : 1;
+    if (x->k.tgt != y->k.tgt) return x->k.tgt < y->k.tgt ? -1 : 1;
+    return x->ord < y->ord ? -1 : x->ord > y->ord;
+}
+static void sort_lex(orc_index *ix, lexrow *rows, uint32_t n) {
+    qsort(rows, n, sizeof *rows, cmp_lexrow);
+    ix->nlex = n; ix->lexk = xmalloc(n * sizeof *ix->lexk); ix->lexv = xmalloc(n * sizeof *ix->lexv);
+    for (uint32_t i = 0; i < n; i++) { ix->lexk[i] = rows[i].k; ix->lexv[i] = rows[i].v; }
+}
+static void load_lex(orc_index *ix, const char *path) {
+    FILE *f = fopen(path, "r");
+    if (!f) { fprintf(stderr, "The Word Possibility File is not Found!\n"); exit(0); }
+    VEC(lexrow) rows = {0};
+    char a[4096], b[4096]; float v1, v2;
+    /* `file >> chinese >> english >> val1 >> val2` until the stream goes bad; a trailing
+     * blank read yields an empty word that is skipped (ExtractPair.cu:2463-2479). */
+    while (fscanf(f, "%4095s %4095s %f %f", a, b, &v1, &v2) == 4) {
+        int32_t s = strmap_get(ix->shash, a), t = strmap_get(ix->thash, b);
+        if (s < 0 && strcmp(a, "NULL")) { printf("Ch Not Available!!! %s\n", a); continue; }
+        if (t < 0 && strcmp(b, "NULL")) { printf("En Not Available!!! %s\n", b); continue; }
+        lexrow r; r.k.src = s < 0 ? -1 : s; r.k.tgt = t < 0 ? -1 : t; r.v.v1 = v1; r.v.v2 = v2; r.ord = (uint32_t)rows.n;
+        VPUSH(rows, r);
+    }
+    fclose(f);
+    sort_lex(ix, rows.v, (uint32_t)rows.n);
+    free(rows.v);
+}
+
+/* searchLexFile, ExtractPair.cu:2108-2142.  The reference starts with high = count (one
+ * past the end) and lets `high = middle-1` underflow; both read out of bounds.  A key that
+ * is absent yields 0 in every case that stays in bounds, so the oracle defines the result
+ * as: value of the matching row, else 0. */
+float orc_lex_lookup(const orc_index *ix, int32_t src, int32_t tgt, int which) {
+    int64_t lo = 0, hi = (int64_t)ix->nlex - 1;
+    while (lo <= hi) {
+        int64_t m = lo + (hi - lo) / 2;
+        const orc_lexkey *k = &ix->lexk[m];
+        if (src < k->src) hi = m - 1; else if (src > k->src) lo = m + 1;
+        else if (tgt < k->tgt) hi = m - 1; else if (tgt > k->tgt) lo = m + 1;
+        else return which ? ix->lexv[m].v1 : ix->lexv[m].v2;
+    }
+    return 0.0f;
+}
+
+/* ------------------------------------------------------------------ */
+/* gap validity: checkBoundaryGap, GappyLook.cu:43-126                  */
+/* ------------------------------------------------------------------ */
+int orc_check_gap(const orc_index *ix, uint32_t start, uint32_t ender) {
+    unsigned char L, R, min_L = 255, max_R = 0; int stb = -1, tempind = 0;
+    for (uint32_t k = start; k <= ender; k++) {
+        uint32_t w = ix->rlp[k]; L = (w >> 24) & 0xFF; R = (w >> 16) & 0xFF;
+        if ((L == 255 || R == 255) && (k == start || k == ender)) return 0;
+        else if (L == 255 || R == 255) { /* unaligned inside the gap: ignored */ }
+        else if (k == start) {
+            tempind = (int)k - (int)((w >> 8) & 0xFF) - 1;
+            stb = tempind == -1 ? 0 : (int)ix->rlp[tempind];
+            min_L = L; max_R = R;
+        } else { if (min_L > L) min_L = L; if (max_R < R) max_R = R; }
+    }
+    if (min_L <= max_R && max_R - min_L < ORC_MAX_SPAN) {
+        tempind++;
+        int ts = min_L + stb, te = max_R + stb;
+        min_L = 255; max_R = 0;
+        for (int k = ts; k <= te; k++) {
+            L = ix->ltar[k]; R = ix->rtar[k];
+            if (L == 255 || R == 255) { }
+            else if (k == ts) { min_L = L; max_R = R; }
+            else { if (min_L > L) min_L = L; if (max_R < R) max_R = R; }
+        }
+        if ((uint32_t)(tempind + min_L) != start || (uint32_t)(tempind + max_R) != ender) return 0;
+        return 1;
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* preComputation + precomp kernel: SuffixArray.cu:1132-1340, GappyLook.cu:740-870 */
+/* ------------------------------------------------------------------ */
+typedef struct { int32_t length, token; int64_t start, end; uint32_t ord; } toptok;
+static int cmp_top_count(const void *a, const void *b) { /* glibc merge-qsort with a 0/1 comparator == stable, count descending */
+    const toptok *x = a, *y = b;
+    if (x->length != y->length) return x->length > y->length ? -1 : 1;
+    return x->ord < y->ord ? -1 : x->ord > y->ord;
+}
+static int cmp_top_token(const void *a, const void *b) { const toptok *x = a, *y = b; return x->token < y->token ? -1 : x->token > y->token; }
+typedef struct { uint32_t index, start; uint8_t length; } prehit_l;
+static int cmp_prehit(const void *a, const void *b) {
+    const prehit_l *x = a, *y = b;
+    if (x->index != y->index) return x->index < y->index ? -1 : 1;
+    if (x->start != y->start) return x->start < y->start ? -1 : 1;
+    return x->length < y->length ? -1 : x->length > y->length;
+}
+int orc_precompute(orc_index *ix) {
+    const int32_t *str = ix->str, *sa = ix->sa; uint32_t n = ix->n;
+    /* token histogram in SA order == ascending token id (:1148-1174) */
+    VEC(toptok) tl = {0};
+    uint32_t i = 0;
+    while (i < n && str[sa[i]] < 2) i++;
+    while (i < n) {
+        uint32_t j = i; int32_t tk = str[sa[i]];
+        while (j < n && str[sa[j]] == tk) j++;
+        toptok t; t.token = tk; t.length = (int32_t)(j - i); t.start = i; t.end = (int64_t)j - 1; t.ord = (uint32_t)tl.n;
+        VPUSH(tl, t); i = j;
+    }
+    if (tl.n < ORC_TOP) { free(tl.v); return -1; }     /* the reference sorts toplist[0..99] unconditionally (:1176) */
+    qsort(tl.v, tl.n, sizeof *tl.v, cmp_top_count);
+    qsort(tl.v, ORC_TOP, sizeof *tl.v, cmp_top_token);
+    for (int j = 0; j < ORC_TOP; j++) ix->freq[j] = tl.v[j].token;
+
+    VEC(prehit_l) hits = {0};
+    memset(ix->miss, 0, sizeof ix->miss);
+    for (int cc = 0; cc < ORC_TOP; cc++) for (int jj = 0; jj < ORC_TOP; jj++) {
+        uint32_t index = (uint32_t)(cc * ORC_TOP + jj);
+        int32_t ta = tl.v[cc].token, tb = tl.v[jj].token;
+        int reverse = tl.v[jj].length >= tl.v[cc].length;   /* drive from the rarer token (:1203-1215) */
+        const toptok *drv = reverse ? &tl.v[cc] : &tl.v[jj];
+        for (int64_t tid = drv->start; tid <= drv->end; tid++) {
+            int64_t go = sa[tid]; int move = 0, fl = 1;
+            if (reverse) {                              /* forward from a (GappyLook.cu:780-822) */
+                while (fl) {
+                    if (move == 0 && str[go + ORC_MIN_GAP] < 2) fl = 0;
+                    int32_t t = str[go + 1 + ORC_MIN_GAP + move];
+                    if (t < 2) fl = 0;
+                    else if (fl && t == tb) {
+                        if (orc_check_gap(ix, (uint32_t)(go + 1), (uint32_t)(go + move + 1 + ORC_MIN_GAP - 1))) {
+                            prehit_l h = { index, (uint32_t)go, (uint8_t)(move + 1 + ORC_MIN_GAP) }; VPUSH(hits, h);
+                        } else ix->miss[index]++;
+                    }
+                    move++;
+                    if (1 + ORC_MIN_GAP + move + 1 > ORC_MAX_SPAN) fl = 0;
+                }
+            } else {                                    /* backward from b (GappyLook.cu:823-864) */
+                while (fl) {
+                    if (move == 0 && go - ORC_MIN_GAP >= 0 && str[go - ORC_MIN_GAP] < 2) fl = 0;
+                    if (fl && go - 1 - ORC_MIN_GAP - move >= 0) {
+                        int32_t t = str[go - 1 - ORC_MIN_GAP - move];
+                        if (t < 2) fl = 0;
+                        else if (t == ta) {
+                            if (orc_check_gap(ix, (uint32_t)(go - 1 - ORC_MIN_GAP - move + 1), (uint32_t)(go - 1))) {
+                                prehit_l h = { index, (uint32_t)(go - 1 - ORC_MIN_GAP - move), (uint8_t)(move + 1 + ORC_MIN_GAP) }; VPUSH(hits, h);
+                            } else ix->miss[index]++;
+                        }
+                    } else fl = 0;
+                    move++;
+                    if (1 + ORC_MIN_GAP + move + 1 > ORC_MAX_SPAN) fl = 0;
+                }
+            }
+        }
+    }
+    free(tl.v);
+    qsort(hits.v, hits.n, sizeof *hits.v, cmp_prehit);   /* compareUserTotal3, :1123-1130,1300 */
+    ix->nphits = (uint32_t)hits.n;
+    ix->phits = xmalloc(hits.n * sizeof *ix->phits);
+    uint32_t c = 0;
+    for (uint32_t ic = 0; ic < ORC_TOP * ORC_TOP; ic++) {
+        ix->pidx[ic].start = 1; ix->pidx[ic].end = 0;     /* empty = {1,0} (:1306-1307) */
+        int first = 1;
+        while (c < hits.n && hits.v[c].index == ic) { if (first) { ix->pidx[ic].start = c; first = 0; } ix->pidx[ic].end = c; c++; }
+    }
+    for (uint32_t k = 0; k < hits.n; k++) { ix->phits[k].start = hits.v[k].start; ix->phits[k].length = hits.v[k].length; }
+    free(hits.v);
+    return 0;
+}
+
+/* existPrecomputation, GappyLook.cu:5-40 */
+static int pre_index(const orc_index *ix, int32_t a, int32_t b) {
+    int ia = -1, ib = -1, lo = 0, hi = ORC_TOP - 1;
+    while (lo <= hi) { int m = (lo + hi) >> 1; if (ix->freq[m] > a) hi = m - 1; else if (ix->freq[m] < a) lo = m + 1; else { ia = m; break; } }
+    lo = 0; hi = ORC_TOP - 1;
+    while (lo <= hi) { int m = (lo + hi) >> 1; if (ix->freq[m] > b) hi = m - 1; else if (ix->freq[m] < b) lo = m + 1; else { ib = m; break; } }
+    return (ia >= 0 && ib >= 0) ? ia * ORC_TOP + ib : -1;
+}
+
+/* ------------------------------------------------------------------ */
+/* index assembly                                                      */
+/* ------------------------------------------------------------------ */
+orc_index *orc_index_load(const char *src, const char *tgt, const char *align, const char *lex) {
+    orc_index *ix = xcalloc(1, sizeof *ix);
+    side_t s, t;
+    load_side(src, &s, 1); load_side(tgt, &t, 0);
+    ix->n = s.n; ix->str = s.str; ix->P = s.P; ix->sentind = s.sentind; ix->nsent = s.nsent;
+    ix->svocab = s.vocab; ix->nsvocab = s.nvocab; ix->shash = s.map;
+    ix->nt = t.n; ix->tstr = t.str; ix->tsentind = t.sentind; ix->tvocab = t.vocab; ix->ntvocab = t.nvocab; ix->thash = t.map;
+    if (t.nsent != s.nsent) DIE("source has %d lines, target %d", s.nsent, t.nsent);
+    ix->sa = xmalloc(ix->n * sizeof *ix->sa);
+    orc_build_sa(ix->str, ix->n, ix->sa);
+    load_lex(ix, lex);
+    load_alignment(ix, align);
+    if (orc_precompute(ix)) DIE("fewer than %d distinct source tokens: the reference reads garbage here", ORC_TOP);
+    return ix;
+}
+
+orc_index *orc_index_from_arrays(const int32_t *str, uint32_t n, const int32_t *sentind, int32_t nsent,
+                                 const int32_t *tstr, uint32_t nt, const int32_t *tsentind,
+                                 const uint8_t *lsrc, const uint8_t *rsrc, const uint8_t *ltar, const uint8_t *rtar,
+                                 const orc_lexkey *lexk, const orc_lexval *lexv, uint32_t nlex, const int32_t *sa) {
+    orc_index *ix = xcalloc(1, sizeof *ix);
+    ix->n = n; ix->str = xcalloc((size_t)n + 3, sizeof(int32_t)); memcpy(ix->str, str, (size_t)n * 4);
+    ix->nsent = nsent; ix->sentind = xmalloc(((size_t)nsent + 1) * 4); memcpy(ix->sentind, sentind, ((size_t)nsent + 1) * 4);
+    ix->nt = nt; ix->tstr = xcalloc((size_t)nt + 3, 4); memcpy(ix->tstr, tstr, (size_t)nt * 4);
+    ix->tsentind = xmalloc(((size_t)nsent + 1) * 4); memcpy(ix->tsentind, tsentind, ((size_t)nsent + 1) * 4);
+    ix->P = xcalloc(n, 1);
+    for (int32_t q = 0; q < nsent; q++) for (int32_t i = sentind[q]; i < sentind[q + 1] - 1; i++) ix->P[i] = (uint8_t)(i - sentind[q]);
+    ix->ltar = xmalloc(nt); memcpy(ix->ltar, ltar, nt); ix->rtar = xmalloc(nt); memcpy(ix->rtar, rtar, nt);
+    pack_rlp(ix, lsrc, rsrc);
+    lexrow *rows = xmalloc((size_t)nlex * sizeof *rows);
+    for (uint32_t i = 0; i < nlex; i++) { rows[i].k = lexk[i]; rows[i].v = lexv[i]; rows[i].ord = i; }
+    sort_lex(ix, rows, nlex); free(rows);
+    ix->sa = xmalloc((size_t)n * 4);
+    if (sa) memcpy(ix->sa, sa, (size_t)n * 4); else orc_build_sa(ix->str, n, ix->sa);
+    int32_t maxs = 0, maxt = 0;
+    for (uint32_t i = 0; i < n; i++) if (str[i] > maxs) maxs = str[i];
+    for (uint32_t i = 0; i < nt; i++) if (tstr[i] > maxt) maxt = tstr[i];
+    ix->nsvocab = maxs; ix->ntvocab = maxt;          /* last = maxid+1, so #ids+2 == last */
+    ix->svocab = xcalloc((size_t)maxs + 1, sizeof(char *)); ix->tvocab = xcalloc((size_t)maxt + 1, sizeof(char *));
+    char buf[32];
+    for (int32_t i = 2; i <= maxs; i++) { snprintf(buf, sizeof buf, "s%d", i); ix->svocab[i] = xstrdup(buf); }
+    for (int32_t i = 2; i <= maxt; i++) { snprintf(buf, sizeof buf, "t%d", i); ix->tvocab[i] = xstrdup(buf); }
+    if (orc_precompute(ix)) DIE("fewer than %d distinct source tokens", ORC_TOP);
+    return ix;
+}
+
+void orc_index_free(orc_index *ix) {
+    if (!ix) return;
+    for (int32_t i = 0; ix->svocab && i < (ix->shash ? ix->nsvocab : ix->nsvocab + 1); i++) free(ix->svocab[i]);
+    for (int32_t i = 0; ix->tvocab && i < (ix->thash ? ix->ntvocab : ix->ntvocab + 1); i++) free(ix->tvocab[i]);
+    free(ix->svocab); free(ix->tvocab); strmap_free(ix->shash); strmap_free(ix->thash);
+    free(ix->str); free(ix->P); free(ix->sentind); free(ix->sa); free(ix->rlp); free(ix->tstr); free(ix->tsentind);
+    free(ix->ltar); free(ix->rtar); free(ix->lexk); free(ix->lexv); free(ix->phits); free(ix);
+}
+
+/* ------------------------------------------------------------------ */
+/* queries: constructQryIndex, Start.cu:50-132                          */
+/* ------------------------------------------------------------------ */
+orc_batch *orc_batch_from_ids(const int32_t *qoff, int32_t nq, const int32_t *qtok, int32_t ntok) {
+    orc_batch *b = xcalloc(1, sizeof *b);
+    b->nq = nq; b->ntok = ntok;
+    b->qoff = xmalloc(((size_t)nq + 1) * 4); memcpy(b->qoff, qoff, (size_t)nq * 4); b->qoff[nq] = ntok;
+    b->qtok = xmalloc(((size_t)ntok + 8) * 4); memcpy(b->qtok, qtok, (size_t)ntok * 4);
+    for (int k = 0; k < 8; k++) b->qtok[ntok + k] = -1;
+    b->tok2q = xmalloc(((size_t)ntok + 1) * 4);
+    for (int32_t q = 0; q < nq; q++) for (int32_t t = b->qoff[q]; t < b->qoff[q + 1]; t++) b->tok2q[t] = q;
+    return b;
+}
+orc_batch *orc_batch_load(const orc_index *ix, const char *qryfile) {
+    FILE *f = fopen(qryfile, "r");
+    if (!f) DIE("cannot open %s", qryfile);
+    VEC(int32_t) off = {0}, tok = {0};
+    char *line = NULL; size_t cap = 0;
+    while (getline(&line, &cap, f) != -1) {
+        VPUSH(off, (int32_t)tok.n);
+        char *save = NULL;
+        for (char *t = strtok_r(line, " ", &save); t && !isspace((unsigned char)*t); t = strtok_r(NULL, " ", &save)) {
+            size_t tl = strlen(t);
+            if (tl && t[tl - 1] == '\n') t[tl - 1] = 0;
+            int32_t id = strmap_get(ix->shash, t);
+            VPUSH(tok, id < 0 ? -1 : id);            /* OOV = -1 (Start.cu:97) */
+        }
+    }
+    free(line); fclose(f);
+    orc_batch *b = orc_batch_from_ids(off.v, (int32_t)off.n, tok.v, (int32_t)tok.n);
+    free(off.v); free(tok.v);
+    return b;
+}
+
+static void free_lex(orc_lexent *l, uint32_t n) { for (uint32_t i = 0; l && i < n; i++) free(l[i].text); free(l); }
+void orc_batch_free(orc_batch *b) {
+    if (!b) return;
+    free(b->qoff); free(b->qtok); free(b->tok2q); free(b->lm); free(b->up); free(b->down);
+    free(b->g1); free(b->p1); free(b->s1); free(b->hits1); free(b->g2); free(b->p2); free(b->s2); free(b->hits2);
+    for (int32_t q = 0; q < b->nq; q++) { if (b->qblocks) free(b->qblocks[q]); if (b->qone) free(b->qone[q]); if (b->qtwo) free(b->qtwo[q]); }
+    free(b->qblocks); free(b->nqblocks); free(b->qone); free(b->nqone); free(b->qtwo); free(b->nqtwo);
+    for (uint32_t i = 0; b->blockname && i < b->g; i++) free(b->blockname[i]);
+    free(b->blockname); free(b->blocks); free(b->r0); free(b->r1); free(b->r2);
+    free_lex(b->lex0, b->nl0); free_lex(b->lex1, b->nl1); free_lex(b->lex2, b->nl2);
+    free(b->rng0); free(b->rng1); free(b->rng2); free(b->tasks); free(b->task_fe); free(b->task_ef); free(b);
+}
+
+/* ------------------------------------------------------------------ */
+/* stage 1: K1 + K2 (SuffixArray.cu:402-767, 109-400)                   */
+/* The kernels are Manber-Myers searches with LCP tables whose result is exactly the SA
+ * interval of q[t..t+l) for l = 1..longestmatch(t), where a match never crosses a
+ * delimiter (token 1) or an OOV query token (-1) and is clipped to the query sentence.
+ * Restated as interval refinement one token at a time.  Intervals are kept for l <= 5:
+ * nothing downstream reads longer ones (ExtractPair.cu:2832, GappyLook.cu:224,235).      */
+/* ------------------------------------------------------------------ */
+void orc_sa_lookup(const orc_index *ix, orc_batch *b) {
+    double t0 = now_s();
+    int32_t T = b->ntok;
+    b->lm = xcalloc((size_t)T + 1, 4);
+    b->up = xmalloc(((size_t)T * 5 + 1) * 4); b->down = xmalloc(((size_t)T * 5 + 1) * 4);
+    for (int64_t i = 0; i < (int64_t)T * 5; i++) b->up[i] = b->down[i] = -1;
+    const int32_t *str = ix->str, *sa = ix->sa;
+    for (int32_t q = 0; q < b->nq; q++) {
+        int32_t off = b->qoff[q], len = b->qoff[q + 1] - off;
+        for (int32_t ti = 0; ti < len && ti < ORC_K1_THREADS; ti++) {   /* threadIdx.x = token, blockDim.x = 128 */
+            int32_t t = off + ti;
+            if (b->qtok[t] == -1) continue;
+            int64_t lo = 0, hi = (int64_t)ix->n - 1; int32_t l = 0;
+            while (l < len - ti && b->qtok[t + l] != -1) {
+                int32_t c = b->qtok[t + l];
+                int64_t a = lo, z = hi + 1;                      /* first m with key >= c */
+                while (a < z) { int64_t m = (a + z) >> 1; if (str[sa[m] + l] < c) a = m + 1; else z = m; }
+                int64_t first = a; z = hi + 1;                   /* first m with key > c */
+                while (a < z) { int64_t m = (a + z) >> 1; if (str[sa[m] + l] <= c) a = m + 1; else z = m; }
+                if (first >= a) break;
+                lo = first; hi = a - 1; l++;
+                if (l <= 5) { b->up[(int64_t)t * 5 + l - 1] = (int32_t)lo; b->down[(int64_t)t * 5 + l - 1] = (int32_t)hi; }
+            }
+            b->lm[t] = l;
+        }
+    }
+    b->t_lookup = now_s() - t0;
+}
+
+/* ------------------------------------------------------------------ */
+/* stage 2a: one-gap enumeration, sort, unique (SuffixArray.cu:928-1039,1598,1041-1068,1644-1719) */
+/* ------------------------------------------------------------------ */
+typedef struct { orc_gappat p; orc_gappy g; uint32_t ord; } enum1;
+static int cmp_enum1(const void *a, const void *b) {          /* oneGapEnumerationCompare (:51-67), made strict; ties keep emission order */
+    const enum1 *x = a, *y = b;
+    if (x->p.number != y->p.number) return x->p.number < y->p.number ? -1 : 1;
+    for (int i = 0; i < y->p.number; i++) if (x->p.pat[i] != y->p.pat[i]) return x->p.pat[i] < y->p.pat[i] ? -1 : 1;
+    return x->ord < y->ord ? -1 : x->ord > y->ord;
+}
+static int same_pat1(const orc_gappat *a, const orc_gappat *b) {   /* zeroOneDiff (:1041-1068) */
+    if (a->number != b->number) return 0;
+    for (int i = 0; i < b->number; i++) if (a->pat[i] != b->pat[i]) return 0;
+    return 1;
+}
+static void idlist_push(uint32_t ***lists, uint32_t **counts, int32_t q, uint32_t id) {
+    uint32_t n = (*counts)[q];
+    if ((n & (n + 1)) == 0 || n == 0) (*lists)[q] = xrealloc((*lists)[q], (size_t)(2 * n + 2) * sizeof(uint32_t));
+    (*lists)[q][n] = id; (*counts)[q] = n + 1;
+}
+
+static void one_gap_enumerate(orc_batch *b) {
+    int32_t T = b->ntok, nq = b->nq; const int32_t *qt = b->qtok;
+    VEC(enum1) ev = {0};
+    for (int32_t t = 0; t < T - 1; t++) {                      /* one CUDA thread per query token (:944-947) */
+        int32_t q = b->tok2q[t], end = b->qoff[q + 1];
+        if (t == end - 1 || t == end - 2) continue;
+        int32_t lms = b->lm[t];
+        for (int32_t al = 1; al <= lms; al++) {
+            for (int32_t s = t + al + ORC_MIN_GAP; s < end && s - t <= ORC_MAX_SPAN_PATTERN; s++) {
+                if (qt[s] == -1) continue;
+                int32_t lme = b->lm[s];
+                for (int32_t bl = 1; al + 1 + bl <= ORC_MAX_SYMBOLS && bl <= lme && s - t + bl - 1 <= ORC_MAX_SPAN_PATTERN; bl++) {
+                    enum1 e; memset(&e, 0, sizeof e);
+                    e.g.qrystart = t; e.g.a_len = (uint8_t)al; e.g.b_len = (uint8_t)bl; e.g.gap = (uint8_t)(s - t - al);
+                    int num = al + 1 + bl;
+                    for (int i = 0; i < ORC_MAX_SYMBOLS; i++) {
+                        if (i >= num) e.p.pat[i] = -2;
+                        else if (i < al) e.p.pat[i] = qt[t + i];
+                        else if (i == al) e.p.pat[i] = -1;
+                        else e.p.pat[i] = qt[s + i - 1 - al];
+                    }
+                    e.p.number = (uint8_t)num; e.ord = (uint32_t)ev.n;
+                    VPUSH(ev, e);
+                }
+            }
+        }
+    }
+    qsort(ev.v, ev.n, sizeof *ev.v, cmp_enum1);
+    b->e1 = (uint32_t)ev.n;
+    b->g1 = xmalloc(ev.n * sizeof *b->g1); b->p1 = xmalloc(ev.n * sizeof *b->p1);
+    b->s1 = xmalloc(ev.n * sizeof *b->s1);
+    b->qone = xcalloc(nq, sizeof *b->qone); b->nqone = xcalloc(nq, sizeof *b->nqone);
+    uint32_t d = 0; int32_t *seen = xmalloc((size_t)nq * 4); for (int32_t q = 0; q < nq; q++) seen[q] = -1;
+    for (uint32_t i = 0; i < ev.n; i++) {
+        b->g1[i] = ev.v[i].g; b->p1[i] = ev.v[i].p;
+        if (i == 0 || !same_pat1(&b->p1[i - 1], &b->p1[i])) {  /* head of a run: new distinct pattern (:1679-1697) */
+            orc_gapsearch *s = &b->s1[d];
+            s->position = i; s->gap = b->g1[i].gap; s->b_len = b->g1[i].b_len; s->qrystart = b->g1[i].qrystart; s->a_len = b->g1[i].a_len;
+            s->sa_start = s->sa_end = -1; d++;
+        }
+        int32_t q = b->tok2q[b->g1[i].qrystart];
+        if (seen[q] != (int32_t)(d - 1)) { seen[q] = (int32_t)(d - 1); idlist_push(&b->qone, &b->nqone, q, d - 1); } /* checkDup (:1713-1718) */
+    }
+    b->d1 = d; free(seen); free(ev.v);
+}
+
+/* ------------------------------------------------------------------ */
+/* stage 2b: oneGapLookUpSA (GappyLook.cu:128-474), one CUDA block per distinct pattern   */
+/* ------------------------------------------------------------------ */
+static int cmp_hit1(const void *a, const void *b) {
+    const orc_hit1 *x = a, *y = b;
+    if (x->position != y->position) return x->position < y->position ? -1 : 1;
+    if (x->str_position != y->str_position) return x->str_position < y->str_position ? -1 : 1;
+    return x->length < y->length ? -1 : x->length > y->length;
+}
+static void interval_of(const orc_batch *b, int32_t t, int len, int32_t *up, int32_t *down) {
+    *up = b->up[(int64_t)t * 5 + len - 1]; *down = b->down[(int64_t)t * 5 + len - 1];
+}
+static void one_gap_lookup(const orc_index *ix, orc_batch *b) {
+    const int32_t *str = ix->str, *sa = ix->sa, *qt = b->qtok;
+    VEC(orc_hit1) out = {0};
+    for (uint32_t id = 0; id < b->d1; id++) {
+        const orc_gapsearch *gs = &b->s1[id];
+        int al = gs->a_len, bl = gs->b_len; int32_t t = gs->qrystart, s = t + gs->gap + al;
+        if (gs->gap == 0 || t < 0) continue;
+        if (b->lm[s] < bl || b->lm[t] < al) continue;
+        int pre = pre_index(ix, qt[t + al - 1], qt[s]);
+        int64_t from, dis; int forward = 1;
+        if (pre == -1) {
+            int32_t u1, d1, u2, d2; interval_of(b, t, al, &u1, &d1); interval_of(b, s, bl, &u2, &d2);
+            if (d1 - u1 <= d2 - u2) { from = u1; dis = d1 - u1; forward = 1; } else { from = u2; dis = d2 - u2; forward = 0; }
+        } else { from = ix->pidx[pre].start; dis = (int64_t)ix->pidx[pre].end - (int64_t)ix->pidx[pre].start; }
+        if (pre != -1 && al == 1 && bl == 1 && dis >= 0) {      /* marker record (:258-272) */
+            orc_hit1 h = { id, (uint32_t)pre, 0 }; VPUSH(out, h); continue;
+        }
+        for (int64_t x = 0; x <= dis; x++) {
+            if (pre != -1) {                                     /* frequent-pair list (:289-334) */
+                int64_t ps = ix->phits[from + x].start; int pl = ix->phits[from + x].length; int ok = 1;
+                if (pl + 1 + al - 1 + bl - 1 > ORC_MAX_SPAN) ok = 0;
+                for (int k = 1; ok && k < al; k++) if (ps - k < 0 || str[ps - k] != qt[t + al - 1 - k]) ok = 0;
+                for (int k = 2; ok && k <= bl; k++) if (str[ps + pl + k - 1] != qt[s + k - 1]) ok = 0;
+                if (ok) { orc_hit1 h = { id, (uint32_t)(ps - al + 1), (uint8_t)(pl + al - 1 + bl - 1) }; VPUSH(out, h); }
+            } else if (forward) {                                /* scan right from a (:335-396) */
+                int64_t go = sa[from + x]; int move = 0, fl = 1;
+                while (fl) {
+                    if (move == 0 && str[go + al] < 2) fl = 0;
+                    int32_t tk = str[go + al + ORC_MIN_GAP + move];
+                    if (tk < 2) fl = 0;
+                    else if (fl && tk == qt[s]) {
+                        int mc = 1, stop = 0;
+                        while (!stop && mc < bl && al + ORC_MIN_GAP + move + 1 + mc <= ORC_MAX_SPAN) {
+                            int32_t r = str[go + al + ORC_MIN_GAP + move + mc];
+                            if (r < 2) { stop = 1; fl = 0; } else if (r == qt[s + mc]) mc++; else stop = 1;
+                        }
+                        if (mc == bl && orc_check_gap(ix, (uint32_t)(go + al), (uint32_t)(go + al + ORC_MIN_GAP + move + bl - 1 - bl))) {
+                            orc_hit1 h = { id, (uint32_t)go, (uint8_t)(al + ORC_MIN_GAP + move + bl - 1) }; VPUSH(out, h);
+                        }
+                    }
+                    move++;
+                    if (al + ORC_MIN_GAP + move + bl > ORC_MAX_SPAN) fl = 0;
+                }
+            } else {                                             /* scan left from b (:397-470) */
+                int64_t go = sa[from + x]; int move = 0, fl = 1;
+                while (fl) {
+                    if (move == 0 && (go - 1 < 0 || str[go - 1] < 2)) fl = 0;
+                    int32_t tk = go - 1 - ORC_MIN_GAP - move < 0 ? -1 : str[go - 1 - ORC_MIN_GAP - move];
+                    if (tk < 2) fl = 0;
+                    else if (fl && tk == qt[t + al - 1]) {
+                        int mc = 1, stop = 0;
+                        while (!stop && mc < al && bl + ORC_MIN_GAP + move + 1 + mc <= ORC_MAX_SPAN) {
+                            int32_t r = go - 1 - ORC_MIN_GAP - move - mc < 0 ? -1 : str[go - 1 - ORC_MIN_GAP - move - mc];
+                            if (r < 2) { stop = 1; fl = 0; } else if (r == qt[t + al - 1 - mc]) mc++; else stop = 1;
+                        }
+                        if (mc == al && orc_check_gap(ix, (uint32_t)(go - 1 - ORC_MIN_GAP - move + 1), (uint32_t)(go - 1))) {
+                            orc_hit1 h = { id, (uint32_t)(go - 1 - ORC_MIN_GAP - move - al + 1), (uint8_t)(bl + ORC_MIN_GAP + move + al - 1) }; VPUSH(out, h);
+                        }
+                    }
+                    move++;
+                    if (al + ORC_MIN_GAP + move + bl > ORC_MAX_SPAN) fl = 0;
+                }
+            }
+        }
+    }
+    qsort(out.v, out.n, sizeof *out.v, cmp_hit1);
+    b->h1 = (uint32_t)out.n; b->hits1 = out.v;
+    for (uint32_t i = 0; i < b->h1; i++) {                       /* start/end_on_salist (:1854-1875) */
+        orc_gapsearch *gs = &b->s1[out.v[i].position];
+        if (gs->sa_start == -1) gs->sa_start = (int32_t)i;
+        gs->sa_end = (int32_t)i;
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* stage 2c: two-gap enumeration (SuffixArray.cu:816-926, 1989, 1070-1105, 2062-2097)      */
+/* ------------------------------------------------------------------ */
+typedef struct { orc_twogappat p; orc_twogappy g; uint32_t ord; } enum2;
+static int cmp_enum2(const void *a, const void *b) {          /* twoGapEnumerationCompare (:31-49) */
+    const enum2 *x = a, *y = b;
+    if (x->p.blockid != y->p.blockid) return x->p.blockid < y->p.blockid ? -1 : 1;
+    if (x->p.number != y->p.number) return x->p.number < y->p.number ? -1 : 1;
+    for (int i = 0; i < y->p.number && i < 1; i++) if (x->p.pat[i] != y->p.pat[i]) return x->p.pat[i] < y->p.pat[i] ? -1 : 1;
+    return x->ord < y->ord ? -1 : x->ord > y->ord;
+}
+static void two_gap_enumerate(orc_batch *b) {
+    int32_t T = b->ntok, nq = b->nq; const int32_t *qt = b->qtok;
+    VEC(enum2) ev = {0};
+    for (uint32_t id = 0; id < b->d1; id++) {                   /* one CUDA block per one-gap pattern */
+        const orc_gapsearch *gs = &b->s1[id];
+        if (gs->sa_start == -1 || gs->sa_end == -1) continue;
+        int limit = ORC_MAX_SYMBOLS - 1 - 1 - gs->a_len - gs->b_len;
+        if (limit < 1) continue;
+        uint32_t ender = id == b->d1 - 1 ? b->e1 : b->s1[id + 1].position;
+        for (uint32_t x = gs->position; x < ender; x++) {       /* every query instance of the pattern */
+            const orc_gappy *g = &b->g1[x];
+            int32_t sstart = g->qrystart + g->a_len + g->gap + g->b_len - 1, s = sstart + ORC_MIN_GAP + 1;
+            if (sstart > T - 1) continue;
+            int32_t end = b->qoff[b->tok2q[sstart] + 1];
+            for (; s < end; s++) {
+                int32_t lme = b->lm[s];
+                for (int it = 1; it <= limit && it <= lme && s - g->qrystart + it - 1 <= ORC_MAX_SPAN_PATTERN; it++) {
+                    enum2 e; memset(&e, 0, sizeof e);
+                    e.g.c_len = (uint8_t)it; e.g.gap2 = (uint32_t)s; e.g.blockid = id;
+                    e.p.pat[0] = 0 < it ? qt[s] : -2; e.p.number = (uint8_t)it; e.p.blockid = id; e.ord = (uint32_t)ev.n;
+                    VPUSH(ev, e);
+                }
+            }
+        }
+    }
+    qsort(ev.v, ev.n, sizeof *ev.v, cmp_enum2);
+    b->e2 = (uint32_t)ev.n;
+    b->g2 = xmalloc(ev.n * sizeof *b->g2); b->p2 = xmalloc(ev.n * sizeof *b->p2); b->s2 = xmalloc(ev.n * sizeof *b->s2);
+    b->qtwo = xcalloc(nq, sizeof *b->qtwo); b->nqtwo = xcalloc(nq, sizeof *b->nqtwo);
+    uint32_t d = 0; int32_t *seen = xmalloc((size_t)nq * 4); for (int32_t q = 0; q < nq; q++) seen[q] = -1;
+    for (uint32_t i = 0; i < ev.n; i++) {
+        b->g2[i] = ev.v[i].g; b->p2[i] = ev.v[i].p;
+        int head = i == 0 || b->p2[i - 1].number != b->p2[i].number || b->p2[i - 1].blockid != b->p2[i].blockid;
+        for (int k = 0; !head && k < b->p2[i].number && k < 1; k++) if (b->p2[i - 1].pat[k] != b->p2[i].pat[k]) head = 1;
+        if (head) {
+            orc_twogapsearch *s = &b->s2[d];
+            s->blockid = b->g2[i].blockid; s->position = i; s->c_len = b->g2[i].c_len; s->gap2 = b->g2[i].gap2; s->sa_start = s->sa_end = -1; d++;
+        }
+        int32_t q = b->tok2q[b->g2[i].gap2];
+        if (seen[q] != (int32_t)(d - 1)) { seen[q] = (int32_t)(d - 1); idlist_push(&b->qtwo, &b->nqtwo, q, d - 1); }
+    }
+    b->d2 = d; free(seen); free(ev.v);
+}
+
+/* ------------------------------------------------------------------ */
+/* stage 2d: twoGapLookUpSA (GappyLook.cu:476-737)                      */
+/* ------------------------------------------------------------------ */
+static int cmp_hit2(const void *a, const void *b) {
+    const orc_hit2 *x = a, *y = b;
+    if (x->position != y->position) return x->position < y->position ? -1 : 1;
+    if (x->str_position != y->str_position) return x->str_position < y->str_position ? -1 : 1;
+    if (x->length != y->length) return x->length < y->length ? -1 : 1;
+    return x->length2 < y->length2 ? -1 : x->length2 > y->length2;
+}
+static void two_gap_lookup(const orc_index *ix, orc_batch *b) {
+    const int32_t *str = ix->str, *qt = b->qtok;
+    VEC(orc_hit2) out = {0};
+    for (uint32_t id = 0; id < b->d2; id++) {
+        const orc_twogapsearch *ts = &b->s2[id]; const orc_gapsearch *gs = &b->s1[ts->blockid];
+        int32_t s0 = gs->sa_start, e0 = gs->sa_end;
+        if (s0 == -1 && e0 == -1) continue;
+        int cl = ts->c_len; if (cl != 1) continue;
+        int32_t c = qt[ts->gap2]; if (c < 2) continue;
+        int64_t dis = (int64_t)e0 - s0 + 1, base = s0; int marker = 0;
+        if (dis == 1 && b->hits1[s0].length == 0) {              /* the one-gap pattern is a frequent-pair marker (:568-583) */
+            int pre = (int)b->hits1[s0].str_position; marker = 1;
+            dis = (int64_t)ix->pidx[pre].end - (int64_t)ix->pidx[pre].start + 1; base = ix->pidx[pre].start;
+            if (gs->a_len != 1 || gs->b_len != 1) continue;
+        }
+        for (int64_t x = 0; x < dis; x++) {
+            uint32_t ps; uint8_t pl;
+            if (marker) { ps = ix->phits[base + x].start; pl = ix->phits[base + x].length; }
+            else { ps = b->hits1[base + x].str_position; pl = b->hits1[base + x].length; if (pl == 0) break; }
+            int64_t go = (int64_t)ps + pl; int move = 0, fl = 1;
+            while (fl) {
+                if (move == 0 && str[go + ORC_MIN_GAP] < 2) fl = 0;
+                int32_t tk = str[go + 1 + ORC_MIN_GAP + move];
+                if (pl + 1 + ORC_MIN_GAP + move + 1 > ORC_MAX_SPAN) fl = 0;
+                if (tk < 2) fl = 0;
+                else if (fl && tk == c) {
+                    if (orc_check_gap(ix, ps + pl + 1, (uint32_t)(ps + 1 + pl + ORC_MIN_GAP + move - 1))) {
+                        orc_hit2 h = { id, ps, pl, (uint8_t)(pl + 1 + ORC_MIN_GAP + move + cl - 1) }; VPUSH(out, h);
+                    }
+                }
+                move++;
+            }
+        }
+    }
+    qsort(out.v, out.n, sizeof *out.v, cmp_hit2);
+    b->h2 = (uint32_t)out.n; b->hits2 = out.v;
+    for (uint32_t i = 0; i < b->h2; i++) {
+        orc_twogapsearch *ts = &b->s2[out.v[i].position];
+        if (ts->sa_start == -1) ts->sa_start = (int32_t)i;
+        ts->sa_end = (int32_t)i;
+    }
+}
+
+void orc_gappy_search(const orc_index *ix, orc_batch *b) {
+    double t0 = now_s();
+    one_gap_enumerate(b);
+    one_gap_lookup(ix, b);
+    two_gap_enumerate(b);
+    two_gap_lookup(ix, b);
+    b->t_gappy = now_s() - t0;
+}
+
+/* ------------------------------------------------------------------ */
+/* GenerateBlocks (ExtractPair.cu:2742-2903): distinct contiguous phrases in first-seen
+ * order over (query, token, l = 1..min(longestmatch,5)); per-query de-duplicated lists.  */
+/* ------------------------------------------------------------------ */
+typedef struct { int64_t *key; uint32_t *val; size_t cap, n; } blkmap;
+static uint32_t blkmap_find_or_add(blkmap *m, int32_t up, int32_t down, int len, uint32_t newid, int *added) {
+    if ((m->n + 1) * 2 > m->cap) {
+        size_t oc = m->cap; int64_t *ok = m->key; uint32_t *ov = m->val;
+        m->cap = oc ? oc * 2 : 1024; m->key = xmalloc(m->cap * 8); m->val = xmalloc(m->cap * 4); memset(m->key, 0xFF, m->cap * 8);
+        for (size_t j = 0; j < oc; j++) if (ok[j] != -1) { size_t i = (size_t)((uint64_t)ok[j] * 0x9E3779B97F4A7C15ull >> 20) & (m->cap - 1); while (m->key[i] != -1) i = (i + 1) & (m->cap - 1); m->key[i] = ok[j]; m->val[i] = ov[j]; }
+        free(ok); free(ov);
+    }
+    (void)down;                                   /* key "up|down|len": down is a function of (up,len) */
+    int64_t k = ((int64_t)up << 3) | len;
+    size_t i = (size_t)((uint64_t)k * 0x9E3779B97F4A7C15ull >> 20) & (m->cap - 1);
+    while (m->key[i] != -1) { if (m->key[i] == k) { *added = 0; return m->val[i]; } i = (i + 1) & (m->cap - 1); }
+    m->key[i] = k; m->val[i] = newid; m->n++; *added = 1; return newid;
+}
+static void generate_blocks(const orc_index *ix, orc_batch *b) {
+    VEC(orc_block) blk = {0}; VEC(char *) names = {0};
+    blkmap m = {0};
+    b->qblocks = xcalloc(b->nq, sizeof *b->qblocks); b->nqblocks = xcalloc(b->nq, sizeof *b->nqblocks);
+    uint32_t *lastq = NULL; size_t lastq_cap = 0;   /* removalDUP: last query that listed each block */
+    char buf[4096];
+    for (int32_t q = 0; q < b->nq; q++) {
+        for (int32_t j = b->qoff[q]; j < b->qoff[q + 1]; j++) {
+            for (int ct = 1; ct <= b->lm[j] && ct <= ORC_LONGEST_SRC; ct++) {
+                int32_t up = b->up[(int64_t)j * 5 + ct - 1], down = b->down[(int64_t)j * 5 + ct - 1];
+                int added; uint32_t id = blkmap_find_or_add(&m, up, down, ct, (uint32_t)blk.n, &added);
+                if (blk.n + 1 > lastq_cap) { size_t nc = lastq_cap ? lastq_cap * 2 : 1024; lastq = xrealloc(lastq, nc * 4); memset(lastq + lastq_cap, 0xFF, (nc - lastq_cap) * 4); lastq_cap = nc; }
+                if (added) {
+                    orc_block k; k.start = up; k.end = down; k.matchlen = ct; k.string_start = ix->sa[up];
+                    VPUSH(blk, k);
+                    size_t o = 0; buf[0] = 0;
+                    for (int s = 0; s < ct; s++) o += (size_t)snprintf(buf + o, sizeof buf - o, s ? " %s" : "%s", ix->svocab[ix->str[k.string_start + s]]);
+                    VPUSH(names, xstrdup(buf));
+                }
+                if (lastq[id] != (uint32_t)q) { lastq[id] = (uint32_t)q; idlist_push(&b->qblocks, &b->nqblocks, q, id); }
+            }
+        }
+    }
+    b->g = (uint32_t)blk.n; b->blocks = blk.v; b->blockname = names.v;
+    free(m.key); free(m.val); free(lastq);
+}
+
+/* ------------------------------------------------------------------ */
+/* alignment helpers shared by the extraction kernels                  */
+/* ------------------------------------------------------------------ */
+/* consistent(), ExtractPair.cu:103-133 */
+static int tight(const orc_index *ix, int start, int end, int start_chk, int end_chk, int src0) {
+    unsigned char L, R, mn = 255, mx = 0;
+    for (int k = start; k <= end; k++) {
+        L = ix->ltar[k]; R = ix->rtar[k];
+        if (L == 255 || R == 255) { }
+        else if (k == start) { mn = L; mx = R; }
+        else { if (mn > L) mn = L; if (mx < R) mx = R; }
+    }
+    return !(src0 + mn != start_chk || src0 + mx != end_chk);
+}
+/* checkBoundaryFast, ExtractPair.cu:135-194 */
+static int span_fast(const orc_index *ix, uint32_t start, uint32_t ender, unsigned char *mnL, unsigned char *mxR, int *stb, int *tempind) {
+    unsigned char L, R, mn = 255, mx = 0; *stb = -1; *tempind = 0;
+    for (uint32_t k = start; k <= ender; k++) {
+        uint32_t w = ix->rlp[k]; L = (w >> 24) & 0xFF; R = (w >> 16) & 0xFF;
+        if ((L == 255 || R == 255) && (k == start || k == ender)) return 0;
+        else if (L == 255 || R == 255) { }
+        else if (k == start) { *tempind = (int)k - (int)((w >> 8) & 0xFF) - 1; *stb = *tempind == -1 ? 0 : (int)ix->rlp[*tempind]; mn = L; mx = R; }
+        else { if (mn > L) mn = L; if (mx < R) mx = R; }
+    }
+    if (mn <= mx && mx - mn < ORC_MAX_SPAN) { (*tempind)++; *mnL = mn; *mxR = mx; return 1; }
+    return 0;
+}
+/* checkBoundaryFast2, ExtractPair.cu:196-250 */
+static int span_fast2(const orc_index *ix, uint32_t start, uint32_t ender, uint32_t *ts, uint32_t *te) {
+    unsigned char L, R, mn = 255, mx = 0; int stb = -1, tempind = 0;
+    for (uint32_t k = start; k <= ender; k++) {
+        uint32_t w = ix->rlp[k]; L = (w >> 24) & 0xFF; R = (w >> 16) & 0xFF;
+        if ((L == 255 || R == 255) && (k == start || k == ender)) return 0;
+        else if (L == 255 || R == 255) { }
+        else if (k == start) { tempind = (int)k - (int)((w >> 8) & 0xFF) - 1; stb = tempind == -1 ? 0 : (int)ix->rlp[tempind]; mn = L; mx = R; }
+        else { if (mn > L) mn = L; if (mx < R) mx = R; }
+    }
+    *ts = (uint32_t)(mn + stb); *te = (uint32_t)(mx + stb);
+    return mn <= mx && mx - mn < ORC_MAX_SPAN;
+}
+/* checkBoundary, ExtractPair.cu:252-342: 0 plain false, 1 ok, 2 front unaligned, 3 end unaligned, 4 both */
+static int span_code(const orc_index *ix, uint32_t start, uint32_t ender, uint32_t *ts, uint32_t *te) {
+    unsigned char L, R, mn = 255, mx = 0; int stb = -1, tempind = 0, wrong = 0;
+    for (uint32_t k = start; k <= ender; k++) {
+        uint32_t w = ix->rlp[k]; L = (w >> 24) & 0xFF; R = (w >> 16) & 0xFF;
+        if ((L == 255 || R == 255) && (k == start || k == ender)) {
+            if (start == ender && wrong == 0) wrong = 4;
+            else if (wrong == 0 && k == start) wrong = 2;
+            else if (wrong == 0 && k == ender) wrong = 3;
+            else wrong = 4;
+            if (k == start) { tempind = (int)k - (int)((w >> 8) & 0xFF) - 1; stb = tempind == -1 ? 0 : (int)ix->rlp[tempind]; }
+        } else if (L == 255 || R == 255) { }
+        else if (k == start) { tempind = (int)k - (int)((w >> 8) & 0xFF) - 1; stb = tempind == -1 ? 0 : (int)ix->rlp[tempind]; mn = L; mx = R; }
+        else { if (mn > L) mn = L; if (mx < R) mx = R; }
+    }
+    *ts = (uint32_t)(mn + stb); *te = (uint32_t)(mx + stb);
+    if (wrong) return wrong;
+    if (mn <= mx && mx - mn < ORC_MAX_SPAN) { tempind++; if (tight(ix, (int)*ts, (int)*te, (int)start, (int)ender, tempind)) return 1; }
+    return 0;
+}
+
+/* uniform sampling test of the kernels (ExtractPair.cu:1143-1160, 454-471, 955-972):
+ * with n > S occurrences only indices ROUND(k * (float)n/(float)S), k < S, are processed. */
+int orc_sample_hit(int n, int sampler, int idx) {
+    if (n <= sampler) return 1;
+    float step = (float)n / (float)sampler;
+    for (int k = 0; k < sampler; k++) {
+        int togo = (int)(k * step + 0.5);
+        if (togo == idx) return 1;
+        if (togo > idx) return 0;
+    }
+    return 0;
+}
+
+typedef struct { VEC(orc_rule0) r0; VEC(orc_rule1) r1; VEC(orc_rule2) r2; } rulebuf;
+#define KTHREADS 512   /* THREADS_PER_BLOCK, ExtractPair.cu:9 */
+
+/* ------------------------------------------------------------------ */
+/* extractConsistentPairs_Gappy, ExtractPair.cu:1055-1795: ab, Xab, abX, XabX for one
+ * sampled corpus occurrence of contiguous block bnum.  Returns 1 when the CUDA thread
+ * would have hit one of the reference's `printf; return;` guards (thread dies).        */
+/* ------------------------------------------------------------------ */
+static int gappy_occurrence(const orc_index *ix, uint32_t bnum, uint32_t G, int lm, int current, rulebuf *out) {
+    const int32_t *str = ix->str; const uint32_t *RLP = ix->rlp;
+    int current_str = ix->sa[current], tempind = 0, stb = -1, ender;
+    unsigned char L, R, min_L = 255, max_R = 0; uint32_t w;
+    int abX = 1, Xab = 1, XabX = 1, ab = 1, XabNo = 1, abXNo = 1, next;
+    uint8_t XabCount = 0, abXCount = 0;
+    uint32_t g1s = 0, g1e = 0, g2s = 0, g2e = 0, ts = 0, te = 0, tmp;
+    for (int k = current_str; k < current_str + lm; k++) {           /* :1178-1212 */
+        w = RLP[k]; L = (w >> 24) & 0xFF; R = (w >> 16) & 0xFF;
+        if (k == current_str) { tempind = k - (int)((w >> 8) & 0xFF) - 1; stb = tempind == -1 ? 0 : (int)RLP[tempind]; }
+        if ((L == 255 || R == 255) && (k == current_str || k == current_str + lm - 1)) { ab = 0; if (k == current_str) abXNo = 0; else XabNo = 0; }
+        else if (L == 255 || R == 255) { }
+        else { if (min_L > L) min_L = L; if (max_R < R) max_R = R; }
+    }
+    if (min_L > max_R || max_R - min_L >= ORC_MAX_SPAN) { abX = Xab = XabX = ab = 0; }
+    tempind++; ender = current_str + lm - 1;
+    if (ab && tight(ix, min_L + stb, max_R + stb, current_str, ender, tempind)) {
+        orc_rule0 r; r.tar_start = min_L + stb; r.tar_end = (uint8_t)(max_R - min_L); r.block = (int32_t)bnum; VPUSH(out->r0, r);
+    }
+    if (lm + 1 > ORC_MAX_SYMBOLS) { abX = 0; Xab = 0; }
+    if (lm + 2 > ORC_MAX_SYMBOLS) XabX = 0;
+    unsigned char i = 1, mnXab = 255, mxXab = 0, mnabX = 255, mxabX = 0, mnXX = 255, mxXX = 0;
+    while (lm + i <= ORC_MAX_SPAN && (abXNo || XabNo || XabX)) {        /* :1280 */
+        if (Xab && current_str - i >= 0 && str[current_str - i] >= 2) {  /* grow a gap to the left */
+            next = 1;
+            w = RLP[current_str - i]; L = (w >> 24) & 0xFF; R = (w >> 16) & 0xFF;
+            if (L == 255 || R == 255) { next = 0; if (i == 1) { Xab = 0; XabX = 0; } }
+            else { if (mnXab > L) mnXab = L; if (mxXab < R) mxXab = R; }
+            if (next && mnXab > mxXab) return 1;
+            if (mxXab - mnXab >= ORC_MAX_SPAN) { next = 0; Xab = 0; }
+            if (next) {
+                g1s = (uint32_t)(stb + mnXab); g1e = (uint32_t)(stb + mxXab);
+                if (g1s > g1e) return 1;
+                next = tight(ix, (int)g1s, (int)g1e, current_str - i, current_str - 1, tempind);
+                if (next) XabCount = i;
+            }
+            if (XabNo && next) {
+                ts = (uint32_t)(stb + (mnXab < min_L ? mnXab : min_L));
+                te = (uint32_t)(stb + (mxXab < max_R ? max_R : mxXab));
+                if (ts > te) return 1;
+                if (te - ts >= ORC_MAX_SPAN) { next = 0; Xab = 0; }
+                if (next) next = tight(ix, (int)ts, (int)te, current_str - i, ender, tempind);
+            }
+            if (XabNo && next) {
+                orc_rule1 r; r.tstart = ts; r.end = (uint8_t)(te - ts); r.gap1 = (uint8_t)(g1s - ts); r.gap1_1 = (uint8_t)(g1e - ts); r.id = (int32_t)bnum;
+                VPUSH(out->r1, r); XabNo = 0;
+            }
+        } else Xab = 0;
+
+        if (abX && str[ender + i] >= 2) {                               /* grow a gap to the right, :1403 */
+            next = 1;
+            w = RLP[ender + i]; L = (w >> 24) & 0xFF; R = (w >> 16) & 0xFF;
+            if (L == 255 || R == 255) { next = 0; if (i == 1) { abX = 0; XabX = 0; } }
+            else { if (mnabX > L) mnabX = L; if (mxabX < R) mxabX = R; }
+            if (next && mnabX > mxabX) return 1;
+            if (mxabX - mnabX >= ORC_MAX_SPAN) { next = 0; abX = 0; }
+            if (next) {
+                g1s = (uint32_t)(stb + mnabX); g1e = (uint32_t)(stb + mxabX);
+                if (g1s > g1e) return 1;
+                next = tight(ix, (int)g1s, (int)g1e, ender + 1, ender + i, tempind);
+                if (next) abXCount = i;
+            }
+            if (abXNo && next) {
+                ts = (uint32_t)(stb + (mnabX < min_L ? mnabX : min_L));
+                te = (uint32_t)(stb + (mxabX < max_R ? max_R : mxabX));
+                if (ts > te) return 1;
+                if (te - ts >= ORC_MAX_SPAN) { next = 0; abX = 0; }
+                if (next) next = tight(ix, (int)ts, (int)te, current_str, ender + i, tempind);
+            }
+            if (abXNo && next) {
+                orc_rule1 r; r.tstart = ts; r.end = (uint8_t)(te - ts); r.gap1 = (uint8_t)(g1s - ts); r.gap1_1 = (uint8_t)(g1e - ts); r.id = (int32_t)(G + bnum);
+                VPUSH(out->r1, r); abXNo = 0;
+            }
+        } else abX = 0;
+
+        if (XabX && (abX || Xab)) {                                     /* :1514 */
+            if (XabCount == i) {                                         /* left gap just became valid: try right gaps 1..abXCount */
+                mnXX = 255; mxXX = 0;
+                for (uint8_t ic = 1; XabX && ic <= abXCount; ic++) {
+                    next = 1;
+                    if (ic + XabCount + lm <= ORC_MAX_SPAN) {
+                        w = RLP[ender + ic]; L = (w >> 24) & 0xFF; R = (w >> 16) & 0xFF;
+                        if (L == 255 || R == 255) { next = 0; if (i == 1) return 1; }
+                        else { if (mnXX > L) mnXX = L; if (mxXX < R) mxXX = R; }
+                    } else { next = 0; ic = abXCount + 1; }
+                    if (next && mxXX - mnXX >= ORC_MAX_SPAN) { next = 0; ic = abXCount + 1; }
+                    if (next) {
+                        g2s = (uint32_t)(stb + mnXX); g2e = (uint32_t)(stb + mxXX);
+                        if (mnXX > mxXX) return 1;
+                        next = tight(ix, (int)g2s, (int)g2e, ender + 1, ender + ic, tempind);
+                    }
+                    if (next) {
+                        tmp = mnXX < mnXab ? mnXX : mnXab; if (tmp > min_L) tmp = min_L; ts = (uint32_t)stb + tmp;
+                        tmp = mxXX < mxXab ? mxXab : mxXX; if (tmp < max_R) tmp = max_R; te = (uint32_t)stb + tmp;
+                        if (ts > te) return 1;
+                        if (te - ts >= ORC_MAX_SPAN) { next = 0; ic = abXCount + 1; }
+                        if (next) next = tight(ix, (int)ts, (int)te, current_str - XabCount, ender + ic, tempind);
+                        if (next) {
+                            g1s = (uint32_t)(stb + mnXab); g1e = (uint32_t)(stb + mxXab);
+                            orc_rule2 r; r.tstart = ts; r.end = (uint8_t)(te - ts); r.gap1 = (uint8_t)(g1s - ts); r.gap1_1 = (uint8_t)(g1e - ts);
+                            r.gap2 = (uint8_t)(g2s - ts); r.gap2_1 = (uint8_t)(g2e - ts); r.id = (int32_t)bnum;
+                            VPUSH(out->r2, r); XabX = 0;
+                        }
+                    }
+                }
+            }
+            if (XabX && abXCount == i) {                                 /* right gap just became valid: try left gaps 1..XabCount */
+                mnXX = 255; mxXX = 0;
+                for (uint8_t ic = 1; XabX && ic <= XabCount; ic++) {
+                    next = 1;
+                    if (ic + abXCount + lm <= ORC_MAX_SPAN) {
+                        w = RLP[current_str - ic]; L = (w >> 24) & 0xFF; R = (w >> 16) & 0xFF;
+                        if (L == 255 || R == 255) { next = 0; if (i == 1) return 1; }
+                        else { if (mnXX > L) mnXX = L; if (mxXX < R) mxXX = R; }
+                    } else { ic = XabCount + 1; next = 0; }
+                    if (next && mxXX - mnXX >= ORC_MAX_SPAN) { ic = XabCount + 1; next = 0; }
+                    if (next) {
+                        g1s = (uint32_t)(stb + mnXX); g1e = (uint32_t)(stb + mxXX);
+                        if (mnXX > mxXX) return 1;
+                        next = tight(ix, (int)g1s, (int)g1e, current_str - ic, current_str - 1, tempind);
+                    }
+                    if (next) {
+                        tmp = mnXX < mnabX ? mnXX : mnabX; if (tmp > min_L) tmp = min_L; ts = (uint32_t)stb + tmp;
+                        tmp = mxXX < mxabX ? mxabX : mxXX; if (tmp < max_R) tmp = max_R; te = (uint32_t)stb + tmp;
+                        if (ts > te) return 1;
+                        if (te - ts >= ORC_MAX_SPAN) { next = 0; ic = XabCount + 1; }
+                        if (next) next = tight(ix, (int)ts, (int)te, current_str - ic, ender + abXCount, tempind);
+                        if (next) {
+                            g2s = (uint32_t)(stb + mnabX); g2e = (uint32_t)(stb + mxabX);
+                            orc_rule2 r; r.tstart = ts; r.end = (uint8_t)(te - ts); r.gap1 = (uint8_t)(g1s - ts); r.gap1_1 = (uint8_t)(g1e - ts);
+                            r.gap2 = (uint8_t)(g2s - ts); r.gap2_1 = (uint8_t)(g2e - ts); r.id = (int32_t)bnum;
+                            VPUSH(out->r2, r); XabX = 0;
+                        }
+                    }
+                }
+            }
+        } else XabX = 0;
+
+        if (!XabX) { if (!Xab && XabNo) XabNo = 0; if (!abX && abXNo) abXNo = 0; }   /* :1782-1789 */
+        i++;
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* extractConsistentPairs_TwoGap, ExtractPair.cu:891-1053: aXbXc         */
+/* ------------------------------------------------------------------ */
+static int twogap_occurrence(const orc_index *ix, const orc_batch *b, uint32_t id, const orc_hit2 *h, rulebuf *out) {
+    const orc_twogapsearch *ts2 = &b->s2[id]; const orc_gapsearch *gs = &b->s1[ts2->blockid];
+    uint32_t cur = h->str_position, fe = h->length, se = h->length2, g1s = 0, g1e = 0, g2s = 0, g2e = 0, ts = 0, te = 0;
+    if (h->position != id) return 1;
+    int next = span_fast2(ix, cur + gs->a_len, cur + fe - gs->b_len, &g1s, &g1e);
+    if (next) next = span_fast2(ix, cur + fe + 1, cur + se - ts2->c_len, &g2s, &g2e);
+    if (!next) return 1;
+    if (span_code(ix, cur, cur + se, &ts, &te) == 1) {
+        orc_rule2 r; r.tstart = ts; r.end = (uint8_t)(te - ts); r.gap1 = (uint8_t)(g1s - ts); r.gap1_1 = (uint8_t)(g1e - ts);
+        r.gap2 = (uint8_t)(g2s - ts); r.gap2_1 = (uint8_t)(g2e - ts); r.id = (int32_t)id; VPUSH(out->r2, r);
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* extractConsistentPairs_OneGap, ExtractPair.cu:351-889: aXb, then XaXb / aXbX          */
+/* ------------------------------------------------------------------ */
+static int onegap_occurrence(const orc_index *ix, uint32_t id, uint32_t D1, int al, int bl, uint32_t cur, unsigned char firstEnd, rulebuf *out) {
+    const int32_t *str = ix->str; const uint32_t *RLP = ix->rlp;
+    unsigned char min_L = 255, max_R = 0, L, R; int stb = -1, tempind = -1, next = 1, left = 1, right = 1;
+    uint32_t g1s, g1e, ts = 0, te = 0, g2s, g2e, w;
+    if (cur + firstEnd - bl > ix->n) return 1;
+    uint32_t ender = cur + firstEnd;
+    int firstGap = span_fast(ix, cur + al, ender - bl, &min_L, &max_R, &stb, &tempind);
+    if (!firstGap) return 1;
+    if (tempind == -1 || stb == -1 || min_L > max_R) return 1;
+    g1s = (uint32_t)(min_L + stb); g1e = (uint32_t)(max_R + stb);
+    int code = span_code(ix, cur, ender, &ts, &te);
+    min_L = (unsigned char)(ts - (uint32_t)stb); max_R = (unsigned char)(te - (uint32_t)stb);
+    if (code == 0) next = 0; else if (code == 1) next = 1;
+    else if (code == 2) { next = 0; right = 0; } else if (code == 3) { next = 0; left = 0; } else { next = 0; left = 0; right = 0; }
+    if ((ts == 0 && te == 0) || min_L > max_R || g1s < ts || g1e > te) return 1;       /* :591-595 */
+    if (next) {
+        orc_rule1 r; r.tstart = ts; r.end = (uint8_t)(te - ts); r.gap1 = (uint8_t)(g1s - ts); r.gap1_1 = (uint8_t)(g1e - ts); r.id = (int32_t)id;
+        VPUSH(out->r1, r);
+    }
+    unsigned char mnL = 255, mxL = 0, mnR = 255, mxR = 0;
+    if (al + bl + 1 + 1 <= ORC_MAX_SYMBOLS) {
+        uint32_t og1s = g1s, og1e = g1e; uint8_t i = 1;
+        while (firstEnd + 1 + i <= ORC_MAX_SPAN && (left || right)) {
+            if (left && (int)(cur - i) >= 0 && str[cur - i] >= 2) {       /* XaXb, :639-757 */
+                next = 1; g1s = g1e = 0;
+                w = RLP[cur - i]; L = (w >> 24) & 0xFF; R = (w >> 16) & 0xFF;
+                if (L == 255 || R == 255) { next = 0; if (i == 1) left = 0; }
+                else { if (mnL > L) mnL = L; if (mxL < R) mxL = R; }
+                if (next && mnL > mxL) return 1;
+                if (mxL - mnL >= ORC_MAX_SPAN) { next = 0; left = 0; }
+                if (next) { g1s = (uint32_t)(stb + mnL); g1e = (uint32_t)(stb + mxL); next = tight(ix, (int)g1s, (int)g1e, (int)(cur - i), (int)cur - 1, tempind); }
+                if (next) {
+                    ts = (uint32_t)(stb + (mnL < min_L ? mnL : min_L)); te = (uint32_t)(stb + (mxL < max_R ? max_R : mxL));
+                    if (ts > te) return 1;
+                    if (te - ts >= ORC_MAX_SPAN) { next = 0; left = 0; }
+                    if (next) next = tight(ix, (int)ts, (int)te, (int)(cur - i), (int)ender, tempind);
+                }
+                if (next) {
+                    orc_rule2 r; r.tstart = ts; r.end = (uint8_t)(te - ts); r.gap1 = (uint8_t)(g1s - ts); r.gap1_1 = (uint8_t)(g1e - ts);
+                    r.gap2 = (uint8_t)(og1s - ts); r.gap2_1 = (uint8_t)(og1e - ts); r.id = (int32_t)id; VPUSH(out->r2, r); left = 0;
+                }
+            } else left = 0;
+            if (right && str[ender + i] >= 2) {                            /* aXbX, :763-877 */
+                next = 1; g2s = g2e = 0;
+                w = RLP[ender + i]; L = (w >> 24) & 0xFF; R = (w >> 16) & 0xFF;
+                if (L == 255 || R == 255) { next = 0; if (i == 1) right = 0; }
+                else { if (mnR > L) mnR = L; if (mxR < R) mxR = R; }
+                if (next && mnR > mxR) return 1;
+                if (mxR - mnR >= ORC_MAX_SPAN) { next = 0; right = 0; }
+                if (next) {
+                    g2s = (uint32_t)(stb + mnR); g2e = (uint32_t)(stb + mxR);
+                    if (g2s > g2e) return 1;
+                    next = tight(ix, (int)g2s, (int)g2e, (int)ender + 1, (int)(ender + i), tempind);
+                }
+                if (next) {
+                    ts = (uint32_t)(stb + (mnR < min_L ? mnR : min_L)); te = (uint32_t)(stb + (mxR < max_R ? max_R : mxR));
+                    if (ts > te) return 1;
+                    if (te - ts >= ORC_MAX_SPAN) { next = 0; right = 0; }
+                    if (next) next = tight(ix, (int)ts, (int)te, (int)cur, (int)(ender + i), tempind);
+                }
+                if (next) {
+                    orc_rule2 r; r.tstart = ts; r.end = (uint8_t)(te - ts); r.gap1 = (uint8_t)(og1s - ts); r.gap1_1 = (uint8_t)(og1e - ts);
+                    r.gap2 = (uint8_t)(g2s - ts); r.gap2_1 = (uint8_t)(g2e - ts); r.id = (int32_t)(D1 + id); VPUSH(out->r2, r); right = 0;
+                }
+            } else right = 0;
+            i++;
+        }
+    }
+    return 0;
+}
+
+/* canonical orders of the rule arrays: every field, id first */
+static int cmp_r0(const void *a, const void *b) { const orc_rule0 *x = a, *y = b;
+    if (x->block != y->block) return x->block < y->block ? -1 : 1;
+    if (x->tar_start != y->tar_start) return x->tar_start < y->tar_start ? -1 : 1;
+    return x->tar_end < y->tar_end ? -1 : x->tar_end > y->tar_end; }
+static int cmp_r1(const void *a, const void *b) { const orc_rule1 *x = a, *y = b;
+    if (x->id != y->id) return x->id < y->id ? -1 : 1;
+    if (x->tstart != y->tstart) return x->tstart < y->tstart ? -1 : 1;
+    if (x->end != y->end) return x->end < y->end ? -1 : 1;
+    if (x->gap1 != y->gap1) return x->gap1 < y->gap1 ? -1 : 1;
+    return x->gap1_1 < y->gap1_1 ? -1 : x->gap1_1 > y->gap1_1; }
+static int cmp_r2(const void *a, const void *b) { const orc_rule2 *x = a, *y = b;
+    if (x->id != y->id) return x->id < y->id ? -1 : 1;
+    if (x->tstart != y->tstart) return x->tstart < y->tstart ? -1 : 1;
+    if (x->end != y->end) return x->end < y->end ? -1 : 1;
+    if (x->gap1 != y->gap1) return x->gap1 < y->gap1 ? -1 : 1;
+    if (x->gap1_1 != y->gap1_1) return x->gap1_1 < y->gap1_1 ? -1 : 1;
+    if (x->gap2 != y->gap2) return x->gap2 < y->gap2 ? -1 : 1;
+    return x->gap2_1 < y->gap2_1 ? -1 : x->gap2_1 > y->gap2_1; }
+
+/* Host driver: ExtractPairs_Large_Data_Gappy, ExtractPair.cu:3215-3670.  Three launches,
+ * each launch's outputs sorted on their own, then concatenated:
+ *   one-gap rules = [Xab (id bnum) / abX (id G+bnum)] ++ [aXb (id pattern)]
+ *   two-gap rules = [XabX (bnum)] ++ [aXbXc (two-gap id)] ++ [XaXb (id) / aXbX (D1+id)]  */
+void orc_extract(const orc_index *ix, orc_batch *b) {
+    double t0 = now_s();
+    generate_blocks(ix, b);
+    rulebuf A, B, C; memset(&A, 0, sizeof A); memset(&B, 0, sizeof B); memset(&C, 0, sizeof C);
+    uint8_t dead[KTHREADS];
+    for (uint32_t bn = 0; bn < b->g; bn++) {                             /* launch 1 */
+        int32_t start = b->blocks[bn].start, end = b->blocks[bn].end; int lm = b->blocks[bn].matchlen;
+        if (lm < 1) continue;
+        int n = 1 + end - start; memset(dead, 0, sizeof dead);
+        for (int x = 0; x < n; x++) {
+            if (dead[x % KTHREADS] || !orc_sample_hit(n, ORC_SAMPLER, x)) continue;
+            if (gappy_occurrence(ix, bn, b->g, lm, start + x, &A)) dead[x % KTHREADS] = 1;
+        }
+    }
+    for (uint32_t id = 0; id < b->d2; id++) {                            /* launch 2 */
+        int32_t s0 = b->s2[id].sa_start, e0 = b->s2[id].sa_end;
+        if (s0 == -1 && e0 == -1) continue;
+        int n = e0 - s0 + 1; memset(dead, 0, sizeof dead);
+        for (int x = 0; x < n; x++) {
+            if (dead[x % KTHREADS] || !orc_sample_hit(n, ORC_SAMPLER_TWOGAP, x)) continue;
+            if (twogap_occurrence(ix, b, id, &b->hits2[s0 + x], &B)) dead[x % KTHREADS] = 1;
+        }
+    }
+    for (uint32_t id = 0; id < b->d1; id++) {                            /* launch 3 */
+        const orc_gapsearch *gs = &b->s1[id];
+        int32_t s0 = gs->sa_start, e0 = gs->sa_end;
+        if (s0 == -1 && e0 == -1) continue;
+        int n = 1 + e0 - s0, marker = 0; int64_t base = s0;
+        if (n == 1 && b->hits1[s0].length == 0) {                        /* frequent-pair marker (:417-431) */
+            int pre = (int)b->hits1[s0].str_position; marker = 1;
+            base = ix->pidx[pre].start; n = 1 + (int)ix->pidx[pre].end - (int)ix->pidx[pre].start;
+            if (gs->a_len != 1 || gs->b_len != 1) continue;
+        }
+        memset(dead, 0, sizeof dead);
+        for (int x = 0; x < n; x++) {
+            if (dead[x % KTHREADS] || !orc_sample_hit(n, ORC_SAMPLER_ONEGAP, x)) continue;
+            uint32_t cur; unsigned char fe;
+            if (marker) { cur = ix->phits[base + x].start; fe = ix->phits[base + x].length; }
+            else { if (b->hits1[base + x].position != id) { dead[x % KTHREADS] = 1; continue; } cur = b->hits1[base + x].str_position; fe = b->hits1[base + x].length; }
+            if (onegap_occurrence(ix, id, b->d1, gs->a_len, gs->b_len, cur, fe, &C)) dead[x % KTHREADS] = 1;
+        }
+    }
+    qsort(A.r0.v, A.r0.n, sizeof *A.r0.v, cmp_r0);
+    qsort(A.r1.v, A.r1.n, sizeof *A.r1.v, cmp_r1); qsort(A.r2.v, A.r2.n, sizeof *A.r2.v, cmp_r2);
+    qsort(B.r2.v, B.r2.n, sizeof *B.r2.v, cmp_r2);
+    qsort(C.r1.v, C.r1.n, sizeof *C.r1.v, cmp_r1); qsort(C.r2.v, C.r2.n, sizeof *C.r2.v, cmp_r2);
+    b->n0 = (uint32_t)A.r0.n; b->r0 = A.r0.v;
+    b->sep1 = (uint32_t)A.r1.n; b->n1 = (uint32_t)(A.r1.n + C.r1.n);
+    b->r1 = xmalloc((size_t)b->n1 * sizeof *b->r1);
+    memcpy(b->r1, A.r1.v, A.r1.n * sizeof *b->r1); memcpy(b->r1 + A.r1.n, C.r1.v, C.r1.n * sizeof *b->r1);
+    b->sep2a = (uint32_t)A.r2.n; b->sep2b = (uint32_t)(A.r2.n + B.r2.n); b->n2 = (uint32_t)(A.r2.n + B.r2.n + C.r2.n);
+    b->r2 = xmalloc((size_t)b->n2 * sizeof *b->r2);
+    memcpy(b->r2, A.r2.v, A.r2.n * sizeof *b->r2); memcpy(b->r2 + b->sep2a, B.r2.v, B.r2.n * sizeof *b->r2);
+    memcpy(b->r2 + b->sep2b, C.r2.v, C.r2.n * sizeof *b->r2);
+    free(A.r1.v); free(A.r2.v); free(B.r2.v); free(C.r1.v); free(C.r2.v);
+    b->t_extract = now_s() - t0;
+}
+
+/* ------------------------------------------------------------------ */
+/* lexicon / feature creation: ExtractPair.c:515-662 (ab), 664-936 (one gap), 939-1276 (two gaps) */
+/* ------------------------------------------------------------------ */
+typedef struct { uint64_t *h; uint32_t *idx; uint32_t *gen; uint32_t cap, cur; } grpmap;   /* per-group target-string -> lexicon index */
+static uint32_t grp_find(grpmap *m, const char *s, orc_lexent *lex, size_t skip) {
+    uint64_t h = fnv1a(s); uint32_t i = (uint32_t)h & (m->cap - 1);
+    while (m->gen[i] == m->cur) { if (m->h[i] == h && !strcmp(lex[m->idx[i]].text + skip, s)) return m->idx[i]; i = (i + 1) & (m->cap - 1); }
+    return UINT32_MAX;
+}
+static void grp_add(grpmap *m, const char *s, uint32_t idx) {
+    uint64_t h = fnv1a(s); uint32_t i = (uint32_t)h & (m->cap - 1);
+    while (m->gen[i] == m->cur) i = (i + 1) & (m->cap - 1);
+    m->gen[i] = m->cur; m->h[i] = h; m->idx[i] = idx;
+}
+static void grp_init(grpmap *m) { m->cap = 4096; m->h = xcalloc(m->cap, 8); m->idx = xcalloc(m->cap, 4); m->gen = xcalloc(m->cap, 4); m->cur = 0; }
+static void grp_free(grpmap *m) { free(m->h); free(m->idx); free(m->gen); }
+
+static void finish_scores(orc_lexent *lex, uint32_t n) {            /* ExtractPair.c:652-656 etc. */
+    for (uint32_t i = 0; i < n; i++) {
+        lex[i].aa = -log10f((float)lex[i].paircount / (float)lex[i].fsample);
+        lex[i].bb = (float)log10((double)(1 + lex[i].paircount));
+        lex[i].fscore = (float)log10((double)(1 + lex[i].fsample));
+    }
+}
+static int marker_fsample(const orc_index *ix, const orc_batch *b, uint32_t oneid) {
+    const orc_gapsearch *gs = &b->s1[oneid];
+    int fs = 1 + gs->sa_end - gs->sa_start;
+    if (fs == 1 && b->hits1[gs->sa_start].length == 0) {              /* ExtractPair.c:899-908 */
+        uint32_t pre = b->hits1[gs->sa_start].str_position;
+        fs = (int)(1 - ix->pidx[pre].start + ix->pidx[pre].end + (uint32_t)ix->miss[pre]);
+    }
+    return fs;
+}
+static size_t pattern_words(const orc_index *ix, const orc_gappat *p, const char *gapname, int lead_space, char *buf, size_t o, size_t cap, int32_t *ids, int *nids) {
+    for (int j = 0; j < p->number; j++) {
+        const char *w;
+        if (p->pat[j] >= 0) { ids[(*nids)++] = p->pat[j]; w = ix->svocab[p->pat[j]]; } else w = gapname;
+        o += (size_t)snprintf(buf + o, cap - o, (j == 0 && !lead_space) ? "%s" : " %s", w);
+    }
+    return o;
+}
+
+typedef struct { VEC(orc_lextask) t; } taskbuf;
+
+static void lexicon_one_gap(const orc_index *ix, orc_batch *b, taskbuf *tb) {
+    uint32_t G = b->g, D1 = b->d1, n = b->n1;
+    int *fs = xcalloc((size_t)2 * G + D1 + 1, sizeof(int));
+    for (uint32_t i = 0; i < n; i++) fs[i < b->sep1 ? (uint32_t)b->r1[i].id : 2 * G + (uint32_t)b->r1[i].id]++;
+    orc_lexent *lex = xmalloc(((size_t)n + 1) * sizeof *lex); uint32_t nl = 0;
+    grpmap gm; grp_init(&gm);
+    char src[2048], tgt[4096]; int32_t ids[8]; int nids = 0; uint32_t cid = 0; size_t srclen = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        const orc_rule1 *r = &b->r1[i];
+        if (i == 0 || r->id != b->r1[i - 1].id || i == b->sep1) {      /* new group */
+            nids = 0; src[0] = 0; size_t o = 0;
+            if (i < b->sep1) {
+                cid = (uint32_t)r->id;
+                const orc_block *k = &b->blocks[cid < G ? cid : cid - G];
+                if (cid < G) o = (size_t)snprintf(src, sizeof src, "[X,1] %s", b->blockname[cid]);
+                else o = (size_t)snprintf(src, sizeof src, "%s [X,1]", b->blockname[cid - G]);
+                for (int s = 0; s < k->matchlen; s++) ids[nids++] = ix->str[k->string_start + s];
+            } else {
+                cid = 2 * G + (uint32_t)r->id;
+                o = pattern_words(ix, &b->p1[b->s1[r->id].position], "[X,1]", 0, src, 0, sizeof src, ids, &nids);
+            }
+            srclen = o; gm.cur++;
+        }
+        uint32_t t0 = r->tstart, t1 = r->tstart + r->end, ga = r->tstart + r->gap1, gb = r->tstart + r->gap1_1;
+        size_t o = (size_t)snprintf(tgt, sizeof tgt, " ||| ");
+        for (uint32_t jj = t0; jj <= t1; jj++) {
+            int ingap = jj >= ga && jj <= gb;
+            o += (size_t)snprintf(tgt + o, sizeof tgt - o, jj == t0 ? "%s" : " %s", ingap ? "[X,1]" : ix->tvocab[ix->tstr[jj]]);
+            if (ingap) jj = gb;
+        }
+        uint32_t hit = grp_find(&gm, tgt, lex, srclen);
+        if (hit != UINT32_MAX) { lex[hit].paircount++; continue; }
+        orc_lextask tk; memset(&tk, 0, sizeof tk);
+        tk.lexid = nl; tk.nsrc = (uint8_t)nids; for (int j = 0; j < nids; j++) tk.src[j] = ids[j];
+        tk.tstart = t0; tk.end = r->end; tk.gap1 = r->gap1; tk.gap1_1 = r->gap1_1; VPUSH(tb->t, tk);
+        orc_lexent *e = &lex[nl]; memset(e, 0, sizeof *e);
+        e->id = (int32_t)cid;
+        if (i < b->sep1) { uint32_t real = cid >= G ? cid - G : cid; e->fsample = 1 + b->blocks[real].end - b->blocks[real].start; }
+        else e->fsample = marker_fsample(ix, b, (uint32_t)r->id);
+        if (e->fsample > ORC_SAMPLER) e->fsample = ORC_SAMPLER;
+        e->f = fs[cid]; e->paircount = 1;
+        e->text = xmalloc(srclen + o + 1); memcpy(e->text, src, srclen); memcpy(e->text + srclen, tgt, o + 1);
+        grp_add(&gm, tgt, nl); nl++;
+    }
+    finish_scores(lex, nl);
+    b->lex1 = lex; b->nl1 = nl; grp_free(&gm); free(fs);
+    b->nrng1 = 2 * G + D1; b->rng1 = xmalloc(((size_t)b->nrng1 + 1) * sizeof *b->rng1);   /* ExtractPair.cu:3743-3756 */
+    for (uint32_t i = 0; i < b->nrng1; i++) b->rng1[i].up = b->rng1[i].down = -1;
+    for (uint32_t i = 0; i < nl; i++) { if (i == 0 || lex[i].id != lex[i - 1].id) b->rng1[lex[i].id].down = (int32_t)i; b->rng1[lex[i].id].up = (int32_t)i; }
+}
+
+static void lexicon_two_gap(const orc_index *ix, orc_batch *b, taskbuf *tb) {
+    uint32_t G = b->g, D1 = b->d1, D2 = b->d2, n = b->n2;
+    int *fs = xcalloc((size_t)G + 2 * D1 + D2 + 1, sizeof(int));
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t c = i < b->sep2a ? (uint32_t)b->r2[i].id : i < b->sep2b ? G + (uint32_t)b->r2[i].id : G + D2 + (uint32_t)b->r2[i].id;
+        fs[c]++;
+    }
+    orc_lexent *lex = xmalloc(((size_t)n + 1) * sizeof *lex); uint32_t nl = 0;
+    grpmap gm; grp_init(&gm);
+    char src[2048], tgt[4096]; int32_t ids[8]; int nids = 0; uint32_t cid = 0; size_t srclen = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        const orc_rule2 *r = &b->r2[i];
+        if (i == 0 || r->id != b->r2[i - 1].id || i == b->sep2a || i == b->sep2b) {
+            nids = 0; src[0] = 0; size_t o = 0;
+            if (i < b->sep2a) {                                          /* XabX */
+                cid = (uint32_t)r->id; const orc_block *k = &b->blocks[cid];
+                o = (size_t)snprintf(src, sizeof src, "[X,1] %s [X,2]", b->blockname[cid]);
+                for (int s = 0; s < k->matchlen; s++) ids[nids++] = ix->str[k->string_start + s];
+            } else if (i < b->sep2b) {                                   /* aXbXc */
+                cid = G + (uint32_t)r->id;
+                const orc_twogapsearch *ts = &b->s2[r->id];
+                o = pattern_words(ix, &b->p1[b->s1[ts->blockid].position], "[X,1]", 0, src, 0, sizeof src, ids, &nids);
+                o += (size_t)snprintf(src + o, sizeof src - o, " [X,2]");
+                const orc_twogappat *p = &b->p2[ts->position];
+                for (int j = 0; j < p->number && j < 1; j++) { ids[nids++] = p->pat[j]; o += (size_t)snprintf(src + o, sizeof src - o, " %s", ix->svocab[p->pat[j]]); }
+            } else {                                                     /* XaXb (id) / aXbX (D1+id) */
+                cid = G + D2 + (uint32_t)r->id;
+                int xaxb = !(cid >= G + D2 + D1); uint32_t one = xaxb ? (uint32_t)r->id : (uint32_t)r->id - D1;
+                if (xaxb) o = (size_t)snprintf(src, sizeof src, "[X,1]");
+                o = pattern_words(ix, &b->p1[b->s1[one].position], xaxb ? "[X,2]" : "[X,1]", xaxb, src, o, sizeof src, ids, &nids);
+                if (!xaxb) o += (size_t)snprintf(src + o, sizeof src - o, " [X,2]");
+            }
+            srclen = o; gm.cur++;
+        }
+        uint32_t t0 = r->tstart, t1 = r->tstart + r->end, ga = t0 + r->gap1, gb = t0 + r->gap1_1, gc = t0 + r->gap2, gd = t0 + r->gap2_1;
+        size_t o = (size_t)snprintf(tgt, sizeof tgt, " ||| ");
+        for (uint32_t jj = t0; jj <= t1; jj++) {
+            int in1 = jj >= ga && jj <= gb, in2 = !in1 && jj >= gc && jj <= gd;
+            o += (size_t)snprintf(tgt + o, sizeof tgt - o, jj == t0 ? "%s" : " %s", in1 ? "[X,1]" : in2 ? "[X,2]" : ix->tvocab[ix->tstr[jj]]);
+            if (in1) jj = gb; else if (in2) jj = gd;
+        }
+        uint32_t hit = grp_find(&gm, tgt, lex, srclen);
+        if (hit != UINT32_MAX) { lex[hit].paircount++; continue; }
+        orc_lextask tk; memset(&tk, 0, sizeof tk);
+        tk.lexid = nl; tk.nsrc = (uint8_t)nids; for (int j = 0; j < nids; j++) tk.src[j] = ids[j];
+        tk.tstart = t0; tk.end = r->end; tk.gap1 = r->gap1; tk.gap1_1 = r->gap1_1; tk.gap2 = r->gap2; tk.gap2_1 = r->gap2_1; VPUSH(tb->t, tk);
+        orc_lexent *e = &lex[nl]; memset(e, 0, sizeof *e);
+        e->id = (int32_t)cid;
+        if (i < b->sep2a) e->fsample = 1 + b->blocks[r->id].end - b->blocks[r->id].start;
+        else if (i < b->sep2b) e->fsample = 1 + b->s2[r->id].sa_end - b->s2[r->id].sa_start;
+        else e->fsample = marker_fsample(ix, b, cid >= G + D2 + D1 ? (uint32_t)r->id - D1 : (uint32_t)r->id);
+        if (e->fsample > ORC_SAMPLER) e->fsample = ORC_SAMPLER;
+        e->f = fs[cid]; e->paircount = 1;
+        e->text = xmalloc(srclen + o + 1); memcpy(e->text, src, srclen); memcpy(e->text + srclen, tgt, o + 1);
+        grp_add(&gm, tgt, nl); nl++;
+    }
+    finish_scores(lex, nl);
+    b->lex2 = lex; b->nl2 = nl; grp_free(&gm); free(fs);
+    b->nrng2 = G + 2 * D1 + D2; b->rng2 = xmalloc(((size_t)b->nrng2 + 1) * sizeof *b->rng2);   /* ExtractPair.cu:3802-3816 */
+    for (uint32_t i = 0; i < b->nrng2; i++) b->rng2[i].up = b->rng2[i].down = -1;
+    for (uint32_t i = 0; i < nl; i++) { if (i == 0 || lex[i].id != lex[i - 1].id) b->rng2[lex[i].id].down = (int32_t)i; b->rng2[lex[i].id].up = (int32_t)i; }
+}
+
+static void lexicon_contiguous(const orc_index *ix, orc_batch *b, taskbuf *tb) {
+    uint32_t G = b->g, n = b->n0;
+    int *fs = xcalloc((size_t)G + 1, sizeof(int));
+    for (uint32_t i = 0; i < n; i++) fs[b->r0[i].block]++;
+    orc_lexent *lex = xmalloc(((size_t)n + 1) * sizeof *lex); uint32_t nl = 0;
+    grpmap gm; grp_init(&gm);
+    char tgt[4096]; size_t srclen = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        const orc_rule0 *r = &b->r0[i]; const orc_block *k = &b->blocks[r->block];
+        if (i == 0 || r->block != b->r0[i - 1].block) { gm.cur++; srclen = strlen(b->blockname[r->block]); }
+        /* "<src> ||" + "| <tgt>" (ExtractPair.c:562,583-587) */
+        size_t o = (size_t)snprintf(tgt, sizeof tgt, " ||| ");
+        int32_t t1 = r->tar_start + r->tar_end;
+        for (int32_t jj = r->tar_start; jj <= t1; jj++) o += (size_t)snprintf(tgt + o, sizeof tgt - o, jj == r->tar_start ? "%s" : " %s", ix->tvocab[ix->tstr[jj]]);
+        uint32_t hit = grp_find(&gm, tgt, lex, srclen);
+        if (hit != UINT32_MAX) { lex[hit].paircount++; continue; }
+        orc_lextask tk; memset(&tk, 0, sizeof tk);
+        tk.lexid = nl; tk.nsrc = (uint8_t)k->matchlen; for (int j = 0; j < k->matchlen; j++) tk.src[j] = ix->str[k->string_start + j];
+        tk.tstart = (uint32_t)r->tar_start; tk.end = r->tar_end; VPUSH(tb->t, tk);
+        orc_lexent *e = &lex[nl]; memset(e, 0, sizeof *e);
+        e->id = r->block; e->fsample = 1 + k->end - k->start; if (e->fsample > ORC_SAMPLER) e->fsample = ORC_SAMPLER;
+        e->f = fs[r->block]; e->paircount = 1;
+        e->text = xmalloc(srclen + o + 1); memcpy(e->text, b->blockname[r->block], srclen); memcpy(e->text + srclen, tgt, o + 1);
+        grp_add(&gm, tgt, nl); nl++;
+    }
+    finish_scores(lex, nl);
+    b->lex0 = lex; b->nl0 = nl; grp_free(&gm); free(fs);
+    b->rng0 = xmalloc(((size_t)G + 1) * sizeof *b->rng0);             /* extractGlobalPairsUpDown, ExtractPair.cu:2082-2106 */
+    for (uint32_t i = 0; i < G; i++) b->rng0[i].up = b->rng0[i].down = -1;
+    for (uint32_t i = 0; i < nl; i++) { if (i == 0 || lex[i].id != lex[i - 1].id) b->rng0[lex[i].id].down = (int32_t)i; b->rng0[lex[i].id].up = (int32_t)i; }
+}
+
+/* lexicalTaskMaxEF, ExtractPair.cu:2144-2432.  kind 0 = one gap, 1 = two gaps, 2 = contiguous */
+static void lex_task(const orc_index *ix, const orc_lextask *tk, int kind, float *fe, float *ef) {
+    float fgivene = 0, egivenf = 0;
+    int tend = (int)tk->tstart + tk->end, g1s = (int)tk->tstart + tk->gap1, g1e = (int)tk->tstart + tk->gap1_1;
+    int g2s = (int)tk->tstart + tk->gap2, g2e = (int)tk->tstart + tk->gap2_1;
+#define OUTSIDE(jj) (kind == 2 || ((jj < g1s || jj > g1e) && (kind == 0 || (jj < g2s || jj > g2e))))
+    for (int j = 0; j < tk->nsrc; j++) {
+        float mx = 0; int first = 1;
+        for (int jj = (int)tk->tstart; jj <= tend; jj++) if (OUTSIDE(jj)) {
+            float v;
+            if (first) { v = orc_lex_lookup(ix, tk->src[j], -1, 0); if (v > mx) mx = v; first = 0; }
+            v = orc_lex_lookup(ix, tk->src[j], ix->tstr[jj], 0); if (v > mx) mx = v;
+        }
+        if (mx > 0) fgivene += -log10f(mx); else fgivene += ORC_MAXSCORE;
+    }
+    for (int jj = (int)tk->tstart; jj <= tend; jj++) if (OUTSIDE(jj)) {
+        float mx = 0; int first = 1;
+        for (int j = 0; j < tk->nsrc; j++) {
+            float v;
+            if (first) { v = orc_lex_lookup(ix, -1, ix->tstr[jj], 1); if (v > mx) mx = v; first = 0; }
+            v = orc_lex_lookup(ix, tk->src[j], ix->tstr[jj], 1); if (v > mx) mx = v;
+        }
+        if (mx > 0) egivenf += -log10f(mx); else egivenf += ORC_MAXSCORE;
+    }
+#undef OUTSIDE
+    *fe = fgivene; *ef = egivenf;
+}
+
+void orc_features(const orc_index *ix, orc_batch *b) {
+    double t0 = now_s();
+    taskbuf tb; memset(&tb, 0, sizeof tb);
+    lexicon_one_gap(ix, b, &tb);
+    lexicon_two_gap(ix, b, &tb);
+    lexicon_contiguous(ix, b, &tb);
+    b->t_lexicon = now_s() - t0; t0 = now_s();
+    b->ntask = (uint32_t)tb.t.n; b->tasks = tb.t.v;
+    b->task_fe = xmalloc(((size_t)b->ntask + 1) * 4); b->task_ef = xmalloc(((size_t)b->ntask + 1) * 4);
+    for (uint32_t i = 0; i < b->ntask; i++) {
+        int kind = i < b->nl1 ? 0 : i < b->nl1 + b->nl2 ? 1 : 2;
+        lex_task(ix, &b->tasks[i], kind, &b->task_fe[i], &b->task_ef[i]);
+        orc_lexent *e = kind == 0 ? &b->lex1[b->tasks[i].lexid] : kind == 1 ? &b->lex2[b->tasks[i].lexid] : &b->lex0[b->tasks[i].lexid];
+        e->maxlex_fe = b->task_fe[i]; e->maxlex_ef = b->task_ef[i];       /* ExtractPair.cu:3965-3982 */
+    }
+    b->t_lextask = now_s() - t0;
+}
+
+/* ------------------------------------------------------------------ */
+/* grammar writer: PrintResults.c:339-405 (printGapMode), 407-577       */
+/* ------------------------------------------------------------------ */
+static uint64_t emit_range(FILE *fp, const orc_lexent *lex, const orc_range *rng, uint32_t id) {
+    uint64_t n = 0;
+    if (rng[id].down != -1 && rng[id].up != -1)
+        for (int32_t i = rng[id].down; i <= rng[id].up; i++, n++)
+            fprintf(fp, "[X] ||| %s ||| EgivenFCoherent=%f SampleCountF=%f CountEF=%f MaxLexFgivenE=%f MaxLexEgivenF=%f IsSingletonF=%d IsSingletonFE=%d\n",
+                    lex[i].text, lex[i].aa, lex[i].fscore, lex[i].bb, lex[i].maxlex_fe, lex[i].maxlex_ef, lex[i].f == 1, lex[i].paircount == 1);
+    return n;
+}
+int orc_write_grammars(const orc_batch *b, const char *outdir, int first) {
+    uint32_t G = b->g, D1 = b->d1, D2 = b->d2; uint64_t lines = 0;
+    char fn[4096];
+    for (int32_t q = 0; q < b->nq; q++) {
+        snprintf(fn, sizeof fn, "%s/grammar.%d.s", outdir, first + q);
+        FILE *fp = fopen(fn, "w");
+        if (!fp) { fprintf(stderr, "Please check your file directory address for grammar rule files output. It is not valid. Program Exits.\n"); return -1; }
+        for (uint32_t k = 0; k < b->nqblocks[q]; k++) {
+            uint32_t p = b->qblocks[q][k];
+            lines += emit_range(fp, b->lex1, b->rng1, p + G);            /* abX  */
+            lines += emit_range(fp, b->lex1, b->rng1, p);                /* Xab  */
+            lines += emit_range(fp, b->lex2, b->rng2, p);                /* XabX */
+            lines += emit_range(fp, b->lex0, b->rng0, p);                /* ab   */
+        }
+        for (uint32_t k = 0; k < b->nqone[q]; k++) {
+            uint32_t id = b->qone[q][k];
+            lines += emit_range(fp, b->lex1, b->rng1, 2 * G + id);       /* aXb  */
+            lines += emit_range(fp, b->lex2, b->rng2, G + D2 + id);      /* XaXb */
+            lines += emit_range(fp, b->lex2, b->rng2, G + D2 + D1 + id); /* aXbX */
+        }
+        for (uint32_t k = 0; k < b->nqtwo[q]; k++) lines += emit_range(fp, b->lex2, b->rng2, G + b->qtwo[q][k]);   /* aXbXc */
+        fclose(fp);
+    }
+    ((orc_batch *)b)->nlines = lines;
+    return 0;
+}
+
+int orc_run_all(const orc_index *ix, orc_batch *b, const char *outdir) {
+    orc_sa_lookup(ix, b);
+    orc_gappy_search(ix, b);
+    orc_extract(ix, b);
+    orc_features(ix, b);
+    if (!outdir) return 0;
+    fprintf(stderr, "Start Printing Gappy Phrases...\n");
+    double t0 = now_s();
+    int rc = orc_write_grammars(b, outdir, 0);
+    b->t_write = now_s() - t0;
+    return rc;
+}
+
+/* ------------------------------------------------------------------ */
+/* dump of every intermediate for the tests and for oracle/_ref          */
+/* ------------------------------------------------------------------ */
+static void put(FILE *f, const char *tag, const void *p, uint64_t nbytes) {
+    char t[8] = {0}; memcpy(t, tag, strlen(tag) < 8 ? strlen(tag) : 8); fwrite(t, 1, 8, f); fwrite(&nbytes, 8, 1, f); if (nbytes) fwrite(p, 1, nbytes, f);
+}
+static void put_strings(FILE *f, const char *tag, char **s, uint32_t n, uint32_t from) {
+    uint64_t tot = 0; for (uint32_t i = 0; i < n; i++) tot += (i >= from && s[i] ? strlen(s[i]) : 0) + 1;
+    char *buf = xmalloc(tot + 1), *p = buf;
+    for (uint32_t i = 0; i < n; i++) { const char *x = (i >= from && s[i]) ? s[i] : ""; size_t L = strlen(x) + 1; memcpy(p, x, L); p += L; }
+    put(f, tag, buf, tot); free(buf);
+}
+static void put_lists(FILE *f, const char *tag, uint32_t **l, const uint32_t *n, int32_t nq) {
+    VEC(uint32_t) v = {0};
+    for (int32_t q = 0; q < nq; q++) { VPUSH(v, n[q]); for (uint32_t k = 0; k < n[q]; k++) VPUSH(v, l[q][k]); }
+    put(f, tag, v.v, v.n * 4); free(v.v);
+}
+static void put_lex(FILE *f, const char *pre, const orc_lexent *lex, uint32_t n) {
+    char tag[9]; VEC(int32_t) iv = {0}; VEC(float) fv = {0}; char **txt = xmalloc(((size_t)n + 1) * sizeof *txt);
+    for (uint32_t i = 0; i < n; i++) {
+        VPUSH(iv, lex[i].id); VPUSH(iv, lex[i].f); VPUSH(iv, lex[i].fsample); VPUSH(iv, lex[i].paircount);
+        VPUSH(fv, lex[i].aa); VPUSH(fv, lex[i].bb); VPUSH(fv, lex[i].fscore); VPUSH(fv, lex[i].maxlex_fe); VPUSH(fv, lex[i].maxlex_ef);
+        txt[i] = lex[i].text;
+    }
+    snprintf(tag, sizeof tag, "%s_int", pre); put(f, tag, iv.v, iv.n * 4);
+    snprintf(tag, sizeof tag, "%s_flt", pre); put(f, tag, fv.v, fv.n * 4);
+    snprintf(tag, sizeof tag, "%s_txt", pre); put_strings(f, tag, txt, n, 0);
+    free(iv.v); free(fv.v); free(txt);
+}
+int orc_dump(const orc_index *ix, const orc_batch *b, const char *path) {
+    FILE *f = fopen(path, "wb");
+    if (!f) return -1;
+    uint32_t hdr[16] = { ix->n, ix->nt, (uint32_t)ix->nsent, (uint32_t)ix->nsvocab, (uint32_t)ix->ntvocab, ix->nlex, ix->nphits,
+                         (uint32_t)b->nq, (uint32_t)b->ntok, b->g, b->d1, b->d2, b->sep1, b->sep2a, b->sep2b, 0 };
+    put(f, "header", hdr, sizeof hdr);
+    put(f, "str", ix->str, (uint64_t)(ix->n + 3) * 4); put(f, "sa", ix->sa, (uint64_t)ix->n * 4); put(f, "rlp", ix->rlp, (uint64_t)ix->n * 4);
+    put(f, "tstr", ix->tstr, (uint64_t)(ix->nt + 3) * 4); put(f, "ltar", ix->ltar, ix->nt); put(f, "rtar", ix->rtar, ix->nt);
+    put(f, "sentind", ix->sentind, (uint64_t)(ix->nsent + 1) * 4); put(f, "tsentind", ix->tsentind, (uint64_t)(ix->nsent + 1) * 4);
+    put(f, "lexk", ix->lexk, (uint64_t)ix->nlex * 8); put(f, "lexv", ix->lexv, (uint64_t)ix->nlex * 8);
+    put(f, "freq", ix->freq, sizeof ix->freq); put(f, "pidx", ix->pidx, sizeof ix->pidx); put(f, "miss", ix->miss, sizeof ix->miss);
+    put(f, "phits", ix->phits, (uint64_t)ix->nphits * sizeof *ix->phits);
+    put_strings(f, "svocab", ix->svocab, (uint32_t)(ix->shash ? ix->nsvocab : ix->nsvocab + 1), 2);
+    put_strings(f, "tvocab", ix->tvocab, (uint32_t)(ix->thash ? ix->ntvocab : ix->ntvocab + 1), 2);
+    put(f, "qoff", b->qoff, (uint64_t)(b->nq + 1) * 4); put(f, "qtok", b->qtok, (uint64_t)b->ntok * 4);
+    if (b->lm) { put(f, "lm", b->lm, (uint64_t)b->ntok * 4); put(f, "up", b->up, (uint64_t)b->ntok * 20); put(f, "down", b->down, (uint64_t)b->ntok * 20); }
+    if (b->s1) {
+        put(f, "g1", b->g1, (uint64_t)b->e1 * sizeof *b->g1); put(f, "p1", b->p1, (uint64_t)b->e1 * sizeof *b->p1);
+        put(f, "s1", b->s1, (uint64_t)b->d1 * sizeof *b->s1); put(f, "hits1", b->hits1, (uint64_t)b->h1 * sizeof *b->hits1);
+        put(f, "g2", b->g2, (uint64_t)b->e2 * sizeof *b->g2); put(f, "p2", b->p2, (uint64_t)b->e2 * sizeof *b->p2);
+        put(f, "s2", b->s2, (uint64_t)b->d2 * sizeof *b->s2); put(f, "hits2", b->hits2, (uint64_t)b->h2 * sizeof *b->hits2);
+        put_lists(f, "qone", b->qone, b->nqone, b->nq); put_lists(f, "qtwo", b->qtwo, b->nqtwo, b->nq);
+    }
+    if (b->blocks) {
+        put(f, "blocks", b->blocks, (uint64_t)b->g * sizeof *b->blocks); put_strings(f, "blkname", b->blockname, b->g, 0);
+        put_lists(f, "qblocks", b->qblocks, b->nqblocks, b->nq);
+        put(f, "r0", b->r0, (uint64_t)b->n0 * sizeof *b->r0); put(f, "r1", b->r1, (uint64_t)b->n1 * sizeof *b->r1); put(f, "r2", b->r2, (uint64_t)b->n2 * sizeof *b->r2);
+    }
+    if (b->lex1) {
+        put_lex(f, "lex1", b->lex1, b->nl1); put_lex(f, "lex2", b->lex2, b->nl2); put_lex(f, "lex0", b->lex0, b->nl0);
+        put(f, "rng1", b->rng1, (uint64_t)b->nrng1 * 8); put(f, "rng2", b->rng2, (uint64_t)b->nrng2 * 8); put(f, "rng0", b->rng0, (uint64_t)b->g * 8);
+        put(f, "tasks", b->tasks, (uint64_t)b->ntask * sizeof *b->tasks); put(f, "task_fe", b->task_fe, (uint64_t)b->ntask * 4); put(f, "task_ef", b->task_ef, (uint64_t)b->ntask * 4);
+    }
+    fclose(f);
+    return 0;
+}
