@@ -1,0 +1,45 @@
+// cgx_ctx.h -- the context behind the opaque cgx_ctx handle (device half).
+#ifndef CGX_CTX_H
+#define CGX_CTX_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <map>
+#include <string>
+#include <vector>
+#include "../../include/cgx.h"
+
+struct cgx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    char err[512] = {0};
+    int k1_limit = 128;                 // K1 launches 128 threads per query sentence (SuffixArray.cu:1374-1378)
+    uint64_t chunk_items = 1ull << 26;  // work items per count/fill chunk
+    std::map<std::string, double> ms;   // stage timings
+
+    // ---- index, resident for the life of the context ----
+    uint32_t n = 0, nt = 0, nlex = 0, nphits = 0; int32_t last = 0;
+    bool have_sa = false, have_pre = false;
+    int32_t *d_str = nullptr, *d_sa = nullptr, *d_tstr = nullptr;
+    uint32_t *d_rlp = nullptr;
+    uint8_t *d_ltar = nullptr, *d_rtar = nullptr;
+    uint64_t *d_lexkey = nullptr; float *d_lexv1 = nullptr, *d_lexv2 = nullptr, *d_lexn1 = nullptr, *d_lexn2 = nullptr;
+    int32_t *d_tokstart = nullptr; int8_t *d_tokrank = nullptr; int32_t *d_freq = nullptr;
+    uint32_t *d_pidx = nullptr; int32_t *d_miss = nullptr; uint32_t *d_phit_start = nullptr; uint8_t *d_phit_len = nullptr;
+    int32_t freq[100] = {0};
+
+    // ---- batch ----
+    int32_t nq = 0, ntok = 0;
+    std::vector<int32_t> h_qoff, h_tok2q;
+    int32_t *d_qoff = nullptr, *d_qtok = nullptr, *d_tok2q = nullptr;
+    int32_t *d_lm = nullptr, *d_up = nullptr, *d_down = nullptr;
+    uint32_t e1 = 0, d1 = 0, h1 = 0, e2 = 0, d2 = 0, h2 = 0;
+    cgx_gappy *d_g1 = nullptr; cgx_gappat *d_p1 = nullptr; uint32_t *d_pid1 = nullptr; cgx_gapsearch *d_s1 = nullptr; cgx_hit1 *d_hits1 = nullptr;
+    cgx_twogappy *d_g2 = nullptr; int32_t *d_c2 = nullptr; uint32_t *d_pid2 = nullptr; cgx_twogapsearch *d_s2 = nullptr; cgx_hit2 *d_hits2 = nullptr;
+    uint32_t g = 0; cgx_block *d_blocks = nullptr;
+    uint32_t n0 = 0, n1 = 0, n2 = 0, sep1 = 0, sep2a = 0, sep2b = 0, guard_exits = 0;
+    cgx_rule0 *d_r0 = nullptr; cgx_rule1 *d_r1 = nullptr; cgx_rule2 *d_r2 = nullptr;
+
+    // ---- host-side stage timings of the whole-path driver ----
+    std::map<std::string, double> host_ms;
+};
+#endif

@@ -1,0 +1,1299 @@
+// cgx_device.hip -- gfx950 kernels and the device half of the C ABI (include/cgx.h).
+//
+// Design (MI355X-first):
+//  * the whole corpus index stays resident in HBM for the life of the context: token ids,
+//    suffix array, packed alignment words, target-side alignment bytes, lexical table,
+//    a per-token SA bucket table and the frequent-pair lists;
+//  * every variable-size result is produced by count -> scan -> fill (ordered compaction)
+//    or by wave-aggregated appends followed by a radix sort on the full record, so no result
+//    depends on atomic arrival order and nothing has a fixed capacity;
+//  * sort / scan / reduce are rocPRIM; integer gathers only, no MFMA.
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+#include <vector>
+#include <string>
+#include <algorithm>
+#include "../../include/cgx.h"
+#include "cgx_rules.h"
+#include "cgx_ctx.h"
+#include "cgx_internal.h"
+
+// ------------------------------------------------------------------------------------
+// error handling / memory helpers
+// ------------------------------------------------------------------------------------
+static int fail(cgx_ctx *c, int code, const char *what, hipError_t e) {
+    snprintf(c->err, sizeof c->err, "%s: %s", what, e == hipSuccess ? "failed" : hipGetErrorString(e));
+    return code;
+}
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(ctx, CGX_ERR_HIP, #x, e_); } while (0)
+#define TRY(x) do { int r_ = (x); if (r_ != CGX_OK) return r_; } while (0)
+
+template <class T> static int dalloc(cgx_ctx *ctx, T **p, size_t count) {
+    *p = nullptr;
+    HIPCHK(hipMalloc((void **)p, (count ? count : 1) * sizeof(T)));
+    return CGX_OK;
+}
+template <class T> static void dfree(T *&p) { if (p) { (void)hipFree((void *)p); p = nullptr; } }
+static inline unsigned nblocks(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
+static int bits_for(uint64_t maxval) { int b = 1; while (b < 64 && (maxval >> b)) b++; return b; }
+
+struct Timer {
+    hipEvent_t a, b; hipStream_t s;
+    Timer(hipStream_t st) : s(st) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, s); }
+    double stop() { (void)hipEventRecord(b, s); (void)hipEventSynchronize(b); float ms = 0; (void)hipEventElapsedTime(&ms, a, b); (void)hipEventDestroy(a); (void)hipEventDestroy(b); return ms; }
+};
+
+// rocPRIM wrappers (temporary storage allocated per call; all on ctx->stream)
+template <class K, class V>
+static int sort_pairs(cgx_ctx *ctx, const K *kin, K *kout, const V *vin, V *vout, size_t n, unsigned b0, unsigned b1) {
+    size_t tb = 0; void *tmp = nullptr;
+    HIPCHK(rocprim::radix_sort_pairs(nullptr, tb, kin, kout, vin, vout, n, b0, b1, ctx->stream));
+    HIPCHK(hipMalloc(&tmp, tb ? tb : 1));
+    hipError_t e = rocprim::radix_sort_pairs(tmp, tb, kin, kout, vin, vout, n, b0, b1, ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream); (void)hipFree(tmp);
+    HIPCHK(e);
+    return CGX_OK;
+}
+template <class K>
+static int sort_keys(cgx_ctx *ctx, const K *kin, K *kout, size_t n, unsigned b0, unsigned b1) {
+    size_t tb = 0; void *tmp = nullptr;
+    HIPCHK(rocprim::radix_sort_keys(nullptr, tb, kin, kout, n, b0, b1, ctx->stream));
+    HIPCHK(hipMalloc(&tmp, tb ? tb : 1));
+    hipError_t e = rocprim::radix_sort_keys(tmp, tb, kin, kout, n, b0, b1, ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream); (void)hipFree(tmp);
+    HIPCHK(e);
+    return CGX_OK;
+}
+template <class In, class Out>
+static int excl_scan(cgx_ctx *ctx, const In *in, Out *out, size_t n) {
+    size_t tb = 0; void *tmp = nullptr;
+    HIPCHK(rocprim::exclusive_scan(nullptr, tb, in, out, (Out)0, n, rocprim::plus<Out>(), ctx->stream));
+    HIPCHK(hipMalloc(&tmp, tb ? tb : 1));
+    hipError_t e = rocprim::exclusive_scan(tmp, tb, in, out, (Out)0, n, rocprim::plus<Out>(), ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream); (void)hipFree(tmp);
+    HIPCHK(e);
+    return CGX_OK;
+}
+template <class In, class Out>
+static int incl_scan(cgx_ctx *ctx, const In *in, Out *out, size_t n) {
+    size_t tb = 0; void *tmp = nullptr;
+    HIPCHK(rocprim::inclusive_scan(nullptr, tb, in, out, n, rocprim::plus<Out>(), ctx->stream));
+    HIPCHK(hipMalloc(&tmp, tb ? tb : 1));
+    hipError_t e = rocprim::inclusive_scan(tmp, tb, in, out, n, rocprim::plus<Out>(), ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream); (void)hipFree(tmp);
+    HIPCHK(e);
+    return CGX_OK;
+}
+template <class T> static int d2h(cgx_ctx *ctx, T *dst, const T *src, size_t count) {
+    HIPCHK(hipMemcpyAsync(dst, src, count * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return CGX_OK;
+}
+template <class T> static int h2d(cgx_ctx *ctx, T *dst, const T *src, size_t count) {
+    HIPCHK(hipMemcpyAsync(dst, src, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return CGX_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------
+// last index i in [0,n] with off[i] <= w  (off is an exclusive-scan array with off[n] = total)
+__device__ __forceinline__ uint32_t seg_of(const uint64_t *off, uint32_t n, uint64_t w) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) { uint32_t m = (lo + hi + 1) >> 1; if (off[m] <= w) lo = m; else hi = m - 1; }
+    return lo;
+}
+// wave-aggregated append: returns the slot of this lane's record (valid lanes only)
+__device__ __forceinline__ uint32_t wave_append(unsigned int *counter, bool valid) {
+    unsigned long long m = __ballot(valid);
+    uint32_t base = 0;
+    int lane = (int)(threadIdx.x & 63);
+    int leader = __ffsll((long long)m) - 1;
+    if (m && lane == leader) base = atomicAdd(counter, (unsigned int)__popcll(m));
+    base = __shfl(base, leader < 0 ? 0 : leader);
+    return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+}
+
+__global__ void k_iota(uint32_t *p, size_t n) { size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; if (i < n) p[i] = (uint32_t)i; }
+template <class T> __global__ void k_gather(const T *src, const uint32_t *perm, T *dst, size_t n) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; if (i < n) dst[i] = src[perm[i]];
+}
+template <class T> __global__ void k_head_flags(const T *keys, uint32_t *flags, size_t n) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) flags[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+}
+
+// stable sort of n records by the 128-bit key (hi,lo): two LSD radix passes.  On return
+// hi/lo hold the sorted keys (buffers are swapped with freshly allocated ones).
+static int sort128(cgx_ctx *ctx, uint64_t *&hi, uint64_t *&lo, size_t n, unsigned lo_bits, unsigned hi_bits) {
+    if (n == 0) return CGX_OK;
+    uint32_t *p0 = nullptr, *p1 = nullptr; uint64_t *k1 = nullptr, *k2 = nullptr;
+    TRY(dalloc(ctx, &p0, n)); TRY(dalloc(ctx, &p1, n)); TRY(dalloc(ctx, &k1, n)); TRY(dalloc(ctx, &k2, n));
+    k_iota<<<nblocks(n, 256), 256, 0, ctx->stream>>>(p0, n);
+    TRY(sort_pairs(ctx, lo, k1, p0, p1, n, 0, lo_bits));                   // k1 = sorted lo, p1 = permutation
+    k_gather<<<nblocks(n, 256), 256, 0, ctx->stream>>>(hi, p1, k2, n);      // k2 = hi in lo-order
+    TRY(sort_pairs(ctx, k2, hi, p1, p0, n, 0, hi_bits));                    // hi = sorted hi, p0 = final permutation
+    k_gather<<<nblocks(n, 256), 256, 0, ctx->stream>>>(lo, p0, k1, n);      // k1 = lo in final order
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    dfree(lo); lo = k1; dfree(k2); dfree(p0); dfree(p1);
+    return CGX_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------
+extern "C" cgx_ctx *cgx_create(int device) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+        fprintf(stderr, "cgx: no HIP device %d available (found %d); there is no CPU fallback\n", device, ndev);
+        return nullptr;
+    }
+    if (hipSetDevice(device) != hipSuccess) return nullptr;
+    cgx_ctx *c = new cgx_ctx();
+    c->device = device;
+    if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return nullptr; }
+    return c;
+}
+static void free_batch(cgx_ctx *c) {
+    dfree(c->d_qoff); dfree(c->d_qtok); dfree(c->d_tok2q); dfree(c->d_lm); dfree(c->d_up); dfree(c->d_down);
+    dfree(c->d_g1); dfree(c->d_p1); dfree(c->d_pid1); dfree(c->d_s1); dfree(c->d_hits1);
+    dfree(c->d_g2); dfree(c->d_c2); dfree(c->d_pid2); dfree(c->d_s2); dfree(c->d_hits2);
+    dfree(c->d_blocks); dfree(c->d_r0); dfree(c->d_r1); dfree(c->d_r2);
+    c->e1 = c->d1 = c->h1 = c->e2 = c->d2 = c->h2 = c->g = c->n0 = c->n1 = c->n2 = c->sep1 = c->sep2a = c->sep2b = 0;
+    c->guard_exits = 0;
+}
+static void free_index(cgx_ctx *c) {
+    dfree(c->d_str); dfree(c->d_sa); dfree(c->d_rlp); dfree(c->d_tstr); dfree(c->d_ltar); dfree(c->d_rtar);
+    dfree(c->d_lexkey); dfree(c->d_lexv1); dfree(c->d_lexv2); dfree(c->d_lexn1); dfree(c->d_lexn2);
+    dfree(c->d_tokstart); dfree(c->d_tokrank); dfree(c->d_freq); dfree(c->d_pidx); dfree(c->d_miss);
+    dfree(c->d_phit_start); dfree(c->d_phit_len);
+    c->n = c->nt = c->nlex = c->nphits = 0; c->have_sa = c->have_pre = false;
+}
+extern "C" void cgx_destroy(cgx_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    free_batch(c); free_index(c);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+extern "C" const char *cgx_last_error(cgx_ctx *c) { return c ? c->err : "null context"; }
+extern "C" int cgx_set_option(cgx_ctx *c, const char *name, int64_t value) {
+    if (!c || !name) return CGX_ERR_ARG;
+    if (!strcmp(name, "k1_limit")) { c->k1_limit = (int)value; return CGX_OK; }
+    if (!strcmp(name, "chunk_items")) { if (value < 1024) return CGX_ERR_ARG; c->chunk_items = (uint64_t)value; return CGX_OK; }
+    snprintf(c->err, sizeof c->err, "unknown option %s", name);
+    return CGX_ERR_ARG;
+}
+extern "C" void cgx__set_host_ms(cgx_ctx *c, const char *name, double ms) { if (c && name) c->host_ms[name] = ms; }
+extern "C" double cgx_host_ms(cgx_ctx *c, const char *name) {
+    if (!c || !name) return -1;
+    auto it = c->host_ms.find(name);
+    return it == c->host_ms.end() ? -1.0 : it->second;
+}
+extern "C" double cgx_stage_ms(cgx_ctx *c, const char *name) {
+    if (!c || !name) return -1;
+    auto it = c->ms.find(name);
+    return it == c->ms.end() ? -1.0 : it->second;
+}
+
+// ------------------------------------------------------------------------------------
+// index upload
+// ------------------------------------------------------------------------------------
+static int build_tokstart(cgx_ctx *ctx, const int32_t *str, uint32_t n) {
+    // SA bucket table: suffixes are ordered by first token, so the SA interval of token c is
+    // [tokstart[c], tokstart[c+1]).  Replaces K1's O(log N) search for 1-token phrases.
+    int32_t last = 0;
+    for (uint32_t i = 0; i < n; i++) if (str[i] > last) last = str[i];
+    ctx->last = last;
+    std::vector<int32_t> ts((size_t)last + 3, 0);
+    for (uint32_t i = 0; i < n; i++) { if (str[i] < 0) { snprintf(ctx->err, sizeof ctx->err, "negative token id at %u", i); return CGX_ERR_ARG; } ts[(size_t)str[i] + 1]++; }
+    for (size_t c = 1; c < ts.size(); c++) ts[c] += ts[c - 1];
+    dfree(ctx->d_tokstart);
+    TRY(dalloc(ctx, &ctx->d_tokstart, ts.size()));
+    TRY(h2d(ctx, ctx->d_tokstart, ts.data(), ts.size()));
+    return CGX_OK;
+}
+static int upload_lex(cgx_ctx *ctx, const cgx_lexkey *k, const cgx_lexval *v, uint32_t nlex) {
+    // sort rows by (src,tgt) like thrust::sort_by_key(lexFileCompare) (ExtractPair.cu:2537) and
+    // precompute -log10f of both probabilities with the host libm (bit-exact MaxLex sums).
+    std::vector<uint32_t> ord(nlex);
+    for (uint32_t i = 0; i < nlex; i++) ord[i] = i;
+    std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) {
+        return cgx_lexkey_pack(k[a].src, k[a].tgt) < cgx_lexkey_pack(k[b].src, k[b].tgt); });
+    std::vector<uint64_t> key(nlex); std::vector<float> v1(nlex), v2(nlex), n1(nlex), n2(nlex);
+    for (uint32_t i = 0; i < nlex; i++) {
+        uint32_t o = ord[i];
+        key[i] = cgx_lexkey_pack(k[o].src, k[o].tgt); v1[i] = v[o].v1; v2[i] = v[o].v2;
+        n1[i] = -log10f(v[o].v1); n2[i] = -log10f(v[o].v2);
+    }
+    TRY(dalloc(ctx, &ctx->d_lexkey, nlex)); TRY(dalloc(ctx, &ctx->d_lexv1, nlex)); TRY(dalloc(ctx, &ctx->d_lexv2, nlex));
+    TRY(dalloc(ctx, &ctx->d_lexn1, nlex)); TRY(dalloc(ctx, &ctx->d_lexn2, nlex));
+    TRY(h2d(ctx, ctx->d_lexkey, key.data(), nlex)); TRY(h2d(ctx, ctx->d_lexv1, v1.data(), nlex)); TRY(h2d(ctx, ctx->d_lexv2, v2.data(), nlex));
+    TRY(h2d(ctx, ctx->d_lexn1, n1.data(), nlex)); TRY(h2d(ctx, ctx->d_lexn2, n2.data(), nlex));
+    ctx->nlex = nlex;
+    return CGX_OK;
+}
+#define STR_PAD 32   // zero tokens after the corpus so window scans never leave the buffer
+extern "C" int cgx_upload_index(cgx_ctx *ctx, const cgx_index_host *ix) {
+    if (!ctx || !ix || !ix->str || !ix->rlp || !ix->tstr || !ix->ltar || !ix->rtar || ix->n < 4) return CGX_ERR_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    free_batch(ctx); free_index(ctx);
+    ctx->n = ix->n; ctx->nt = ix->nt;
+    TRY(dalloc(ctx, &ctx->d_str, (size_t)ix->n + STR_PAD)); HIPCHK(hipMemsetAsync(ctx->d_str, 0, ((size_t)ix->n + STR_PAD) * 4, ctx->stream));
+    TRY(h2d(ctx, ctx->d_str, ix->str, ix->n));
+    TRY(dalloc(ctx, &ctx->d_rlp, (size_t)ix->n + STR_PAD)); HIPCHK(hipMemsetAsync(ctx->d_rlp, 0xFF, ((size_t)ix->n + STR_PAD) * 4, ctx->stream));
+    TRY(h2d(ctx, ctx->d_rlp, ix->rlp, ix->n));
+    TRY(dalloc(ctx, &ctx->d_tstr, (size_t)ix->nt + STR_PAD)); HIPCHK(hipMemsetAsync(ctx->d_tstr, 0, ((size_t)ix->nt + STR_PAD) * 4, ctx->stream));
+    TRY(h2d(ctx, ctx->d_tstr, ix->tstr, ix->nt));
+    TRY(dalloc(ctx, &ctx->d_ltar, (size_t)ix->nt + 256)); TRY(dalloc(ctx, &ctx->d_rtar, (size_t)ix->nt + 256));
+    HIPCHK(hipMemsetAsync(ctx->d_ltar, 0xFF, (size_t)ix->nt + 256, ctx->stream)); HIPCHK(hipMemsetAsync(ctx->d_rtar, 0xFF, (size_t)ix->nt + 256, ctx->stream));
+    TRY(h2d(ctx, ctx->d_ltar, ix->ltar, ix->nt)); TRY(h2d(ctx, ctx->d_rtar, ix->rtar, ix->nt));
+    TRY(upload_lex(ctx, ix->lexk, ix->lexv, ix->nlex));
+    TRY(build_tokstart(ctx, ix->str, ix->n));
+    TRY(dalloc(ctx, &ctx->d_sa, (size_t)ix->n));
+    if (ix->sa) { TRY(h2d(ctx, ctx->d_sa, ix->sa, ix->n)); ctx->have_sa = true; }
+    return CGX_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// suffix array on the device: prefix doubling with rocPRIM radix sort.
+// Replaces suffixArrayInt (DC3, SuffixArray.c:51-129); a suffix array is unique, so the
+// result is identical.  The LCP tables of buildLCPTable are not needed by this design.
+// ------------------------------------------------------------------------------------
+__global__ void k_sa_keys(const uint32_t *rank, uint64_t *key, uint32_t *val, uint32_t n, uint32_t h) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t second = (i + h < n) ? (uint64_t)rank[i + h] + 1 : 0;   // a suffix that ends first sorts first
+    key[i] = ((uint64_t)rank[i] << 32) | second;
+    val[i] = (uint32_t)i;
+}
+__global__ void k_sa_rank(const uint32_t *sa, const uint32_t *incl, uint32_t *rank, uint32_t n) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) rank[sa[i]] = incl[i] - 1;
+}
+__global__ void k_copy_i32_u32(const int32_t *a, uint32_t *b, uint32_t n) { size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; if (i < n) b[i] = (uint32_t)a[i]; }
+extern "C" int cgx_build_sa(cgx_ctx *ctx) {
+    if (!ctx || !ctx->d_str) return CGX_ERR_STATE;
+    HIPCHK(hipSetDevice(ctx->device));
+    Timer tm(ctx->stream);
+    uint32_t n = ctx->n;
+    uint32_t *rank = nullptr, *val = nullptr, *sa = nullptr, *flags = nullptr; uint64_t *key = nullptr, *keys = nullptr;
+    TRY(dalloc(ctx, &rank, n)); TRY(dalloc(ctx, &val, n)); TRY(dalloc(ctx, &sa, n)); TRY(dalloc(ctx, &flags, n));
+    TRY(dalloc(ctx, &key, n)); TRY(dalloc(ctx, &keys, n));
+    k_copy_i32_u32<<<nblocks(n, 256), 256, 0, ctx->stream>>>(ctx->d_str, rank, n);
+    uint32_t maxrank = (uint32_t)ctx->last;
+    int rounds = 0;
+    for (uint32_t h = 1;; h *= 2) {
+        k_sa_keys<<<nblocks(n, 256), 256, 0, ctx->stream>>>(rank, key, val, n, h);
+        unsigned hb = 32 + (unsigned)bits_for(maxrank);
+        TRY(sort_pairs(ctx, key, keys, val, sa, n, 0, hb > 64 ? 64 : hb));
+        k_head_flags<<<nblocks(n, 256), 256, 0, ctx->stream>>>(keys, flags, n);
+        TRY(incl_scan(ctx, flags, val, n));                                   // val = dense 1-based rank of each sorted suffix
+        k_sa_rank<<<nblocks(n, 256), 256, 0, ctx->stream>>>(sa, val, rank, n);
+        uint32_t top = 0; TRY(d2h(ctx, &top, val + (n - 1), 1));
+        maxrank = top - 1; rounds++;
+        if (top == n) break;
+        if (h > n) { snprintf(ctx->err, sizeof ctx->err, "suffix array did not converge"); return CGX_ERR_STATE; }
+    }
+    HIPCHK(hipMemcpyAsync(ctx->d_sa, sa, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    dfree(rank); dfree(val); dfree(sa); dfree(flags); dfree(key); dfree(keys);
+    ctx->have_sa = true;
+    ctx->ms["build_sa"] = tm.stop(); ctx->ms["build_sa_rounds"] = rounds;
+    return CGX_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// frequent-pair precomputation (SuffixArray.cu:1132-1340 + precomp kernel GappyLook.cu:740-870)
+// One thread per corpus position instead of one block per (a,b) pair: a coalesced sweep of
+// str with a 14-token window; hits are appended as 64-bit keys and radix-sorted by
+// (pair, start, length), exactly the order of compareUserTotal3.
+// ------------------------------------------------------------------------------------
+template <bool FILL>
+__global__ void k_precomp(cgx_view v, const int8_t *tokrank, uint32_t n, unsigned int *counter, uint64_t *keys, int32_t *miss) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    int ra = -1;
+    if (i < n) { int32_t a = v.str[i]; ra = a >= 2 ? tokrank[a] : -1; }
+    if (ra >= 0 && v.str[i + 1] >= 2) {
+        for (int d = 2; d + 1 <= CGX_MAX_SPAN; d++) {            // b sits d tokens right of a; span d+1 <= 15
+            int32_t t = v.str[i + d];
+            if (t < 2) break;
+            int rb = tokrank[t];
+            if (rb < 0) continue;
+            bool ok = cgx_gap_ok(v, (uint32_t)i + 1, (uint32_t)i + d - 1);
+            uint32_t pair = (uint32_t)(ra * CGX_TOP + rb);
+            if (ok) {
+                unsigned int slot = atomicAdd(counter, 1u);
+                if (FILL) keys[slot] = ((uint64_t)pair << 36) | ((uint64_t)(uint32_t)i << 4) | (uint64_t)d;
+            } else if (!FILL) atomicAdd(&miss[pair], 1);
+        }
+    }
+}
+__global__ void k_precomp_unpack(const uint64_t *keys, uint32_t cnt, uint32_t *start, uint8_t *len, uint32_t *pidx) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= cnt) return;
+    uint64_t k = keys[i]; uint32_t pair = (uint32_t)(k >> 36);
+    start[i] = (uint32_t)((k >> 4) & 0xFFFFFFFFu); len[i] = (uint8_t)(k & 15);
+    if (i == 0 || (uint32_t)(keys[i - 1] >> 36) != pair) pidx[2 * pair] = (uint32_t)i;
+    if (i + 1 == cnt || (uint32_t)(keys[i + 1] >> 36) != pair) pidx[2 * pair + 1] = (uint32_t)i;
+}
+static int install_freq(cgx_ctx *ctx, const int32_t *freq) {
+    std::vector<int8_t> rank((size_t)ctx->last + 2, (int8_t)-1);
+    for (int j = 0; j < CGX_TOP; j++) rank[(size_t)freq[j]] = (int8_t)j;
+    dfree(ctx->d_tokrank); dfree(ctx->d_freq);
+    TRY(dalloc(ctx, &ctx->d_tokrank, rank.size())); TRY(h2d(ctx, ctx->d_tokrank, rank.data(), rank.size()));
+    TRY(dalloc(ctx, &ctx->d_freq, CGX_TOP)); TRY(h2d(ctx, ctx->d_freq, freq, CGX_TOP));
+    memcpy(ctx->freq, freq, sizeof ctx->freq);
+    return CGX_OK;
+}
+extern "C" int cgx_precompute(cgx_ctx *ctx) {
+    if (!ctx || !ctx->d_str || !ctx->d_tokstart) return CGX_ERR_STATE;
+    HIPCHK(hipSetDevice(ctx->device));
+    Timer tm(ctx->stream);
+    // top-100 tokens by (count desc, id asc), then ordered by id (SuffixArray.cu:1175-1176)
+    size_t nts = (size_t)ctx->last + 3;
+    std::vector<int32_t> ts(nts); TRY(d2h(ctx, ts.data(), ctx->d_tokstart, nts));
+    std::vector<std::pair<int32_t, int32_t>> cand;      // (count, id) for ids >= 2 including the final sentinel
+    for (int32_t c = 2; c <= ctx->last; c++) { int32_t cnt = ts[(size_t)c + 1] - ts[c]; if (cnt > 0) cand.push_back({cnt, c}); }
+    if (cand.size() < CGX_TOP) { snprintf(ctx->err, sizeof ctx->err, "fewer than %d distinct source tokens", CGX_TOP); return CGX_ERR_ARG; }
+    std::stable_sort(cand.begin(), cand.end(), [](const std::pair<int32_t, int32_t> &a, const std::pair<int32_t, int32_t> &b) { return a.first > b.first; });
+    int32_t freq[CGX_TOP];
+    for (int j = 0; j < CGX_TOP; j++) freq[j] = cand[j].second;
+    std::sort(freq, freq + CGX_TOP);
+    TRY(install_freq(ctx, freq));
+
+    cgx_view v{ctx->d_str, ctx->d_rlp, ctx->d_ltar, ctx->d_rtar, ctx->n};
+    unsigned int *counter = nullptr; TRY(dalloc(ctx, &counter, 1));
+    dfree(ctx->d_miss); TRY(dalloc(ctx, &ctx->d_miss, CGX_TOP * CGX_TOP));
+    HIPCHK(hipMemsetAsync(ctx->d_miss, 0, sizeof(int32_t) * CGX_TOP * CGX_TOP, ctx->stream));
+    HIPCHK(hipMemsetAsync(counter, 0, sizeof(unsigned int), ctx->stream));
+    k_precomp<false><<<nblocks(ctx->n, 256), 256, 0, ctx->stream>>>(v, ctx->d_tokrank, ctx->n, counter, nullptr, ctx->d_miss);
+    unsigned int cnt = 0; TRY(d2h(ctx, &cnt, counter, 1));
+    uint64_t *keys = nullptr, *skeys = nullptr; TRY(dalloc(ctx, &keys, cnt)); TRY(dalloc(ctx, &skeys, cnt));
+    HIPCHK(hipMemsetAsync(counter, 0, sizeof(unsigned int), ctx->stream));
+    k_precomp<true><<<nblocks(ctx->n, 256), 256, 0, ctx->stream>>>(v, ctx->d_tokrank, ctx->n, counter, keys, ctx->d_miss);
+    if (cnt) TRY(sort_keys(ctx, keys, skeys, cnt, 0, 50));
+    dfree(ctx->d_pidx); dfree(ctx->d_phit_start); dfree(ctx->d_phit_len);
+    TRY(dalloc(ctx, &ctx->d_pidx, 2 * CGX_TOP * CGX_TOP)); TRY(dalloc(ctx, &ctx->d_phit_start, cnt)); TRY(dalloc(ctx, &ctx->d_phit_len, cnt));
+    std::vector<uint32_t> empty(2 * CGX_TOP * CGX_TOP);
+    for (int i = 0; i < CGX_TOP * CGX_TOP; i++) { empty[2 * i] = 1; empty[2 * i + 1] = 0; }        // empty pair = {1,0} (SuffixArray.cu:1306)
+    TRY(h2d(ctx, ctx->d_pidx, empty.data(), empty.size()));
+    if (cnt) k_precomp_unpack<<<nblocks(cnt, 256), 256, 0, ctx->stream>>>(skeys, cnt, ctx->d_phit_start, ctx->d_phit_len, ctx->d_pidx);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    dfree(keys); dfree(skeys); dfree(counter);
+    ctx->nphits = cnt; ctx->have_pre = true;
+    ctx->ms["precompute"] = tm.stop();
+    return CGX_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// multi-GPU replica plumbing
+// ------------------------------------------------------------------------------------
+struct bufdesc { const char *name; void **ptr; uint64_t bytes; };
+static std::vector<bufdesc> index_buffers(cgx_ctx *c) {
+    std::vector<bufdesc> b;
+    b.push_back({"str", (void **)&c->d_str, ((uint64_t)c->n + STR_PAD) * 4});
+    b.push_back({"sa", (void **)&c->d_sa, (uint64_t)c->n * 4});
+    b.push_back({"rlp", (void **)&c->d_rlp, ((uint64_t)c->n + STR_PAD) * 4});
+    b.push_back({"tstr", (void **)&c->d_tstr, ((uint64_t)c->nt + STR_PAD) * 4});
+    b.push_back({"ltar", (void **)&c->d_ltar, (uint64_t)c->nt + 256});
+    b.push_back({"rtar", (void **)&c->d_rtar, (uint64_t)c->nt + 256});
+    b.push_back({"lexkey", (void **)&c->d_lexkey, (uint64_t)c->nlex * 8});
+    b.push_back({"lexv1", (void **)&c->d_lexv1, (uint64_t)c->nlex * 4});
+    b.push_back({"lexv2", (void **)&c->d_lexv2, (uint64_t)c->nlex * 4});
+    b.push_back({"lexn1", (void **)&c->d_lexn1, (uint64_t)c->nlex * 4});
+    b.push_back({"lexn2", (void **)&c->d_lexn2, (uint64_t)c->nlex * 4});
+    b.push_back({"tokstart", (void **)&c->d_tokstart, ((uint64_t)c->last + 3) * 4});
+    b.push_back({"tokrank", (void **)&c->d_tokrank, (uint64_t)c->last + 2});
+    b.push_back({"freq", (void **)&c->d_freq, CGX_TOP * 4});
+    b.push_back({"pidx", (void **)&c->d_pidx, 2 * CGX_TOP * CGX_TOP * 4});
+    b.push_back({"miss", (void **)&c->d_miss, CGX_TOP * CGX_TOP * 4});
+    b.push_back({"phit_start", (void **)&c->d_phit_start, (uint64_t)c->nphits * 4});
+    b.push_back({"phit_len", (void **)&c->d_phit_len, (uint64_t)c->nphits});
+    return b;
+}
+extern "C" int cgx_index_alloc(cgx_ctx *ctx, uint32_t n, uint32_t nt, uint32_t nlex, uint32_t nphits, int32_t last) {
+    if (!ctx) return CGX_ERR_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    free_batch(ctx); free_index(ctx);
+    ctx->n = n; ctx->nt = nt; ctx->nlex = nlex; ctx->nphits = nphits; ctx->last = last;
+    for (auto &b : index_buffers(ctx)) HIPCHK(hipMalloc(b.ptr, b.bytes ? b.bytes : 1));
+    return CGX_OK;
+}
+extern "C" int cgx_index_nbuffers(cgx_ctx *ctx) { return ctx ? (int)index_buffers(ctx).size() : CGX_ERR_ARG; }
+extern "C" int cgx_index_buffer(cgx_ctx *ctx, int i, const char **name, uint64_t *nbytes) {
+    if (!ctx) return CGX_ERR_ARG;
+    auto b = index_buffers(ctx);
+    if (i < 0 || i >= (int)b.size()) return CGX_ERR_ARG;
+    if (name) *name = b[i].name;
+    if (nbytes) *nbytes = b[i].bytes;
+    return CGX_OK;
+}
+extern "C" int cgx_index_d2d(cgx_ctx *ctx, int i, void *dptr, int dir) {
+    if (!ctx || !dptr) return CGX_ERR_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    auto b = index_buffers(ctx);
+    if (i < 0 || i >= (int)b.size() || !*b[i].ptr) return CGX_ERR_ARG;
+    if (b[i].bytes == 0) return CGX_OK;
+    if (dir == 0) HIPCHK(hipMemcpyAsync(dptr, *b[i].ptr, b[i].bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    else HIPCHK(hipMemcpyAsync(*b[i].ptr, dptr, b[i].bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return CGX_OK;
+}
+extern "C" int cgx_index_finalize(cgx_ctx *ctx) {
+    if (!ctx || !ctx->d_freq) return CGX_ERR_STATE;
+    TRY(d2h(ctx, ctx->freq, ctx->d_freq, CGX_TOP));
+    ctx->have_sa = ctx->have_pre = true;
+    return CGX_OK;
+}
+
+
+// one-time broadcast of the whole index over xGMI with RCCL.  librccl is loaded on demand so
+// that single-GPU use never pays for it.
+#include <dlfcn.h>
+typedef int (*nccl_bcast_fn)(const void *, void *, size_t, int, int, void *, hipStream_t);
+typedef int (*nccl_group_fn)(void);
+extern "C" int cgx_broadcast_index(cgx_ctx *ctx, void *nccl_comm, int root, int rank) {
+    if (!ctx || !nccl_comm) return CGX_ERR_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    static void *lib = nullptr; static nccl_bcast_fn bcast = nullptr; static nccl_group_fn gstart = nullptr, gend = nullptr;
+    if (!lib) {
+        lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) { snprintf(ctx->err, sizeof ctx->err, "cannot load librccl: %s", dlerror()); return CGX_ERR_STATE; }
+        bcast = (nccl_bcast_fn)dlsym(lib, "ncclBroadcast"); gstart = (nccl_group_fn)dlsym(lib, "ncclGroupStart"); gend = (nccl_group_fn)dlsym(lib, "ncclGroupEnd");
+        if (!bcast || !gstart || !gend) { snprintf(ctx->err, sizeof ctx->err, "librccl lacks ncclBroadcast"); return CGX_ERR_STATE; }
+    }
+    auto bufs = index_buffers(ctx);
+    for (auto &b : bufs) if (!*b.ptr) { snprintf(ctx->err, sizeof ctx->err, "index buffer %s not allocated (call cgx_index_alloc on non-root ranks)", b.name); return CGX_ERR_STATE; }
+    if (gstart() != 0) return fail(ctx, CGX_ERR_HIP, "ncclGroupStart", hipSuccess);
+    for (auto &b : bufs) if (b.bytes && bcast(*b.ptr, *b.ptr, (size_t)b.bytes, /*ncclUint8*/ 1, root, nccl_comm, ctx->stream) != 0) return fail(ctx, CGX_ERR_HIP, "ncclBroadcast", hipSuccess);
+    if (gend() != 0) return fail(ctx, CGX_ERR_HIP, "ncclGroupEnd", hipSuccess);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (rank != root) return cgx_index_finalize(ctx);
+    return CGX_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// queries
+// ------------------------------------------------------------------------------------
+#define QPAD 16
+extern "C" int cgx_upload_queries(cgx_ctx *ctx, const int32_t *qoff, int32_t nq, const int32_t *qtok, int32_t ntok) {
+    if (!ctx || nq < 0 || ntok < 0 || (nq && !qoff) || (ntok && !qtok)) return CGX_ERR_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    free_batch(ctx);
+    ctx->nq = nq; ctx->ntok = ntok;
+    std::vector<int32_t> off((size_t)nq + 1), t2q((size_t)ntok + 1), tok((size_t)ntok + QPAD, -1);
+    for (int32_t q = 0; q < nq; q++) off[q] = qoff[q];
+    off[nq] = ntok;
+    for (int32_t q = 0; q < nq; q++) {
+        if (off[q] > off[q + 1] || off[q] < 0) { snprintf(ctx->err, sizeof ctx->err, "query offsets not monotone at %d", q); return CGX_ERR_ARG; }
+        for (int32_t t = off[q]; t < off[q + 1]; t++) t2q[t] = q;
+    }
+    for (int32_t t = 0; t < ntok; t++) { tok[t] = qtok[t]; if (qtok[t] > ctx->last || qtok[t] < -1 || qtok[t] == 0 || qtok[t] == 1) tok[t] = -1; }
+    TRY(dalloc(ctx, &ctx->d_qoff, off.size())); TRY(h2d(ctx, ctx->d_qoff, off.data(), off.size()));
+    TRY(dalloc(ctx, &ctx->d_tok2q, t2q.size())); TRY(h2d(ctx, ctx->d_tok2q, t2q.data(), t2q.size()));
+    TRY(dalloc(ctx, &ctx->d_qtok, tok.size())); TRY(h2d(ctx, ctx->d_qtok, tok.data(), tok.size()));
+    ctx->h_qoff = off; ctx->h_tok2q = t2q;
+    return CGX_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// batched SA interval search (replaces K1 + K2, SuffixArray.cu:402-767 and 109-400).
+// One lane per query token.  l = 1 comes from the bucket table; for l = 2..5 the interval of
+// q[t..t+l) is found inside the interval of q[t..t+l-1) by comparing ONE corpus token per
+// probe (str[sa[m] + l-1]); lower and upper bound run in the same loop so each lane keeps
+// two independent gather chains in flight.  The block's query tokens are staged in LDS.
+// Result layout: lm[t] = min(longestmatch, 5); up/down[t*5 + l-1], -1 when l > lm.
+// ------------------------------------------------------------------------------------
+#define LOOK_BS 256
+__global__ __launch_bounds__(LOOK_BS) void k_sa_lookup(const int32_t *__restrict__ str, const int32_t *__restrict__ sa,
+        const int32_t *__restrict__ tokstart, const int32_t *__restrict__ qtok, const int32_t *__restrict__ qoff,
+        const int32_t *__restrict__ tok2q, int32_t ntok, int k1_limit,
+        int32_t *__restrict__ lm, int32_t *__restrict__ up, int32_t *__restrict__ down) {
+    __shared__ int32_t s_tok[LOOK_BS + 8];
+    const int32_t base = (int32_t)(blockIdx.x * LOOK_BS);
+    for (int i = threadIdx.x; i < LOOK_BS + 8; i += LOOK_BS) s_tok[i] = base + i < ntok + QPAD ? qtok[base + i] : -1;   // qtok is padded with -1
+    __syncthreads();
+    const int32_t t = base + (int32_t)threadIdx.x;
+    if (t >= ntok) return;
+    int32_t r_up[5], r_dn[5];
+#pragma unroll
+    for (int l = 0; l < 5; l++) { r_up[l] = -1; r_dn[l] = -1; }
+    int len = 0;
+    const int32_t q = tok2q[t], qs = qoff[q], qe = qoff[q + 1];
+    const int32_t c0 = s_tok[threadIdx.x];
+    if (c0 >= 2 && t - qs < k1_limit) {
+        int32_t lo = tokstart[c0], hi = tokstart[c0 + 1] - 1;
+        if (lo <= hi) {
+            r_up[0] = lo; r_dn[0] = hi; len = 1;
+            for (int l = 1; l < 5; l++) {
+                if (t + l >= qe) break;
+                const int32_t c = s_tok[threadIdx.x + l];
+                if (c < 2) break;
+                // first m in [lo,hi+1) with tok(m) >= c, and first with tok(m) > c
+                int32_t a0 = lo, z0 = hi + 1, a1 = lo, z1 = hi + 1;
+                while (a0 < z0 || a1 < z1) {
+                    int32_t m0 = (a0 + z0) >> 1, m1 = (a1 + z1) >> 1;
+                    int32_t p0 = a0 < z0 ? sa[m0] : 0, p1 = a1 < z1 ? sa[m1] : 0;
+                    int32_t t0 = str[p0 + l], t1 = str[p1 + l];
+                    if (a0 < z0) { if (t0 < c) a0 = m0 + 1; else z0 = m0; }
+                    if (a1 < z1) { if (t1 <= c) a1 = m1 + 1; else z1 = m1; }
+                }
+                if (a0 >= a1) break;
+                lo = a0; hi = a1 - 1;
+                r_up[l] = lo; r_dn[l] = hi; len = l + 1;
+            }
+        }
+    }
+    lm[t] = len;
+#pragma unroll
+    for (int l = 0; l < 5; l++) { up[(size_t)t * 5 + l] = r_up[l]; down[(size_t)t * 5 + l] = r_dn[l]; }
+}
+extern "C" int cgx_sa_lookup(cgx_ctx *ctx) {
+    if (!ctx || !ctx->have_sa || !ctx->d_qtok) return CGX_ERR_STATE;
+    HIPCHK(hipSetDevice(ctx->device));
+    Timer tm(ctx->stream);
+    int32_t T = ctx->ntok;
+    dfree(ctx->d_lm); dfree(ctx->d_up); dfree(ctx->d_down);
+    TRY(dalloc(ctx, &ctx->d_lm, (size_t)T + 1)); TRY(dalloc(ctx, &ctx->d_up, (size_t)T * 5 + 1)); TRY(dalloc(ctx, &ctx->d_down, (size_t)T * 5 + 1));
+    if (T > 0) {
+        hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+        HIPCHK(hipEventRecord(a, ctx->stream));
+        k_sa_lookup<<<nblocks(T, LOOK_BS), LOOK_BS, 0, ctx->stream>>>(ctx->d_str, ctx->d_sa, ctx->d_tokstart, ctx->d_qtok, ctx->d_qoff,
+                                                                     ctx->d_tok2q, T, ctx->k1_limit, ctx->d_lm, ctx->d_up, ctx->d_down);
+        HIPCHK(hipEventRecord(b, ctx->stream)); HIPCHK(hipEventSynchronize(b));
+        float ms = 0; HIPCHK(hipEventElapsedTime(&ms, a, b)); ctx->ms["sa_lookup_kernel"] = ms;
+        (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+        HIPCHK(hipGetLastError());
+    }
+    ctx->ms["sa_lookup"] = tm.stop();
+    return CGX_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// one-gap enumeration (oneGapEnumeration, SuffixArray.cu:928-1039): count -> scan -> fill,
+// so the candidate list comes out in (token, a_len, b start, b_len) order without atomics.
+// ------------------------------------------------------------------------------------
+template <bool FILL>
+__global__ void k_enum1(const int32_t *qtok, const int32_t *qoff, const int32_t *tok2q, const int32_t *lm, int32_t ntok,
+                        uint32_t *count, const uint64_t *offset, cgx_gappy *g, cgx_gappat *p) {
+    int32_t t = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (t >= ntok) return;
+    uint32_t n = 0; uint64_t o = FILL ? offset[t] : 0;
+    int32_t end = qoff[tok2q[t] + 1];
+    if (t < ntok - 1 && t != end - 1 && t != end - 2) {
+        int lms = lm[t];
+        for (int al = 1; al <= lms && al + 2 <= CGX_MAX_SYMBOLS; al++) {
+            for (int32_t s = t + al + 1; s < end && s - t <= CGX_MAX_SPAN; s++) {
+                if (qtok[s] == -1) continue;
+                int lme = lm[s];
+                for (int bl = 1; al + 1 + bl <= CGX_MAX_SYMBOLS && bl <= lme && s - t + bl - 1 <= CGX_MAX_SPAN; bl++) {
+                    if (FILL) {
+                        cgx_gappy gg; gg.qrystart = t; gg.a_len = (uint8_t)al; gg.b_len = (uint8_t)bl; gg.gap = (uint8_t)(s - t - al);
+                        cgx_gappat pp; int num = al + 1 + bl;
+                        for (int i = 0; i < 5; i++) pp.pat[i] = i >= num ? -2 : i < al ? qtok[t + i] : i == al ? -1 : qtok[s + i - 1 - al];
+                        pp.number = (uint8_t)num;
+                        g[o + n] = gg; p[o + n] = pp;
+                    }
+                    n++;
+                }
+            }
+        }
+    }
+    if (!FILL) count[t] = n;
+}
+// 128-bit sort key of a pattern: number, then the five symbols (pad -2 -> 0, gap -1 -> 1, token c -> c)
+__global__ void k_pat_keys(const cgx_gappat *p, uint32_t n, int w, uint64_t *hi, uint64_t *lo) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    cgx_gappat x = p[i];
+    uint64_t h = 0, l = x.number;                         // 128-bit value (h:l), symbols appended w bits at a time
+    for (int j = 0; j < 5; j++) {
+        uint32_t s = x.pat[j] == -2 ? 0u : x.pat[j] == -1 ? 1u : (uint32_t)x.pat[j];
+        h = (h << w) | (l >> (64 - w)); l = (l << w) | s;
+    }
+    hi[i] = h; lo[i] = l;
+}
+__global__ void k_flags128(const uint64_t *hi, const uint64_t *lo, uint32_t *flags, uint32_t n) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) flags[i] = (i == 0 || hi[i] != hi[i - 1] || lo[i] != lo[i - 1]) ? 1u : 0u;
+}
+__global__ void k_make_s1(const cgx_gappy *g, const uint32_t *flags, const uint32_t *incl, uint32_t n, uint32_t *pid, cgx_gapsearch *s1) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t id = incl[i] - 1; pid[i] = id;
+    if (flags[i]) {
+        cgx_gappy x = g[i]; cgx_gapsearch s;
+        s.qrystart = x.qrystart; s.a_len = x.a_len; s.b_len = x.b_len; s.gap = x.gap; s.position = (uint32_t)i; s.sa_start = -1; s.sa_end = -1; s.marker = 0;
+        s1[id] = s;
+    }
+}
+template <class T> __global__ void k_permute(const T *src, const uint32_t *perm, T *dst, uint32_t n) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; if (i < n) dst[i] = src[perm[i]];
+}
+
+// ------------------------------------------------------------------------------------
+// one-gap lookup (oneGapLookUpSA, GappyLook.cu:128-474).  Plan: per distinct pattern pick the
+// occurrence list to drive from (frequent-pair list, a's SA interval or b's, whichever the
+// reference picks); the work items (pattern, occurrence) are flattened with a scan so that
+// heavy patterns spread over the whole chip instead of one block each.
+// ------------------------------------------------------------------------------------
+struct plan1 { int32_t mode; uint32_t base; };          // mode 0 marker, 1 frequent-pair list, 2 forward from a, 3 backward from b
+__device__ __forceinline__ int pre_index_dev(const int8_t *tokrank, int32_t a, int32_t b) {
+    int ra = tokrank[a], rb = tokrank[b];
+    return (ra >= 0 && rb >= 0) ? ra * CGX_TOP + rb : -1;
+}
+__global__ void k_plan1(cgx_gapsearch *s1, uint32_t d1, const int32_t *qtok, const int32_t *lm, const int32_t *up, const int32_t *down,
+                        const int8_t *tokrank, const uint32_t *pidx, plan1 *plan, uint64_t *work) {
+    uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= d1) return;
+    cgx_gapsearch s = s1[id];
+    int al = s.a_len, bl = s.b_len; int32_t t = s.qrystart, sb = t + s.gap + al;
+    plan1 pl; pl.mode = -1; pl.base = 0; uint64_t w = 0;
+    if (s.gap != 0 && t >= 0 && lm[sb] >= bl && lm[t] >= al) {
+        int pre = pre_index_dev(tokrank, qtok[t + al - 1], qtok[sb]);
+        if (pre == -1) {
+            int64_t u1 = up[(size_t)t * 5 + al - 1], d1_ = down[(size_t)t * 5 + al - 1], u2 = up[(size_t)sb * 5 + bl - 1], d2 = down[(size_t)sb * 5 + bl - 1];
+            if (d1_ - u1 <= d2 - u2) { pl.mode = 2; pl.base = (uint32_t)u1; w = (uint64_t)(d1_ - u1 + 1); }
+            else { pl.mode = 3; pl.base = (uint32_t)u2; w = (uint64_t)(d2 - u2 + 1); }
+        } else {
+            int64_t ps = pidx[2 * pre], pe = pidx[2 * pre + 1], dis = pe - ps;
+            if (al == 1 && bl == 1 && dis >= 0) { pl.mode = 0; pl.base = (uint32_t)pre; w = 1; s1[id].marker = 1; }
+            else { pl.mode = 1; pl.base = (uint32_t)ps; w = dis >= 0 ? (uint64_t)(dis + 1) : 0; }
+        }
+    }
+    plan[id] = pl; work[id] = w;
+}
+// hit record key: pattern id (28 bits) | corpus start (32) | length (4)
+#define HITKEY(id, start, len) (((uint64_t)(id) << 36) | ((uint64_t)(uint32_t)(start) << 4) | (uint64_t)(len))
+template <bool FILL>
+__global__ void k_look1(cgx_view v, const int32_t *sa, const cgx_gapsearch *s1, const plan1 *plan, const uint64_t *woff, uint32_t d1,
+                        uint64_t w0, uint64_t nw, const int32_t *qtok, const uint32_t *phs, const uint8_t *phl,
+                        uint8_t *count, const uint32_t *offset, uint64_t *keys) {
+    uint64_t wi = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (wi >= nw) return;
+    uint32_t id = seg_of(woff, d1, w0 + wi);
+    uint64_t x = w0 + wi - woff[id];
+    cgx_gapsearch s = s1[id]; plan1 pl = plan[id];
+    const int al = s.a_len, bl = s.b_len; const int32_t t = s.qrystart, sb = t + s.gap + al;
+    uint32_t n = 0; uint32_t o = FILL ? offset[wi] : 0;
+    if (pl.mode == 0) {
+        if (FILL) keys[o] = HITKEY(id, pl.base, 0);
+        n = 1;
+    } else if (pl.mode == 1) {                            // frequent-pair list entry: check the rest of a and b around it
+        int64_t ps = phs[pl.base + x]; int plen = phl[pl.base + x]; bool ok = plen + al + bl - 1 <= CGX_MAX_SPAN;
+        for (int k = 1; ok && k < al; k++) if (ps - k < 0 || v.str[ps - k] != qtok[t + al - 1 - k]) ok = false;
+        for (int k = 2; ok && k <= bl; k++) if (v.str[ps + plen + k - 1] != qtok[sb + k - 1]) ok = false;
+        if (ok) { if (FILL) keys[o] = HITKEY(id, ps - al + 1, plen + al - 1 + bl - 1); n = 1; }
+    } else if (pl.mode == 2) {                            // scan right from an occurrence of a
+        int64_t go = sa[pl.base + x];
+        if (v.str[go + al] >= 2) {
+            const int32_t b0 = qtok[sb];
+            for (int move = 0; al + 1 + move + bl <= CGX_MAX_SPAN || move == 0; move++) {
+                int32_t tk = v.str[go + al + 1 + move];
+                if (tk < 2) break;
+                if (tk == b0) {
+                    int mc = 1; bool dead = false;
+                    while (mc < bl) { int32_t r = v.str[go + al + 1 + move + mc]; if (r < 2) { dead = true; break; } if (r != qtok[sb + mc]) break; mc++; }
+                    if (dead) break;
+                    if (mc == bl && cgx_gap_ok(v, (uint32_t)(go + al), (uint32_t)(go + al + move))) {
+                        if (FILL) keys[o + n] = HITKEY(id, go, al + 1 + move + bl - 1);
+                        n++;
+                    }
+                }
+            }
+        }
+    } else if (pl.mode == 3) {                            // scan left from an occurrence of b
+        int64_t go = sa[pl.base + x];
+        if (go - 1 >= 0 && v.str[go - 1] >= 2) {
+            const int32_t a_last = qtok[t + al - 1];
+            for (int move = 0; al + 1 + move + bl <= CGX_MAX_SPAN || move == 0; move++) {
+                int64_t pa = go - 2 - move;
+                int32_t tk = pa < 0 ? -1 : v.str[pa];
+                if (tk < 2) break;
+                if (tk == a_last) {
+                    int mc = 1; bool dead = false;
+                    while (mc < al) { int32_t r = pa - mc < 0 ? -1 : v.str[pa - mc]; if (r < 2) { dead = true; break; } if (r != qtok[t + al - 1 - mc]) break; mc++; }
+                    if (dead) break;
+                    if (mc == al && cgx_gap_ok(v, (uint32_t)(pa + 1), (uint32_t)(go - 1))) {
+                        if (FILL) keys[o + n] = HITKEY(id, pa - al + 1, bl + 1 + move + al - 1);
+                        n++;
+                    }
+                }
+            }
+        }
+    }
+    if (!FILL) count[wi] = (uint8_t)n;
+}
+__global__ void k_unpack_hits1(const uint64_t *keys, uint32_t n, cgx_hit1 *hits, cgx_gapsearch *s1) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t k = keys[i]; uint32_t id = (uint32_t)(k >> 36);
+    cgx_hit1 h; h.position = id; h.str_position = (uint32_t)((k >> 4) & 0xFFFFFFFFu); h.length = (uint8_t)(k & 15);
+    hits[i] = h;
+    if (i == 0 || (uint32_t)(keys[i - 1] >> 36) != id) s1[id].sa_start = (int32_t)i;
+    if (i + 1 == n || (uint32_t)(keys[i + 1] >> 36) != id) s1[id].sa_end = (int32_t)i;
+}
+
+// growable device array of u64
+struct dvec64 { uint64_t *p = nullptr; size_t n = 0, cap = 0; };
+static int dvec_reserve(cgx_ctx *ctx, dvec64 &v, size_t need) {
+    if (need <= v.cap) return CGX_OK;
+    size_t nc = v.cap ? v.cap : 1024; while (nc < need) nc *= 2;
+    uint64_t *np = nullptr; TRY(dalloc(ctx, &np, nc));
+    if (v.n) HIPCHK(hipMemcpyAsync(np, v.p, v.n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    dfree(v.p); v.p = np; v.cap = nc;
+    return CGX_OK;
+}
+
+// run a count/fill kernel pair over work items [0,W) in chunks; the lambda launches one pass
+template <class Launch>
+static int chunked_count_fill(cgx_ctx *ctx, uint64_t W, dvec64 &out, Launch launch) {
+    uint64_t chunk = ctx->chunk_items;
+    uint8_t *cnt = nullptr; uint32_t *off = nullptr;
+    uint64_t cw = W < chunk ? W : chunk;
+    TRY(dalloc(ctx, &cnt, cw + 1)); TRY(dalloc(ctx, &off, cw + 1));
+    for (uint64_t w0 = 0; w0 < W; w0 += chunk) {
+        uint64_t nw = W - w0 < chunk ? W - w0 : chunk;
+        HIPCHK(hipMemsetAsync(cnt + nw, 0, 1, ctx->stream));
+        launch(false, w0, nw, cnt, off, (uint64_t *)nullptr);
+        TRY(excl_scan(ctx, cnt, off, nw + 1));
+        uint32_t total = 0; TRY(d2h(ctx, &total, off + nw, 1));
+        TRY(dvec_reserve(ctx, out, out.n + total));
+        if (total) launch(true, w0, nw, cnt, off, out.p + out.n);
+        HIPCHK(hipGetLastError());
+        out.n += total;
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    dfree(cnt); dfree(off);
+    return CGX_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// two-gap enumeration (twoGapEnumeration, SuffixArray.cu:816-926): one lane per sorted one-gap
+// instance; only single-token a, b, c can fit the five-symbol limit.
+// ------------------------------------------------------------------------------------
+template <bool FILL>
+__global__ void k_enum2(const cgx_gappy *g1, const uint32_t *pid1, const cgx_gapsearch *s1, uint32_t e1, const int32_t *qtok, const int32_t *qoff,
+                        const int32_t *tok2q, const int32_t *lm, int32_t ntok, uint32_t *count, const uint64_t *offset, cgx_twogappy *g2, int32_t *c2) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= e1) return;
+    uint32_t n = 0; uint64_t o = FILL ? offset[i] : 0;
+    uint32_t id = pid1[i]; cgx_gapsearch s = s1[id]; cgx_gappy x = g1[i];
+    int limit = CGX_MAX_SYMBOLS - 2 - s.a_len - s.b_len;
+    if (s.sa_start != -1 && s.sa_end != -1 && limit >= 1) {
+        int32_t sstart = x.qrystart + x.a_len + x.gap + x.b_len - 1;
+        if (sstart <= ntok - 1) {
+            int32_t end = qoff[tok2q[sstart] + 1];
+            for (int32_t sc = sstart + 2; sc < end; sc++) {
+                int lme = lm[sc];
+                for (int it = 1; it <= limit && it <= lme && sc - x.qrystart + it - 1 <= CGX_MAX_SPAN; it++) {
+                    if (FILL) { cgx_twogappy t; t.blockid = id; t.gap2 = (uint32_t)sc; t.c_len = (uint8_t)it; g2[o + n] = t; c2[o + n] = qtok[sc]; }
+                    n++;
+                }
+            }
+        }
+    }
+    if (!FILL) count[i] = n;
+}
+__global__ void k_keys2(const cgx_twogappy *g2, const int32_t *c2, uint32_t n, uint64_t *key) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) key[i] = ((uint64_t)g2[i].blockid << 32) | (uint32_t)c2[i];       // (one-gap id, number == 1, c)
+}
+__global__ void k_make_s2(const cgx_twogappy *g, const uint32_t *flags, const uint32_t *incl, uint32_t n, uint32_t *pid, cgx_twogapsearch *s2) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t id = incl[i] - 1; pid[i] = id;
+    if (flags[i]) { cgx_twogappy x = g[i]; cgx_twogapsearch s; s.blockid = x.blockid; s.gap2 = x.gap2; s.c_len = x.c_len; s.position = (uint32_t)i; s.sa_start = -1; s.sa_end = -1; s2[id] = s; }
+}
+// two-gap lookup (twoGapLookUpSA, GappyLook.cu:476-737): extend every occurrence of aXb to the right
+__global__ void k_plan2(const cgx_twogapsearch *s2, uint32_t d2, const cgx_gapsearch *s1, const uint32_t *pidx, const cgx_hit1 *hits1, uint64_t *work) {
+    uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= d2) return;
+    cgx_gapsearch g = s1[s2[id].blockid]; uint64_t w = 0;
+    if (g.sa_start != -1 && s2[id].c_len == 1) {
+        if (g.marker) { uint32_t pre = hits1[g.sa_start].str_position; int64_t ps = pidx[2 * pre], pe = pidx[2 * pre + 1]; w = pe >= ps ? (uint64_t)(pe - ps + 1) : 0; }
+        else w = (uint64_t)(g.sa_end - g.sa_start + 1);
+    }
+    work[id] = w;
+}
+template <bool FILL>
+__global__ void k_look2(cgx_view v, const cgx_twogapsearch *s2, const cgx_gapsearch *s1, const uint64_t *woff, uint32_t d2, uint64_t w0, uint64_t nw,
+                        const int32_t *qtok, const cgx_hit1 *hits1, const uint32_t *pidx, const uint32_t *phs, const uint8_t *phl,
+                        uint8_t *count, const uint32_t *offset, cgx_hit2 *out) {
+    uint64_t wi = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (wi >= nw) return;
+    uint32_t id = seg_of(woff, d2, w0 + wi);
+    uint64_t x = w0 + wi - woff[id];
+    cgx_twogapsearch ts = s2[id]; cgx_gapsearch g = s1[ts.blockid];
+    uint32_t ps; int pl;
+    if (g.marker) { uint32_t pre = hits1[g.sa_start].str_position; uint32_t b = pidx[2 * pre]; ps = phs[b + x]; pl = phl[b + x]; }
+    else { cgx_hit1 h = hits1[g.sa_start + x]; ps = h.str_position; pl = h.length; }
+    uint32_t n = 0; uint32_t o = FILL ? offset[wi] : 0;
+    const int32_t c = qtok[ts.gap2];
+    int64_t go = (int64_t)ps + pl;
+    if (c >= 2 && pl > 0 && v.str[go + 1] >= 2) {
+        for (int move = 0; pl + 3 + move <= CGX_MAX_SPAN; move++) {
+            int32_t tk = v.str[go + 2 + move];
+            if (tk < 2) break;
+            if (tk == c && cgx_gap_ok(v, ps + pl + 1, (uint32_t)(ps + pl + 1 + move))) {
+                if (FILL) { cgx_hit2 h; h.position = id; h.str_position = ps; h.length = (uint8_t)pl; h.length2 = (uint8_t)(pl + 2 + move); out[o + n] = h; }
+                n++;
+            }
+        }
+    }
+    if (!FILL) count[wi] = (uint8_t)n;
+}
+__global__ void k_ranges2(const cgx_hit2 *hits, uint32_t n, cgx_twogapsearch *s2) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t id = hits[i].position;
+    if (i == 0 || hits[i - 1].position != id) s2[id].sa_start = (int32_t)i;
+    if (i + 1 == n || hits[i + 1].position != id) s2[id].sa_end = (int32_t)i;
+}
+
+extern "C" int cgx_gappy_search(cgx_ctx *ctx) {
+    if (!ctx || !ctx->d_lm || !ctx->have_pre) return CGX_ERR_STATE;
+    HIPCHK(hipSetDevice(ctx->device));
+    Timer tm(ctx->stream);
+    const int32_t T = ctx->ntok; hipStream_t st = ctx->stream;
+    cgx_view v{ctx->d_str, ctx->d_rlp, ctx->d_ltar, ctx->d_rtar, ctx->n};
+    dfree(ctx->d_g1); dfree(ctx->d_p1); dfree(ctx->d_pid1); dfree(ctx->d_s1); dfree(ctx->d_hits1);
+    dfree(ctx->d_g2); dfree(ctx->d_c2); dfree(ctx->d_pid2); dfree(ctx->d_s2); dfree(ctx->d_hits2);
+    ctx->e1 = ctx->d1 = ctx->h1 = ctx->e2 = ctx->d2 = ctx->h2 = 0;
+    if (T == 0) { ctx->ms["gappy"] = tm.stop(); return CGX_OK; }
+
+    // ---- one-gap enumeration ----
+    uint32_t *cnt = nullptr; uint64_t *off = nullptr;
+    TRY(dalloc(ctx, &cnt, (size_t)T + 1)); TRY(dalloc(ctx, &off, (size_t)T + 1));
+    HIPCHK(hipMemsetAsync(cnt, 0, ((size_t)T + 1) * 4, st));
+    k_enum1<false><<<nblocks(T, 128), 128, 0, st>>>(ctx->d_qtok, ctx->d_qoff, ctx->d_tok2q, ctx->d_lm, T, cnt, nullptr, nullptr, nullptr);
+    TRY(excl_scan(ctx, cnt, off, (size_t)T + 1));
+    uint64_t e1_64 = 0; TRY(d2h(ctx, &e1_64, off + T, 1));
+    if (e1_64 > 0xFFFFFFF0ull) { snprintf(ctx->err, sizeof ctx->err, "too many one-gap candidates"); return CGX_ERR_NOMEM; }
+    uint32_t E1 = (uint32_t)e1_64; ctx->e1 = E1;
+    cgx_gappy *g_raw = nullptr; cgx_gappat *p_raw = nullptr;
+    TRY(dalloc(ctx, &g_raw, E1)); TRY(dalloc(ctx, &p_raw, E1));
+    if (E1) k_enum1<true><<<nblocks(T, 128), 128, 0, st>>>(ctx->d_qtok, ctx->d_qoff, ctx->d_tok2q, ctx->d_lm, T, cnt, off, g_raw, p_raw);
+    dfree(cnt); dfree(off);
+    TRY(dalloc(ctx, &ctx->d_g1, E1)); TRY(dalloc(ctx, &ctx->d_p1, E1)); TRY(dalloc(ctx, &ctx->d_pid1, E1));
+    uint32_t D1 = 0;
+    if (E1) {
+        // stable sort by (number, symbols): thrust::sort_by_key(oneGapEnumerationCompare), SuffixArray.cu:1598
+        int w = bits_for((uint64_t)ctx->last + 1);
+        if (5 * w + 3 > 128) { snprintf(ctx->err, sizeof ctx->err, "vocabulary too large for the packed pattern key"); return CGX_ERR_ARG; }
+        uint64_t *hi = nullptr, *lo = nullptr, *shi = nullptr, *slo = nullptr; uint32_t *p0 = nullptr, *p1 = nullptr, *flags = nullptr;
+        TRY(dalloc(ctx, &hi, E1)); TRY(dalloc(ctx, &lo, E1)); TRY(dalloc(ctx, &shi, E1)); TRY(dalloc(ctx, &slo, E1));
+        TRY(dalloc(ctx, &p0, E1)); TRY(dalloc(ctx, &p1, E1)); TRY(dalloc(ctx, &flags, E1));
+        k_pat_keys<<<nblocks(E1, 256), 256, 0, st>>>(p_raw, E1, w, hi, lo);
+        k_iota<<<nblocks(E1, 256), 256, 0, st>>>(p0, E1);
+        int total_bits = 5 * w + 3, lo_bits = total_bits < 64 ? total_bits : 64, hi_bits = total_bits > 64 ? total_bits - 64 : 1;
+        TRY(sort_pairs(ctx, lo, slo, p0, p1, E1, 0, (unsigned)lo_bits));
+        k_gather<<<nblocks(E1, 256), 256, 0, st>>>(hi, p1, shi, E1);
+        TRY(sort_pairs(ctx, shi, hi, p1, p0, E1, 0, (unsigned)hi_bits));            // hi = sorted hi, p0 = final permutation
+        k_gather<<<nblocks(E1, 256), 256, 0, st>>>(lo, p0, slo, E1);                 // slo = lo in final order
+        k_permute<<<nblocks(E1, 256), 256, 0, st>>>(g_raw, p0, ctx->d_g1, E1);
+        k_permute<<<nblocks(E1, 256), 256, 0, st>>>(p_raw, p0, ctx->d_p1, E1);
+        k_flags128<<<nblocks(E1, 256), 256, 0, st>>>(hi, slo, flags, E1);            // zeroOneDiff, SuffixArray.cu:1041-1068
+        TRY(incl_scan(ctx, flags, p1, E1));
+        TRY(d2h(ctx, &D1, p1 + (E1 - 1), 1));
+        TRY(dalloc(ctx, &ctx->d_s1, D1));
+        k_make_s1<<<nblocks(E1, 256), 256, 0, st>>>(ctx->d_g1, flags, p1, E1, ctx->d_pid1, ctx->d_s1);
+        HIPCHK(hipStreamSynchronize(st));
+        dfree(hi); dfree(lo); dfree(shi); dfree(slo); dfree(p0); dfree(p1); dfree(flags);
+    }
+    dfree(g_raw); dfree(p_raw);
+    ctx->d1 = D1;
+    if (D1 >= (1u << 28)) { snprintf(ctx->err, sizeof ctx->err, "too many distinct one-gap patterns"); return CGX_ERR_NOMEM; }
+
+    // ---- one-gap lookup ----
+    if (D1) {
+        plan1 *plan = nullptr; uint64_t *work = nullptr, *woff = nullptr;
+        TRY(dalloc(ctx, &plan, D1)); TRY(dalloc(ctx, &work, (size_t)D1 + 1)); TRY(dalloc(ctx, &woff, (size_t)D1 + 1));
+        HIPCHK(hipMemsetAsync(work, 0, ((size_t)D1 + 1) * 8, st));
+        k_plan1<<<nblocks(D1, 256), 256, 0, st>>>(ctx->d_s1, D1, ctx->d_qtok, ctx->d_lm, ctx->d_up, ctx->d_down, ctx->d_tokrank, ctx->d_pidx, plan, work);
+        TRY(excl_scan(ctx, work, woff, (size_t)D1 + 1));
+        uint64_t W = 0; TRY(d2h(ctx, &W, woff + D1, 1));
+        ctx->ms["look1_items"] = (double)W;
+        dvec64 keys;
+        cgx_gapsearch *s1 = ctx->d_s1; const int32_t *sa = ctx->d_sa, *qtok = ctx->d_qtok; const uint32_t *phs = ctx->d_phit_start; const uint8_t *phl = ctx->d_phit_len;
+        TRY(chunked_count_fill(ctx, W, keys, [&](bool fill, uint64_t w0, uint64_t nw, uint8_t *c, uint32_t *o, uint64_t *out) {
+            if (fill) k_look1<true><<<nblocks(nw, 256), 256, 0, st>>>(v, sa, s1, plan, woff, D1, w0, nw, qtok, phs, phl, c, o, out);
+            else k_look1<false><<<nblocks(nw, 256), 256, 0, st>>>(v, sa, s1, plan, woff, D1, w0, nw, qtok, phs, phl, c, o, out);
+        }));
+        if (keys.n > 0xFFFFFFF0ull) { snprintf(ctx->err, sizeof ctx->err, "too many one-gap occurrences"); return CGX_ERR_NOMEM; }
+        uint32_t H1 = (uint32_t)keys.n; ctx->h1 = H1;
+        TRY(dalloc(ctx, &ctx->d_hits1, H1));
+        if (H1) {
+            uint64_t *sk = nullptr; TRY(dalloc(ctx, &sk, H1));
+            TRY(sort_keys(ctx, keys.p, sk, H1, 0, 64));                               // thrust::sort(oneGapSACompare) + canonical tie order
+            k_unpack_hits1<<<nblocks(H1, 256), 256, 0, st>>>(sk, H1, ctx->d_hits1, ctx->d_s1);
+            HIPCHK(hipStreamSynchronize(st));
+            dfree(sk);
+        }
+        dfree(keys.p); dfree(plan); dfree(work); dfree(woff);
+    }
+
+    // ---- two-gap enumeration ----
+    uint32_t E2 = 0, D2 = 0;
+    if (E1 && D1) {
+        TRY(dalloc(ctx, &cnt, (size_t)E1 + 1)); TRY(dalloc(ctx, &off, (size_t)E1 + 1));
+        HIPCHK(hipMemsetAsync(cnt, 0, ((size_t)E1 + 1) * 4, st));
+        k_enum2<false><<<nblocks(E1, 128), 128, 0, st>>>(ctx->d_g1, ctx->d_pid1, ctx->d_s1, E1, ctx->d_qtok, ctx->d_qoff, ctx->d_tok2q, ctx->d_lm, T, cnt, nullptr, nullptr, nullptr);
+        TRY(excl_scan(ctx, cnt, off, (size_t)E1 + 1));
+        uint64_t e2_64 = 0; TRY(d2h(ctx, &e2_64, off + E1, 1));
+        if (e2_64 > 0xFFFFFFF0ull) { snprintf(ctx->err, sizeof ctx->err, "too many two-gap candidates"); return CGX_ERR_NOMEM; }
+        E2 = (uint32_t)e2_64;
+        cgx_twogappy *g2raw = nullptr; int32_t *c2raw = nullptr;
+        TRY(dalloc(ctx, &g2raw, E2)); TRY(dalloc(ctx, &c2raw, E2));
+        if (E2) k_enum2<true><<<nblocks(E1, 128), 128, 0, st>>>(ctx->d_g1, ctx->d_pid1, ctx->d_s1, E1, ctx->d_qtok, ctx->d_qoff, ctx->d_tok2q, ctx->d_lm, T, cnt, off, g2raw, c2raw);
+        dfree(cnt); dfree(off);
+        TRY(dalloc(ctx, &ctx->d_g2, E2)); TRY(dalloc(ctx, &ctx->d_c2, E2)); TRY(dalloc(ctx, &ctx->d_pid2, E2));
+        if (E2) {
+            uint64_t *key = nullptr, *skey = nullptr; uint32_t *p0 = nullptr, *p1 = nullptr, *flags = nullptr;
+            TRY(dalloc(ctx, &key, E2)); TRY(dalloc(ctx, &skey, E2)); TRY(dalloc(ctx, &p0, E2)); TRY(dalloc(ctx, &p1, E2)); TRY(dalloc(ctx, &flags, E2));
+            k_keys2<<<nblocks(E2, 256), 256, 0, st>>>(g2raw, c2raw, E2, key);
+            k_iota<<<nblocks(E2, 256), 256, 0, st>>>(p0, E2);
+            TRY(sort_pairs(ctx, key, skey, p0, p1, E2, 0, 64));                       // sort_by_key(twoGapEnumerationCompare), SuffixArray.cu:1989
+            k_permute<<<nblocks(E2, 256), 256, 0, st>>>(g2raw, p1, ctx->d_g2, E2);
+            k_permute<<<nblocks(E2, 256), 256, 0, st>>>(c2raw, p1, ctx->d_c2, E2);
+            k_head_flags<<<nblocks(E2, 256), 256, 0, st>>>(skey, flags, E2);         // zeroOneDiffTwoGap
+            TRY(incl_scan(ctx, flags, p0, E2));
+            TRY(d2h(ctx, &D2, p0 + (E2 - 1), 1));
+            TRY(dalloc(ctx, &ctx->d_s2, D2));
+            k_make_s2<<<nblocks(E2, 256), 256, 0, st>>>(ctx->d_g2, flags, p0, E2, ctx->d_pid2, ctx->d_s2);
+            HIPCHK(hipStreamSynchronize(st));
+            dfree(key); dfree(skey); dfree(p0); dfree(p1); dfree(flags);
+        }
+        dfree(g2raw); dfree(c2raw);
+    }
+    ctx->e2 = E2; ctx->d2 = D2;
+
+    // ---- two-gap lookup: ordered compaction keeps (pattern, start, length, length2) order, no sort needed ----
+    if (D2) {
+        uint64_t *work = nullptr, *woff = nullptr;
+        TRY(dalloc(ctx, &work, (size_t)D2 + 1)); TRY(dalloc(ctx, &woff, (size_t)D2 + 1));
+        HIPCHK(hipMemsetAsync(work, 0, ((size_t)D2 + 1) * 8, st));
+        k_plan2<<<nblocks(D2, 256), 256, 0, st>>>(ctx->d_s2, D2, ctx->d_s1, ctx->d_pidx, ctx->d_hits1, work);
+        TRY(excl_scan(ctx, work, woff, (size_t)D2 + 1));
+        uint64_t W = 0; TRY(d2h(ctx, &W, woff + D2, 1));
+        ctx->ms["look2_items"] = (double)W;
+        // hit2 records are 10 bytes; reuse the chunk driver with a byte-pair trick: collect per-chunk outputs in a vector of chunks
+        uint64_t chunk = ctx->chunk_items; uint64_t cw = W < chunk ? W : chunk;
+        uint8_t *c8 = nullptr; uint32_t *o32 = nullptr; TRY(dalloc(ctx, &c8, cw + 1)); TRY(dalloc(ctx, &o32, cw + 1));
+        cgx_hit2 *acc = nullptr; size_t accn = 0, acccap = 0;
+        for (uint64_t w0 = 0; w0 < W; w0 += chunk) {
+            uint64_t nw = W - w0 < chunk ? W - w0 : chunk;
+            HIPCHK(hipMemsetAsync(c8 + nw, 0, 1, st));
+            k_look2<false><<<nblocks(nw, 256), 256, 0, st>>>(v, ctx->d_s2, ctx->d_s1, woff, D2, w0, nw, ctx->d_qtok, ctx->d_hits1, ctx->d_pidx, ctx->d_phit_start, ctx->d_phit_len, c8, o32, nullptr);
+            TRY(excl_scan(ctx, c8, o32, nw + 1));
+            uint32_t total = 0; TRY(d2h(ctx, &total, o32 + nw, 1));
+            if (accn + total > acccap) {
+                size_t nc = acccap ? acccap : 1024; while (nc < accn + total) nc *= 2;
+                cgx_hit2 *np = nullptr; TRY(dalloc(ctx, &np, nc));
+                if (accn) HIPCHK(hipMemcpyAsync(np, acc, accn * sizeof(cgx_hit2), hipMemcpyDeviceToDevice, st));
+                HIPCHK(hipStreamSynchronize(st)); dfree(acc); acc = np; acccap = nc;
+            }
+            if (total) k_look2<true><<<nblocks(nw, 256), 256, 0, st>>>(v, ctx->d_s2, ctx->d_s1, woff, D2, w0, nw, ctx->d_qtok, ctx->d_hits1, ctx->d_pidx, ctx->d_phit_start, ctx->d_phit_len, c8, o32, acc + accn);
+            HIPCHK(hipGetLastError());
+            accn += total;
+        }
+        HIPCHK(hipStreamSynchronize(st));
+        if (accn > 0xFFFFFFF0ull) { snprintf(ctx->err, sizeof ctx->err, "too many two-gap occurrences"); return CGX_ERR_NOMEM; }
+        ctx->d_hits2 = acc; ctx->h2 = (uint32_t)accn;
+        if (!acc) TRY(dalloc(ctx, &ctx->d_hits2, 1));
+        if (accn) k_ranges2<<<nblocks(accn, 256), 256, 0, st>>>(ctx->d_hits2, (uint32_t)accn, ctx->d_s2);
+        HIPCHK(hipStreamSynchronize(st));
+        dfree(c8); dfree(o32); dfree(work); dfree(woff);
+    }
+    HIPCHK(hipGetLastError());
+    ctx->ms["gappy"] = tm.stop();
+    return CGX_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// extraction (three launches of ExtractPair.cu:3361, 3492, 3603).  Work item = one SAMPLED
+// occurrence, flattened over blocks / patterns with a scan, so a 300-sample block and a
+// 1-sample block cost what they should.  Valid rules are appended with one atomic per wave
+// (ballot + popcount) as 128-bit sort keys; a radix sort on the whole record then yields the
+// canonical order (id, target start, end, gaps), independent of arrival order.
+// ------------------------------------------------------------------------------------
+struct keybuf { uint64_t *hi, *lo; unsigned int *count; };
+__device__ __forceinline__ void emit_key(keybuf kb, bool valid, uint64_t hi, uint64_t lo) {
+    uint32_t slot = wave_append(kb.count, valid);
+    if (valid) { kb.hi[slot] = hi; kb.lo[slot] = lo; }
+}
+#define K1_HI(r) (((uint64_t)(uint32_t)(r).id << 32) | (uint64_t)(r).tstart)
+#define K1_LO(r) (((uint64_t)(r).end << 16) | ((uint64_t)(r).gap1 << 8) | (uint64_t)(r).gap1_1)
+#define K2_LO(r) (((uint64_t)(r).end << 32) | ((uint64_t)(r).gap1 << 24) | ((uint64_t)(r).gap1_1 << 16) | ((uint64_t)(r).gap2 << 8) | (uint64_t)(r).gap2_1)
+
+__global__ void k_work_blocks(const cgx_block *b, uint32_t g, uint64_t *work) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= g) return;
+    int64_t n = (int64_t)b[i].end - b[i].start + 1;
+    work[i] = (b[i].matchlen < 1 || n < 1) ? 0 : (uint64_t)(n < CGX_SAMPLER ? n : CGX_SAMPLER);
+}
+__global__ void k_extract0(cgx_view v, const int32_t *sa, const cgx_block *blocks, const uint64_t *woff, uint32_t g, uint64_t w0, uint64_t nw,
+                           keybuf k0, keybuf k1, keybuf k2, unsigned int *guard) {
+    uint64_t wi = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    bool active = wi < nw;
+    cgx_r0 ab; cgx_r1 xab, abx; cgx_r2 xabx; ab.valid = 0; xab.valid = 0; abx.valid = 0; xabx.valid = 0;
+    if (active) {
+        uint32_t bn = seg_of(woff, g, w0 + wi);
+        int k = (int)(w0 + wi - woff[bn]);
+        cgx_block b = blocks[bn];
+        int n = b.end - b.start + 1;
+        int x = cgx_sample_index(n, CGX_SAMPLER, k);
+        if (cgx_extract_contig(v, (int32_t)bn, (int32_t)g, b.matchlen, sa[b.start + x], &ab, &xab, &abx, &xabx)) atomicAdd(guard, 1u);
+    }
+    emit_key(k0, ab.valid, ((uint64_t)(uint32_t)ab.block << 32) | (uint32_t)ab.tar_start, ab.tar_end);
+    emit_key(k1, xab.valid, K1_HI(xab), K1_LO(xab));
+    emit_key(k1, abx.valid, K1_HI(abx), K1_LO(abx));
+    emit_key(k2, xabx.valid, K1_HI(xabx), K2_LO(xabx));
+}
+__global__ void k_work_two(const cgx_twogapsearch *s2, uint32_t d2, uint64_t *work) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d2) return;
+    int64_t n = s2[i].sa_start == -1 ? 0 : (int64_t)s2[i].sa_end - s2[i].sa_start + 1;
+    work[i] = (uint64_t)(n < CGX_SAMPLER_TWOGAP ? n : CGX_SAMPLER_TWOGAP);
+}
+__global__ void k_extract2(cgx_view v, const cgx_twogapsearch *s2, const cgx_gapsearch *s1, const cgx_hit2 *hits2, const uint64_t *woff, uint32_t d2,
+                           uint64_t w0, uint64_t nw, keybuf k2, unsigned int *guard) {
+    uint64_t wi = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    cgx_r2 r; r.valid = 0;
+    if (wi < nw) {
+        uint32_t id = seg_of(woff, d2, w0 + wi);
+        int k = (int)(w0 + wi - woff[id]);
+        cgx_twogapsearch ts = s2[id]; cgx_gapsearch g = s1[ts.blockid];
+        int n = ts.sa_end - ts.sa_start + 1;
+        cgx_hit2 h = hits2[ts.sa_start + cgx_sample_index(n, CGX_SAMPLER_TWOGAP, k)];
+        if (cgx_extract_twogap(v, (int32_t)id, g.a_len, g.b_len, ts.c_len, h.str_position, h.length, h.length2, &r)) atomicAdd(guard, 1u);
+    }
+    emit_key(k2, r.valid, K1_HI(r), K2_LO(r));
+}
+__global__ void k_work_one(const cgx_gapsearch *s1, uint32_t d1, const cgx_hit1 *hits1, const uint32_t *pidx, uint64_t *work) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d1) return;
+    cgx_gapsearch s = s1[i]; int64_t n = 0;
+    if (s.sa_start != -1) {
+        if (s.marker) { uint32_t pre = hits1[s.sa_start].str_position; n = (int64_t)pidx[2 * pre + 1] - (int64_t)pidx[2 * pre] + 1; }
+        else n = (int64_t)s.sa_end - s.sa_start + 1;
+    }
+    if (n < 0) n = 0;
+    work[i] = (uint64_t)(n < CGX_SAMPLER_ONEGAP ? n : CGX_SAMPLER_ONEGAP);
+}
+__global__ void k_extract1(cgx_view v, const cgx_gapsearch *s1, const cgx_hit1 *hits1, const uint32_t *pidx, const uint32_t *phs, const uint8_t *phl,
+                           const uint64_t *woff, uint32_t d1, uint64_t w0, uint64_t nw, keybuf k1, keybuf k2, unsigned int *guard) {
+    uint64_t wi = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    cgx_r1 axb; cgx_r2 xaxb, axbx; axb.valid = 0; xaxb.valid = 0; axbx.valid = 0;
+    if (wi < nw) {
+        uint32_t id = seg_of(woff, d1, w0 + wi);
+        int k = (int)(w0 + wi - woff[id]);
+        cgx_gapsearch s = s1[id];
+        uint32_t cur; int fe;
+        if (s.marker) {
+            uint32_t pre = hits1[s.sa_start].str_position; uint32_t b = pidx[2 * pre]; int n = (int)(pidx[2 * pre + 1] - b + 1);
+            int x = cgx_sample_index(n, CGX_SAMPLER_ONEGAP, k); cur = phs[b + x]; fe = phl[b + x];
+        } else {
+            int n = s.sa_end - s.sa_start + 1;
+            cgx_hit1 h = hits1[s.sa_start + cgx_sample_index(n, CGX_SAMPLER_ONEGAP, k)]; cur = h.str_position; fe = h.length;
+        }
+        if (cgx_extract_onegap(v, (int32_t)id, (int32_t)d1, s.a_len, s.b_len, cur, fe, &axb, &xaxb, &axbx)) atomicAdd(guard, 1u);
+    }
+    emit_key(k1, axb.valid, K1_HI(axb), K1_LO(axb));
+    emit_key(k2, xaxb.valid, K1_HI(xaxb), K2_LO(xaxb));
+    emit_key(k2, axbx.valid, K1_HI(axbx), K2_LO(axbx));
+}
+__global__ void k_pack_r0(const uint64_t *hi, const uint64_t *lo, uint32_t n, cgx_rule0 *out) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; if (i >= n) return;
+    cgx_rule0 r; r.block = (int32_t)(hi[i] >> 32); r.tar_start = (int32_t)(hi[i] & 0xFFFFFFFFu); r.tar_end = (uint8_t)lo[i]; out[i] = r;
+}
+__global__ void k_pack_r1(const uint64_t *hi, const uint64_t *lo, uint32_t n, cgx_rule1 *out) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; if (i >= n) return;
+    cgx_rule1 r; r.id = (int32_t)(hi[i] >> 32); r.tstart = (uint32_t)(hi[i] & 0xFFFFFFFFu);
+    r.end = (uint8_t)(lo[i] >> 16); r.gap1 = (uint8_t)(lo[i] >> 8); r.gap1_1 = (uint8_t)lo[i]; out[i] = r;
+}
+__global__ void k_pack_r2(const uint64_t *hi, const uint64_t *lo, uint32_t n, cgx_rule2 *out) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; if (i >= n) return;
+    cgx_rule2 r; r.id = (int32_t)(hi[i] >> 32); r.tstart = (uint32_t)(hi[i] & 0xFFFFFFFFu);
+    r.end = (uint8_t)(lo[i] >> 32); r.gap1 = (uint8_t)(lo[i] >> 24); r.gap1_1 = (uint8_t)(lo[i] >> 16); r.gap2 = (uint8_t)(lo[i] >> 8); r.gap2_1 = (uint8_t)lo[i]; out[i] = r;
+}
+
+__global__ void k_block_starts(cgx_block *b, uint32_t g, const int32_t *sa) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < g) b[i].string_start = sa[b[i].start];
+}
+extern "C" int cgx_set_blocks(cgx_ctx *ctx, cgx_block *blocks, uint32_t g) {
+    if (!ctx || (g && !blocks)) return CGX_ERR_ARG;
+    if (!ctx->have_sa) return CGX_ERR_STATE;
+    HIPCHK(hipSetDevice(ctx->device));
+    for (uint32_t i = 0; i < g; i++) if (blocks[i].start < 0 || (uint32_t)blocks[i].end >= ctx->n || blocks[i].start > blocks[i].end || blocks[i].matchlen < 1 || blocks[i].matchlen > 5) {
+        snprintf(ctx->err, sizeof ctx->err, "block %u is not a valid SA interval", i); return CGX_ERR_ARG; }
+    dfree(ctx->d_blocks);
+    TRY(dalloc(ctx, &ctx->d_blocks, g));
+    if (g) {
+        TRY(h2d(ctx, ctx->d_blocks, blocks, g));
+        k_block_starts<<<nblocks(g, 256), 256, 0, ctx->stream>>>(ctx->d_blocks, g, ctx->d_sa);
+        TRY(d2h(ctx, blocks, ctx->d_blocks, g));
+    }
+    ctx->g = g;
+    return CGX_OK;
+}
+
+// one launch family: scan the per-unit sample counts, run the kernel in chunks, sort the keys
+struct keyset { uint64_t *hi = nullptr, *lo = nullptr; unsigned int *count = nullptr; size_t cap = 0; uint32_t n = 0; };
+static int keyset_alloc(cgx_ctx *ctx, keyset &k, size_t cap) {
+    k.cap = cap; TRY(dalloc(ctx, &k.hi, cap)); TRY(dalloc(ctx, &k.lo, cap)); TRY(dalloc(ctx, &k.count, 1));
+    HIPCHK(hipMemsetAsync(k.count, 0, 4, ctx->stream));
+    return CGX_OK;
+}
+static int keyset_finish(cgx_ctx *ctx, keyset &k, unsigned lo_bits) {
+    unsigned int c = 0; TRY(d2h(ctx, &c, k.count, 1)); k.n = c;
+    if (c > k.cap) { snprintf(ctx->err, sizeof ctx->err, "rule buffer overflow"); return CGX_ERR_STATE; }
+    TRY(sort128(ctx, k.hi, k.lo, c, lo_bits, 64));
+    return CGX_OK;
+}
+static void keyset_free(keyset &k) { dfree(k.hi); dfree(k.lo); dfree(k.count); }
+
+extern "C" int cgx_extract(cgx_ctx *ctx) {
+    if (!ctx || !ctx->d_blocks || !ctx->have_sa) return CGX_ERR_STATE;
+    HIPCHK(hipSetDevice(ctx->device));
+    Timer tm(ctx->stream);
+    hipStream_t st = ctx->stream;
+    cgx_view v{ctx->d_str, ctx->d_rlp, ctx->d_ltar, ctx->d_rtar, ctx->n};
+    dfree(ctx->d_r0); dfree(ctx->d_r1); dfree(ctx->d_r2);
+    unsigned int *guard = nullptr; TRY(dalloc(ctx, &guard, 1)); HIPCHK(hipMemsetAsync(guard, 0, 4, st));
+    const uint32_t G = ctx->g, D1 = ctx->d1, D2 = ctx->d2;
+    uint64_t chunk = ctx->chunk_items;
+
+    // work lists
+    uint64_t *wA = nullptr, *oA = nullptr, *wB = nullptr, *oB = nullptr, *wC = nullptr, *oC = nullptr; uint64_t WA = 0, WB = 0, WC = 0;
+    TRY(dalloc(ctx, &wA, (size_t)G + 1)); TRY(dalloc(ctx, &oA, (size_t)G + 1)); HIPCHK(hipMemsetAsync(wA, 0, ((size_t)G + 1) * 8, st));
+    if (G) k_work_blocks<<<nblocks(G, 256), 256, 0, st>>>(ctx->d_blocks, G, wA);
+    TRY(excl_scan(ctx, wA, oA, (size_t)G + 1)); TRY(d2h(ctx, &WA, oA + G, 1));
+    TRY(dalloc(ctx, &wB, (size_t)D2 + 1)); TRY(dalloc(ctx, &oB, (size_t)D2 + 1)); HIPCHK(hipMemsetAsync(wB, 0, ((size_t)D2 + 1) * 8, st));
+    if (D2) k_work_two<<<nblocks(D2, 256), 256, 0, st>>>(ctx->d_s2, D2, wB);
+    TRY(excl_scan(ctx, wB, oB, (size_t)D2 + 1)); TRY(d2h(ctx, &WB, oB + D2, 1));
+    TRY(dalloc(ctx, &wC, (size_t)D1 + 1)); TRY(dalloc(ctx, &oC, (size_t)D1 + 1)); HIPCHK(hipMemsetAsync(wC, 0, ((size_t)D1 + 1) * 8, st));
+    if (D1) k_work_one<<<nblocks(D1, 256), 256, 0, st>>>(ctx->d_s1, D1, ctx->d_hits1, ctx->d_pidx, wC);
+    TRY(excl_scan(ctx, wC, oC, (size_t)D1 + 1)); TRY(d2h(ctx, &WC, oC + D1, 1));
+    ctx->ms["extract_items"] = (double)(WA + WB + WC);
+    if (WA + 2 * WC > 0x7FFFFFF0ull || 2 * WA > 0x7FFFFFF0ull || WA + WB + 2 * WC > 0x7FFFFFF0ull) { snprintf(ctx->err, sizeof ctx->err, "too many sampled occurrences for one batch"); return CGX_ERR_NOMEM; }
+
+    // launch 1: ab / Xab / abX / XabX
+    keyset a0, a1, a2, b2, c1, c2;
+    TRY(keyset_alloc(ctx, a0, WA)); TRY(keyset_alloc(ctx, a1, 2 * WA)); TRY(keyset_alloc(ctx, a2, WA));
+    for (uint64_t w0 = 0; w0 < WA; w0 += chunk) {
+        uint64_t nw = WA - w0 < chunk ? WA - w0 : chunk;
+        k_extract0<<<nblocks(nw, 256), 256, 0, st>>>(v, ctx->d_sa, ctx->d_blocks, oA, G, w0, nw, keybuf{a0.hi, a0.lo, a0.count}, keybuf{a1.hi, a1.lo, a1.count}, keybuf{a2.hi, a2.lo, a2.count}, guard);
+    }
+    HIPCHK(hipGetLastError());
+    TRY(keyset_finish(ctx, a0, 8)); TRY(keyset_finish(ctx, a1, 24)); TRY(keyset_finish(ctx, a2, 40));
+    // launch 2: aXbXc
+    TRY(keyset_alloc(ctx, b2, WB));
+    for (uint64_t w0 = 0; w0 < WB; w0 += chunk) {
+        uint64_t nw = WB - w0 < chunk ? WB - w0 : chunk;
+        k_extract2<<<nblocks(nw, 256), 256, 0, st>>>(v, ctx->d_s2, ctx->d_s1, ctx->d_hits2, oB, D2, w0, nw, keybuf{b2.hi, b2.lo, b2.count}, guard);
+    }
+    HIPCHK(hipGetLastError());
+    TRY(keyset_finish(ctx, b2, 40));
+    // launch 3: aXb / XaXb / aXbX
+    TRY(keyset_alloc(ctx, c1, WC)); TRY(keyset_alloc(ctx, c2, 2 * WC));
+    for (uint64_t w0 = 0; w0 < WC; w0 += chunk) {
+        uint64_t nw = WC - w0 < chunk ? WC - w0 : chunk;
+        k_extract1<<<nblocks(nw, 256), 256, 0, st>>>(v, ctx->d_s1, ctx->d_hits1, ctx->d_pidx, ctx->d_phit_start, ctx->d_phit_len, oC, D1, w0, nw,
+                                                     keybuf{c1.hi, c1.lo, c1.count}, keybuf{c2.hi, c2.lo, c2.count}, guard);
+    }
+    HIPCHK(hipGetLastError());
+    TRY(keyset_finish(ctx, c1, 24)); TRY(keyset_finish(ctx, c2, 40));
+
+    // concatenate like ExtractPair.cu:3419-3666: r1 = [Xab,abX | aXb], r2 = [XabX | aXbXc | XaXb,aXbX]
+    ctx->n0 = a0.n; ctx->sep1 = a1.n; ctx->n1 = a1.n + c1.n; ctx->sep2a = a2.n; ctx->sep2b = a2.n + b2.n; ctx->n2 = a2.n + b2.n + c2.n;
+    TRY(dalloc(ctx, &ctx->d_r0, ctx->n0)); TRY(dalloc(ctx, &ctx->d_r1, ctx->n1)); TRY(dalloc(ctx, &ctx->d_r2, ctx->n2));
+    if (a0.n) k_pack_r0<<<nblocks(a0.n, 256), 256, 0, st>>>(a0.hi, a0.lo, a0.n, ctx->d_r0);
+    if (a1.n) k_pack_r1<<<nblocks(a1.n, 256), 256, 0, st>>>(a1.hi, a1.lo, a1.n, ctx->d_r1);
+    if (c1.n) k_pack_r1<<<nblocks(c1.n, 256), 256, 0, st>>>(c1.hi, c1.lo, c1.n, ctx->d_r1 + a1.n);
+    if (a2.n) k_pack_r2<<<nblocks(a2.n, 256), 256, 0, st>>>(a2.hi, a2.lo, a2.n, ctx->d_r2);
+    if (b2.n) k_pack_r2<<<nblocks(b2.n, 256), 256, 0, st>>>(b2.hi, b2.lo, b2.n, ctx->d_r2 + a2.n);
+    if (c2.n) k_pack_r2<<<nblocks(c2.n, 256), 256, 0, st>>>(c2.hi, c2.lo, c2.n, ctx->d_r2 + a2.n + b2.n);
+    HIPCHK(hipStreamSynchronize(st));
+    unsigned int gx = 0; TRY(d2h(ctx, &gx, guard, 1)); ctx->guard_exits = gx;
+    keyset_free(a0); keyset_free(a1); keyset_free(a2); keyset_free(b2); keyset_free(c1); keyset_free(c2);
+    dfree(wA); dfree(oA); dfree(wB); dfree(oB); dfree(wC); dfree(oC); dfree(guard);
+    HIPCHK(hipGetLastError());
+    ctx->ms["extract"] = tm.stop();
+    return CGX_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// lexical features (lexicalTaskMaxEF, ExtractPair.cu:2144-2432): one lane per distinct rule
+// ------------------------------------------------------------------------------------
+__global__ void k_lextask(cgx_lexview t, const int32_t *tstr, const cgx_lextask *tasks, uint32_t n, uint32_t n1, uint32_t n12, float *fe, float *ef) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    cgx_lextask k = tasks[i];
+    int kind = i < n1 ? 0 : i < n12 ? 1 : 2;
+    int32_t src[5];
+    for (int j = 0; j < 5; j++) src[j] = k.src[j];
+    float a, b;
+    cgx_maxlex(t, tstr, src, k.nsrc, k.tstart, k.end, k.gap1, k.gap1_1, k.gap2, k.gap2_1, kind, &a, &b);
+    fe[i] = a; ef[i] = b;
+}
+extern "C" int cgx_lex_features(cgx_ctx *ctx, const cgx_lextask *tasks, uint32_t ntask, uint32_t n_onegap, uint32_t n_twogap, float *max_fe, float *max_ef) {
+    if (!ctx || !ctx->d_lexkey || (ntask && (!tasks || !max_fe || !max_ef))) return CGX_ERR_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    Timer tm(ctx->stream);
+    if (ntask) {
+        cgx_lextask *d = nullptr; float *fe = nullptr, *ef = nullptr;
+        TRY(dalloc(ctx, &d, ntask)); TRY(dalloc(ctx, &fe, ntask)); TRY(dalloc(ctx, &ef, ntask));
+        TRY(h2d(ctx, d, tasks, ntask));
+        cgx_lexview t{ctx->d_lexkey, ctx->d_lexv1, ctx->d_lexv2, ctx->d_lexn1, ctx->d_lexn2, ctx->nlex};
+        k_lextask<<<nblocks(ntask, 128), 128, 0, ctx->stream>>>(t, ctx->d_tstr, d, ntask, n_onegap, n_onegap + n_twogap, fe, ef);
+        HIPCHK(hipGetLastError());
+        TRY(d2h(ctx, max_fe, fe, ntask)); TRY(d2h(ctx, max_ef, ef, ntask));
+        dfree(d); dfree(fe); dfree(ef);
+    }
+    ctx->ms["lex"] = tm.stop();
+    return CGX_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// result fetch
+// ------------------------------------------------------------------------------------
+extern "C" int64_t cgx_fetch(cgx_ctx *ctx, const char *name, void *dst, int64_t cap) {
+    if (!ctx || !name) return CGX_ERR_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return CGX_ERR_HIP;
+    const void *src = nullptr; int64_t bytes = -1;
+    uint32_t counts[16] = { ctx->e1, ctx->d1, ctx->h1, ctx->e2, ctx->d2, ctx->h2, ctx->g, ctx->n0, ctx->n1, ctx->n2, ctx->sep1, ctx->sep2a, ctx->sep2b,
+                            ctx->nphits, ctx->guard_exits, (uint32_t)ctx->last };
+    std::string s(name);
+#define ENT(nm, ptr, cnt, T) if (s == nm) { src = (ptr); bytes = (int64_t)(cnt) * (int64_t)sizeof(T); }
+    ENT("sa", ctx->d_sa, ctx->n, int32_t) ENT("tokstart", ctx->d_tokstart, (size_t)ctx->last + 3, int32_t)
+    ENT("freq", ctx->d_freq, CGX_TOP, int32_t) ENT("pidx", ctx->d_pidx, 2 * CGX_TOP * CGX_TOP, uint32_t) ENT("miss", ctx->d_miss, CGX_TOP * CGX_TOP, int32_t)
+    ENT("phit_start", ctx->d_phit_start, ctx->nphits, uint32_t) ENT("phit_len", ctx->d_phit_len, ctx->nphits, uint8_t)
+    ENT("lm", ctx->d_lm, ctx->ntok, int32_t) ENT("up", ctx->d_up, (size_t)ctx->ntok * 5, int32_t) ENT("down", ctx->d_down, (size_t)ctx->ntok * 5, int32_t)
+    ENT("g1", ctx->d_g1, ctx->e1, cgx_gappy) ENT("p1", ctx->d_p1, ctx->e1, cgx_gappat) ENT("pid1", ctx->d_pid1, ctx->e1, uint32_t)
+    ENT("s1", ctx->d_s1, ctx->d1, cgx_gapsearch) ENT("hits1", ctx->d_hits1, ctx->h1, cgx_hit1)
+    ENT("g2", ctx->d_g2, ctx->e2, cgx_twogappy) ENT("c2", ctx->d_c2, ctx->e2, int32_t) ENT("pid2", ctx->d_pid2, ctx->e2, uint32_t)
+    ENT("s2", ctx->d_s2, ctx->d2, cgx_twogapsearch) ENT("hits2", ctx->d_hits2, ctx->h2, cgx_hit2)
+    ENT("r0", ctx->d_r0, ctx->n0, cgx_rule0) ENT("r1", ctx->d_r1, ctx->n1, cgx_rule1) ENT("r2", ctx->d_r2, ctx->n2, cgx_rule2)
+#undef ENT
+    if (s == "counts") { bytes = sizeof counts; if (!dst) return bytes; if (cap < bytes) return CGX_ERR_ARG; memcpy(dst, counts, sizeof counts); return bytes; }
+    if (bytes < 0) { snprintf(ctx->err, sizeof ctx->err, "unknown result %s", name); return CGX_ERR_ARG; }
+    if (!dst) return bytes;
+    if (cap < bytes) { snprintf(ctx->err, sizeof ctx->err, "buffer too small for %s", name); return CGX_ERR_ARG; }
+    if (bytes && !src) { snprintf(ctx->err, sizeof ctx->err, "%s not computed yet", name); return CGX_ERR_STATE; }
+    if (bytes) {
+        if (hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return CGX_ERR_HIP;
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) return CGX_ERR_HIP;
+    }
+    return bytes;
+}

@@ -1,0 +1,699 @@
+/*
+ * cgx_host.c -- host side (plain C) of the extractor: corpus / query / alignment / lexical
+ * table loaders, distinct-phrase bookkeeping, lexicon + feature creation and the grammar
+ * writer.  Everything between those stages runs on the GPU through the C ABI in cgx.h;
+ * nothing here has a CPU fallback for the kernels.
+ *
+ * Reference behaviour followed (file:line in /root/reference):
+ *   corpus tokenisation, ids, sentinels          Start.cu:142-380
+ *   query tokenisation, OOV = -1                 Start.cu:50-132
+ *   alignment -> RLP / L_tar / R_tar             ExtractPair.cu:2639-2739
+ *   lexical table text format                    ExtractPair.cu:2442-2519
+ *   distinct contiguous phrases (blocks)         ExtractPair.cu:2742-2903
+ *   per-query pattern id lists                   SuffixArray.cu:1666-1719, 2056-2097
+ *   lexicon + features                           ExtractPair.c:515-1276
+ *   id -> lexicon ranges                         ExtractPair.cu:3743-3756, 3802-3816, 2082-2106
+ *   grammar files                                PrintResults.c:339-577
+ * Unlike the reference, the lexicon is keyed on integer target-symbol tuples; spellings are
+ * only touched when a line is formatted.
+ */
+#define _GNU_SOURCE
+#include "../../include/cgx.h"
+#include "cgx_internal.h"
+#include <ctype.h>
+#include <errno.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#define SAMPLER 300
+#define LONGEST_SRC 5
+
+static double now_ms(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+
+/* ------------------------------------------------------------------ */
+/* word -> id table                                                    */
+/* ------------------------------------------------------------------ */
+typedef struct { const char **key; int32_t *val; size_t cap, n; } wordmap;
+static uint64_t hash_bytes(const char *s, size_t n) { uint64_t h = 0xcbf29ce484222325ull; for (size_t i = 0; i < n; i++) { h ^= (unsigned char)s[i]; h *= 0x100000001b3ull; } return h; }
+static int wordmap_init(wordmap *m, size_t cap) { m->cap = cap; m->n = 0; m->key = calloc(cap, sizeof *m->key); m->val = calloc(cap, sizeof *m->val); return m->key && m->val ? 0 : -1; }
+static void wordmap_free(wordmap *m) { free(m->key); free(m->val); memset(m, 0, sizeof *m); }
+static int32_t wordmap_get(const wordmap *m, const char *s, size_t len) {
+    if (!m->cap) return -1;
+    size_t i = hash_bytes(s, len) & (m->cap - 1);
+    while (m->key[i]) { if (!strncmp(m->key[i], s, len) && m->key[i][len] == 0) return m->val[i]; i = (i + 1) & (m->cap - 1); }
+    return -1;
+}
+static int wordmap_put(wordmap *m, const char *key, int32_t v) {
+    if ((m->n + 1) * 2 > m->cap) {
+        wordmap b; if (wordmap_init(&b, m->cap * 2)) return -1;
+        for (size_t j = 0; j < m->cap; j++) if (m->key[j]) wordmap_put(&b, m->key[j], m->val[j]);
+        wordmap_free(m); *m = b;
+    }
+    size_t i = hash_bytes(key, strlen(key)) & (m->cap - 1);
+    while (m->key[i]) i = (i + 1) & (m->cap - 1);
+    m->key[i] = key; m->val[i] = v; m->n++;
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* corpus                                                              */
+/* ------------------------------------------------------------------ */
+struct cgx_corpus {
+    uint32_t n, nt; int32_t nsent;
+    int32_t *str, *tstr, *sentind, *tsentind;
+    uint8_t *P;
+    uint32_t *rlp; uint8_t *ltar, *rtar;
+    char **svocab, **tvocab; int32_t nsvocab, ntvocab;   /* id -> spelling, NULL entries when built from ids */
+    wordmap smap, tmap;
+    cgx_lexkey *lexk; cgx_lexval *lexv; uint32_t nlex;
+};
+
+static char *slurp(const char *path, size_t *len) {
+    FILE *f = fopen(path, "rb");
+    if (!f) return NULL;
+    fseek(f, 0, SEEK_END); long sz = ftell(f); fseek(f, 0, SEEK_SET);
+    char *buf = malloc((size_t)sz + 2);
+    if (!buf) { fclose(f); return NULL; }
+    size_t got = fread(buf, 1, (size_t)sz, f); fclose(f);
+    buf[got] = 0; *len = got;
+    return buf;
+}
+#define GROW(arr, cnt, cap) do { if ((cnt) == (cap)) { (cap) = (cap) ? (cap) * 2 : 1024; (arr) = realloc((arr), (cap) * sizeof *(arr)); if (!(arr)) return -1; } } while (0)
+
+/* One side of the bitext.  Lines end at '\n'; words are separated by single blanks only
+ * (strtok(" ")); a word that starts with other white space ends the line (Start.cu:280). */
+static int load_side(const char *path, int32_t **str_out, uint32_t *n_out, uint8_t **P_out, int32_t **sent_out, int32_t *nsent_out,
+                     char ***vocab_out, int32_t *nvocab_out, wordmap *map) {
+    size_t len; char *buf = slurp(path, &len);
+    if (!buf) return -1;
+    int32_t *str = NULL; uint8_t *P = NULL; int32_t *sent = NULL; char **voc = NULL;
+    size_t ns = 0, cs = 0, np = 0, cp = 0, nl = 0, cl = 0, nv = 0, cv = 0;
+    if (wordmap_init(map, 1 << 16)) return -1;
+    GROW(voc, nv, cv); voc[nv++] = NULL; GROW(voc, nv, cv); voc[nv++] = NULL;
+    GROW(sent, nl, cl); sent[nl++] = 0;
+    int32_t last = -1; size_t i = 0;
+    while (i < len) {
+        size_t e = i; while (e < len && buf[e] != '\n') e++;
+        uint8_t local = 0; size_t p = i;
+        for (;;) {
+            while (p < e && buf[p] == ' ') p++;
+            if (p >= e) break;
+            size_t q = p; while (q < e && buf[q] != ' ') q++;
+            if (isspace((unsigned char)buf[p])) break;
+            int32_t id = wordmap_get(map, buf + p, q - p);
+            if (id < 0) {
+                id = (int32_t)map->n + 2; last = id;
+                char *w = malloc(q - p + 1); if (!w) return -1; memcpy(w, buf + p, q - p); w[q - p] = 0;
+                if (wordmap_put(map, w, id)) return -1;
+                GROW(voc, nv, cv); voc[nv++] = w;
+            }
+            GROW(str, ns, cs); str[ns++] = id;
+            if (P_out) { GROW(P, np, cp); P[np++] = local; }
+            local++; p = q;
+        }
+        GROW(str, ns, cs); str[ns++] = 1;
+        if (P_out) { GROW(P, np, cp); P[np++] = 0; }
+        GROW(sent, nl, cl); sent[nl++] = (int32_t)ns;
+        i = e + 1;
+    }
+    free(buf);
+    GROW(str, ns, cs); str[ns++] = 1; if (P_out) { GROW(P, np, cp); P[np++] = 0; }
+    last++;
+    GROW(str, ns, cs); str[ns++] = last; if (P_out) { GROW(P, np, cp); P[np++] = 0; }
+    *str_out = str; *n_out = (uint32_t)ns; if (P_out) *P_out = P;
+    *sent_out = sent; *nsent_out = (int32_t)nl - 1; *vocab_out = voc; *nvocab_out = (int32_t)nv;
+    return 0;
+}
+
+static int pack_alignment(cgx_corpus *c, const uint8_t *Ls, const uint8_t *Rs) {
+    c->rlp = calloc((size_t)c->n + 1, sizeof(uint32_t));
+    if (!c->rlp) return -1;
+    int q = 1;
+    for (uint32_t i = 0; i + 1 < c->n; i++) {
+        if (q <= c->nsent && (int32_t)i == c->sentind[q] - 1) { c->rlp[i] = (uint32_t)c->tsentind[q]; q++; }
+        else c->rlp[i] = ((uint32_t)Ls[i] << 24) | ((uint32_t)Rs[i] << 16) | ((uint32_t)c->P[i] << 8);
+    }
+    return 0;
+}
+static int load_alignment(cgx_corpus *c, const char *path, char *err, size_t errcap) {
+    size_t len; char *buf = slurp(path, &len);
+    if (!buf) { snprintf(err, errcap, "Can not open reference file \"%s\"", path); return CGX_ERR_IO; }
+    uint8_t *Ls = malloc(c->n), *Rs = malloc(c->n);
+    c->ltar = malloc((size_t)c->nt + 1); c->rtar = malloc((size_t)c->nt + 1);
+    if (!Ls || !Rs || !c->ltar || !c->rtar) return CGX_ERR_NOMEM;
+    memset(Ls, 255, c->n); memset(Rs, 255, c->n); memset(c->ltar, 255, c->nt); memset(c->rtar, 255, c->nt);
+    size_t i = 0; int q = -1; int rc = CGX_OK;
+    while (i < len && rc == CGX_OK) {
+        size_t e = i; while (e < len && buf[e] != '\n') e++;
+        q++;
+        if (q >= c->nsent) { snprintf(err, errcap, "alignment file has more lines than the corpus"); rc = CGX_ERR_ARG; break; }
+        size_t p = i; int have_s = 0, s = 0;
+        for (;;) {                                      /* tokens separated by blanks and '-' (ExtractPair.cu:2657) */
+            while (p < e && (buf[p] == ' ' || buf[p] == '-')) p++;
+            if (p >= e) break;
+            size_t t = p; while (t < e && buf[t] != ' ' && buf[t] != '-') t++;
+            if (isspace((unsigned char)buf[p])) break;
+            char tmp[32]; size_t L = t - p < sizeof tmp - 1 ? t - p : sizeof tmp - 1; memcpy(tmp, buf + p, L); tmp[L] = 0;
+            int val = atoi(tmp); p = t;
+            if (!have_s) { s = val; have_s = 1; continue; }
+            have_s = 0;
+            if (s >= 255 || val >= 255 || s < 0 || val < 0) { snprintf(err, errcap, "Not possible, too long sentence"); rc = CGX_ERR_ALIGN_RANGE; break; }
+            uint32_t si = (uint32_t)(c->sentind[q] + s), ti = (uint32_t)(c->tsentind[q] + val);
+            if (si >= c->n || ti >= c->nt) { snprintf(err, errcap, "alignment link outside the corpus on line %d", q + 1); rc = CGX_ERR_ARG; break; }
+            if (Ls[si] == 255 || Rs[si] == 255) Ls[si] = Rs[si] = (uint8_t)val; else if (val > Rs[si]) Rs[si] = (uint8_t)val; else if (val < Ls[si]) Ls[si] = (uint8_t)val;
+            if (c->ltar[ti] == 255 || c->rtar[ti] == 255) c->ltar[ti] = c->rtar[ti] = (uint8_t)s; else if (s > c->rtar[ti]) c->rtar[ti] = (uint8_t)s; else if (s < c->ltar[ti]) c->ltar[ti] = (uint8_t)s;
+        }
+        if (rc == CGX_OK && have_s) { snprintf(err, errcap, "Not possible!"); rc = CGX_ERR_ALIGN_PAIR; }
+        i = e + 1;
+    }
+    free(buf);
+    if (rc == CGX_OK && pack_alignment(c, Ls, Rs)) rc = CGX_ERR_NOMEM;
+    free(Ls); free(Rs);
+    return rc;
+}
+static int load_lex(cgx_corpus *c, const char *path, char *err, size_t errcap) {
+    size_t len; char *buf = slurp(path, &len);
+    if (!buf) { snprintf(err, errcap, "The Word Possibility File is not Found!"); return CGX_ERR_IO; }
+    size_t cap = 0, n = 0, p = 0;
+    const char *w[4]; size_t wl[4];
+    for (;;) {
+        int k = 0;
+        while (k < 4) {                                  /* four white-space separated fields, like `file >> a >> b >> v1 >> v2` */
+            while (p < len && isspace((unsigned char)buf[p])) p++;
+            if (p >= len) break;
+            w[k] = buf + p; size_t q = p; while (q < len && !isspace((unsigned char)buf[q])) q++;
+            wl[k] = q - p; p = q; k++;
+        }
+        if (k < 4) break;
+        int32_t s = wordmap_get(&c->smap, w[0], wl[0]), t = wordmap_get(&c->tmap, w[1], wl[1]);
+        int snull = wl[0] == 4 && !strncmp(w[0], "NULL", 4), tnull = wl[1] == 4 && !strncmp(w[1], "NULL", 4);
+        if (s < 0 && !snull) { printf("Ch Not Available!!! %.*s\n", (int)wl[0], w[0]); continue; }
+        if (t < 0 && !tnull) { printf("En Not Available!!! %.*s\n", (int)wl[1], w[1]); continue; }
+        char f1[64], f2[64]; size_t a = wl[2] < 63 ? wl[2] : 63, b = wl[3] < 63 ? wl[3] : 63;
+        memcpy(f1, w[2], a); f1[a] = 0; memcpy(f2, w[3], b); f2[b] = 0;
+        if (n == cap) { cap = cap ? cap * 2 : 4096; c->lexk = realloc(c->lexk, cap * sizeof *c->lexk); c->lexv = realloc(c->lexv, cap * sizeof *c->lexv); if (!c->lexk || !c->lexv) return CGX_ERR_NOMEM; }
+        c->lexk[n].src = s < 0 ? -1 : s; c->lexk[n].tgt = t < 0 ? -1 : t;
+        c->lexv[n].v1 = strtof(f1, NULL); c->lexv[n].v2 = strtof(f2, NULL); n++;
+    }
+    free(buf);
+    c->nlex = (uint32_t)n;
+    return CGX_OK;
+}
+
+void cgx_corpus_free(cgx_corpus *c) {
+    if (!c) return;
+    for (int32_t i = 0; c->svocab && i < c->nsvocab; i++) free(c->svocab[i]);
+    for (int32_t i = 0; c->tvocab && i < c->ntvocab; i++) free(c->tvocab[i]);
+    free(c->svocab); free(c->tvocab); wordmap_free(&c->smap); wordmap_free(&c->tmap);
+    free(c->str); free(c->tstr); free(c->sentind); free(c->tsentind); free(c->P); free(c->rlp); free(c->ltar); free(c->rtar);
+    free(c->lexk); free(c->lexv); free(c);
+}
+
+cgx_corpus *cgx_corpus_load(const char *src, const char *tgt, const char *align, const char *lex, char *err, size_t errcap) {
+    char dummy[8]; if (!err) { err = dummy; errcap = sizeof dummy; }
+    err[0] = 0;
+    cgx_corpus *c = calloc(1, sizeof *c);
+    if (!c) return NULL;
+    int32_t tn;
+    if (load_side(src, &c->str, &c->n, &c->P, &c->sentind, &c->nsent, &c->svocab, &c->nsvocab, &c->smap)) { snprintf(err, errcap, "Can not open reference file \"%s\"", src); goto bad; }
+    if (load_side(tgt, &c->tstr, &c->nt, NULL, &c->tsentind, &tn, &c->tvocab, &c->ntvocab, &c->tmap)) { snprintf(err, errcap, "Can not open reference file \"%s\"", tgt); goto bad; }
+    if (tn != c->nsent) { snprintf(err, errcap, "source has %d lines, target %d", c->nsent, tn); goto bad; }
+    if (load_lex(c, lex, err, errcap) != CGX_OK) goto bad;
+    if (load_alignment(c, align, err, errcap) != CGX_OK) goto bad;
+    return c;
+bad:
+    cgx_corpus_free(c);
+    return NULL;
+}
+
+cgx_corpus *cgx_corpus_from_ids(const int32_t *str, uint32_t n, const int32_t *sentind, int32_t nsent, const int32_t *tstr, uint32_t nt,
+                                const int32_t *tsentind, const uint8_t *lsrc, const uint8_t *rsrc, const uint8_t *ltar, const uint8_t *rtar,
+                                const cgx_lexkey *lexk, const cgx_lexval *lexv, uint32_t nlex) {
+    cgx_corpus *c = calloc(1, sizeof *c);
+    if (!c) return NULL;
+    c->n = n; c->nt = nt; c->nsent = nsent; c->nlex = nlex;
+    c->str = malloc((size_t)n * 4); c->tstr = malloc((size_t)nt * 4); c->sentind = malloc(((size_t)nsent + 1) * 4); c->tsentind = malloc(((size_t)nsent + 1) * 4);
+    c->P = calloc(n, 1); c->ltar = malloc((size_t)nt + 1); c->rtar = malloc((size_t)nt + 1);
+    c->lexk = malloc(((size_t)nlex + 1) * sizeof *c->lexk); c->lexv = malloc(((size_t)nlex + 1) * sizeof *c->lexv);
+    if (!c->str || !c->tstr || !c->sentind || !c->tsentind || !c->P || !c->ltar || !c->rtar || !c->lexk || !c->lexv) { cgx_corpus_free(c); return NULL; }
+    memcpy(c->str, str, (size_t)n * 4); memcpy(c->tstr, tstr, (size_t)nt * 4);
+    memcpy(c->sentind, sentind, ((size_t)nsent + 1) * 4); memcpy(c->tsentind, tsentind, ((size_t)nsent + 1) * 4);
+    memcpy(c->ltar, ltar, nt); memcpy(c->rtar, rtar, nt); memcpy(c->lexk, lexk, (size_t)nlex * sizeof *lexk); memcpy(c->lexv, lexv, (size_t)nlex * sizeof *lexv);
+    for (int32_t q = 0; q < nsent; q++) for (int32_t i = sentind[q]; i < sentind[q + 1] - 1; i++) c->P[i] = (uint8_t)(i - sentind[q]);
+    if (pack_alignment(c, lsrc, rsrc)) { cgx_corpus_free(c); return NULL; }
+    return c;
+}
+
+int cgx_corpus_upload(cgx_ctx *ctx, const cgx_corpus *c) {
+    if (!ctx || !c) return CGX_ERR_ARG;
+    cgx_index_host ix; memset(&ix, 0, sizeof ix);
+    ix.str = c->str; ix.n = c->n; ix.rlp = c->rlp; ix.tstr = c->tstr; ix.nt = c->nt; ix.ltar = c->ltar; ix.rtar = c->rtar;
+    ix.lexk = c->lexk; ix.lexv = c->lexv; ix.nlex = c->nlex; ix.sa = NULL;
+    int rc = cgx_upload_index(ctx, &ix);
+    if (rc == CGX_OK) rc = cgx_build_sa(ctx);
+    if (rc == CGX_OK) rc = cgx_precompute(ctx);
+    return rc;
+}
+
+/* ------------------------------------------------------------------ */
+/* per batch host state                                                */
+/* ------------------------------------------------------------------ */
+typedef struct { uint32_t *v; uint32_t n, cap; } idlist;
+static int idlist_push(idlist *l, uint32_t x) { if (l->n == l->cap) { l->cap = l->cap ? l->cap * 2 : 8; l->v = realloc(l->v, l->cap * 4); if (!l->v) return -1; } l->v[l->n++] = x; return 0; }
+
+typedef struct {                       /* one lexicon line (red_dup_t, ComTypes.h:244) */
+    int32_t id; uint32_t rule; int32_t f, fsample, paircount;
+    float aa, bb, fscore, fe, ef;
+} lexent;
+typedef struct { int32_t down, up; } range;
+
+typedef struct {
+    const cgx_corpus *c;
+    int32_t nq, ntok; int32_t *qoff, *qtok;
+    int32_t *lm, *up, *down;
+    uint32_t g; cgx_block *blocks;
+    idlist *qblocks, *qone, *qtwo;
+    uint32_t e1, d1, e2, d2, h1;
+    cgx_gappat *p1; cgx_gapsearch *s1; cgx_twogapsearch *s2; int32_t *c2; cgx_hit1 *hits1;
+    uint32_t n0, n1, n2, sep1, sep2a, sep2b;
+    cgx_rule0 *r0; cgx_rule1 *r1; cgx_rule2 *r2;
+    uint32_t *pidx; int32_t *miss;
+    lexent *lex0, *lex1, *lex2; uint32_t nl0, nl1, nl2;
+    range *rng0, *rng1, *rng2;
+    cgx_lextask *tasks; uint32_t ntask;
+} batch;
+
+static void batch_free(batch *b) {
+    free(b->qoff); free(b->qtok); free(b->lm); free(b->up); free(b->down); free(b->blocks);
+    for (int32_t q = 0; q < b->nq; q++) { if (b->qblocks) free(b->qblocks[q].v); if (b->qone) free(b->qone[q].v); if (b->qtwo) free(b->qtwo[q].v); }
+    free(b->qblocks); free(b->qone); free(b->qtwo); free(b->p1); free(b->s1); free(b->s2); free(b->c2); free(b->hits1);
+    free(b->r0); free(b->r1); free(b->r2); free(b->pidx); free(b->miss); free(b->lex0); free(b->lex1); free(b->lex2);
+    free(b->rng0); free(b->rng1); free(b->rng2); free(b->tasks);
+}
+
+static int fetch_alloc(cgx_ctx *ctx, const char *name, void **out, size_t elem, uint32_t *count) {
+    int64_t bytes = cgx_fetch(ctx, name, NULL, 0);
+    if (bytes < 0) return (int)bytes;
+    *out = malloc((size_t)bytes + 16);
+    if (!*out) return CGX_ERR_NOMEM;
+    int64_t got = cgx_fetch(ctx, name, *out, bytes);
+    if (got < 0) return (int)got;
+    if (count) *count = (uint32_t)((size_t)bytes / elem);
+    return CGX_OK;
+}
+
+/* GenerateBlocks: distinct (SA interval, length) in first-seen order; per-query lists without repeats */
+typedef struct { uint64_t *key; uint32_t *val; size_t cap, n; } u64map;
+static int u64map_get_or_add(u64map *m, uint64_t k, uint32_t newid, uint32_t *id, int *added) {
+    if ((m->n + 1) * 2 > m->cap) {
+        size_t oc = m->cap; uint64_t *ok = m->key; uint32_t *ov = m->val;
+        m->cap = oc ? oc * 2 : 4096; m->key = malloc(m->cap * 8); m->val = malloc(m->cap * 4);
+        if (!m->key || !m->val) return -1;
+        memset(m->key, 0xFF, m->cap * 8);
+        for (size_t j = 0; j < oc; j++) if (ok[j] != UINT64_MAX) { size_t i = (size_t)(ok[j] * 0x9E3779B97F4A7C15ull >> 17) & (m->cap - 1); while (m->key[i] != UINT64_MAX) i = (i + 1) & (m->cap - 1); m->key[i] = ok[j]; m->val[i] = ov[j]; }
+        free(ok); free(ov);
+    }
+    size_t i = (size_t)(k * 0x9E3779B97F4A7C15ull >> 17) & (m->cap - 1);
+    while (m->key[i] != UINT64_MAX) { if (m->key[i] == k) { *id = m->val[i]; *added = 0; return 0; } i = (i + 1) & (m->cap - 1); }
+    m->key[i] = k; m->val[i] = newid; m->n++; *id = newid; *added = 1;
+    return 0;
+}
+static int make_blocks(cgx_ctx *ctx, batch *b) {
+    uint32_t cap = 0, g = 0; u64map m; memset(&m, 0, sizeof m);
+    int32_t *lastq = NULL; size_t lqcap = 0;
+    int32_t *sa_first = NULL;       /* string_start = sa[up]: fetched in one gather below */
+    b->qblocks = calloc((size_t)b->nq + 1, sizeof *b->qblocks);
+    if (!b->qblocks) return CGX_ERR_NOMEM;
+    for (int32_t q = 0; q < b->nq; q++) for (int32_t j = b->qoff[q]; j < b->qoff[q + 1]; j++)
+        for (int ct = 1; ct <= b->lm[j] && ct <= LONGEST_SRC; ct++) {
+            int32_t up = b->up[(size_t)j * 5 + ct - 1], down = b->down[(size_t)j * 5 + ct - 1];
+            uint32_t id; int added;
+            if (u64map_get_or_add(&m, ((uint64_t)(uint32_t)up << 3) | (uint64_t)ct, g, &id, &added)) return CGX_ERR_NOMEM;
+            if (added) {
+                if (g == cap) { cap = cap ? cap * 2 : 1024; b->blocks = realloc(b->blocks, (size_t)cap * sizeof *b->blocks); if (!b->blocks) return CGX_ERR_NOMEM; }
+                b->blocks[g].start = up; b->blocks[g].end = down; b->blocks[g].matchlen = ct; b->blocks[g].string_start = -1; g++;
+            }
+            if ((size_t)g > lqcap) { size_t nc = lqcap ? lqcap * 2 : 1024; while (nc < g) nc *= 2; lastq = realloc(lastq, nc * 4); if (!lastq) return CGX_ERR_NOMEM; memset(lastq + lqcap, 0xFF, (nc - lqcap) * 4); lqcap = nc; }
+            if (lastq[id] != q) { lastq[id] = q; if (idlist_push(&b->qblocks[q], id)) return CGX_ERR_NOMEM; }
+        }
+    free(m.key); free(m.val); free(lastq); (void)sa_first;
+    b->g = g;
+    return CGX_OK;
+}
+
+/* per-query lists of distinct pattern ids, ascending (checkDup loops, SuffixArray.cu:1707-1718, 2085-2096) */
+static int pattern_lists(batch *b, const uint32_t *pid, const int32_t *tokpos, uint32_t n, const int32_t *tok2q, idlist **out) {
+    idlist *l = calloc((size_t)b->nq + 1, sizeof *l);
+    int64_t *seen = malloc(((size_t)b->nq + 1) * 8);
+    if (!l || !seen) return CGX_ERR_NOMEM;
+    for (int32_t q = 0; q < b->nq; q++) seen[q] = -1;
+    for (uint32_t i = 0; i < n; i++) { int32_t q = tok2q[tokpos[i]]; if (seen[q] != (int64_t)pid[i]) { seen[q] = pid[i]; if (idlist_push(&l[q], pid[i])) return CGX_ERR_NOMEM; } }
+    free(seen); *out = l;
+    return CGX_OK;
+}
+
+/* ------------------------------------------------------------------ */
+/* lexicon: per id group, distinct target sides in first-occurrence order */
+/* ------------------------------------------------------------------ */
+typedef struct { uint64_t *h; uint32_t *idx; uint32_t *gen; uint32_t cap, cur; } grpmap;
+static int grp_init(grpmap *m) { m->cap = 4096; m->cur = 0; m->h = calloc(m->cap, 8); m->idx = calloc(m->cap, 4); m->gen = calloc(m->cap, 4); return m->h && m->idx && m->gen ? 0 : -1; }
+static void grp_free(grpmap *m) { free(m->h); free(m->idx); free(m->gen); }
+
+/* target side of a rule as a symbol tuple: words, -1 for [X,1], -2 for [X,2] */
+static int target_symbols(const cgx_corpus *c, uint32_t t0, int end, int g1, int g1e, int g2, int g2e, int kind, int32_t *out) {
+    int n = 0; uint32_t t1 = t0 + (uint32_t)end, a = t0 + (uint32_t)g1, b = t0 + (uint32_t)g1e, cs = t0 + (uint32_t)g2, ce = t0 + (uint32_t)g2e;
+    for (uint32_t jj = t0; jj <= t1 && n < 40; jj++) {
+        if (kind >= 1 && jj >= a && jj <= b) { out[n++] = -1; jj = b; }
+        else if (kind >= 2 && jj >= cs && jj <= ce) { out[n++] = -2; jj = ce; }
+        else out[n++] = c->tstr[jj];
+    }
+    return n;
+}
+static uint64_t hash_syms(const int32_t *s, int n) { uint64_t h = 0x9E3779B97F4A7C15ull; for (int i = 0; i < n; i++) { h ^= (uint32_t)s[i]; h *= 0xff51afd7ed558ccdull; h ^= h >> 29; } return h; }
+
+typedef struct { const batch *b; int kind; } lexctx;   /* kind 0 contiguous, 1 one gap, 2 two gaps */
+static int rule_symbols(const batch *b, int kind, uint32_t rule, int32_t *out) {
+    if (kind == 0) return target_symbols(b->c, (uint32_t)b->r0[rule].tar_start, b->r0[rule].tar_end, 0, 0, 0, 0, 0, out);
+    if (kind == 1) return target_symbols(b->c, b->r1[rule].tstart, b->r1[rule].end, b->r1[rule].gap1, b->r1[rule].gap1_1, 0, 0, 1, out);
+    return target_symbols(b->c, b->r2[rule].tstart, b->r2[rule].end, b->r2[rule].gap1, b->r2[rule].gap1_1, b->r2[rule].gap2, b->r2[rule].gap2_1, 2, out);
+}
+static uint32_t grp_find(grpmap *m, const batch *b, int kind, const lexent *lex, const int32_t *sym, int n, uint64_t h) {
+    uint32_t i = (uint32_t)h & (m->cap - 1); int32_t other[48];
+    while (m->gen[i] == m->cur) {
+        if (m->h[i] == h) { int k = rule_symbols(b, kind, lex[m->idx[i]].rule, other); if (k == n && !memcmp(other, sym, (size_t)n * 4)) return m->idx[i]; }
+        i = (i + 1) & (m->cap - 1);
+    }
+    return UINT32_MAX;
+}
+static void grp_add(grpmap *m, uint64_t h, uint32_t idx) { uint32_t i = (uint32_t)h & (m->cap - 1); while (m->gen[i] == m->cur) i = (i + 1) & (m->cap - 1); m->gen[i] = m->cur; m->h[i] = h; m->idx[i] = idx; }
+
+static int marker_fsample(const batch *b, uint32_t one) {          /* ExtractPair.c:895-908 */
+    const cgx_gapsearch *s = &b->s1[one];
+    int fs = 1 + s->sa_end - s->sa_start;
+    if (fs == 1 && b->hits1[s->sa_start].length == 0) { uint32_t pre = b->hits1[s->sa_start].str_position; fs = (int)(1 - b->pidx[2 * pre] + b->pidx[2 * pre + 1] + (uint32_t)b->miss[pre]); }
+    return fs;
+}
+static void scores(lexent *l, uint32_t n) {
+    for (uint32_t i = 0; i < n; i++) {
+        l[i].aa = -log10f((float)l[i].paircount / (float)l[i].fsample);
+        l[i].bb = (float)log10((double)(1 + l[i].paircount));
+        l[i].fscore = (float)log10((double)(1 + l[i].fsample));
+    }
+}
+static int pattern_src(const cgx_gappat *p, int32_t *src) { int n = 0; for (int j = 0; j < p->number; j++) if (p->pat[j] >= 0) src[n++] = p->pat[j]; return n; }
+static int block_src(const batch *b, uint32_t bn, int32_t *src) { const cgx_block *k = &b->blocks[bn]; for (int s = 0; s < k->matchlen; s++) src[s] = b->c->str[k->string_start + s]; return k->matchlen; }
+
+static int push_task(batch *b, uint32_t *cap, uint32_t lexid, const int32_t *src, int nsrc, uint32_t tstart, int end, int g1, int g1e, int g2, int g2e) {
+    if (b->ntask == *cap) { *cap = *cap ? *cap * 2 : 4096; b->tasks = realloc(b->tasks, (size_t)*cap * sizeof *b->tasks); if (!b->tasks) return -1; }
+    cgx_lextask *t = &b->tasks[b->ntask++]; memset(t, 0, sizeof *t);
+    t->lexid = lexid; t->nsrc = (uint8_t)nsrc; for (int j = 0; j < nsrc; j++) t->src[j] = src[j];
+    t->tstart = tstart; t->end = (uint8_t)end; t->gap1 = (uint8_t)g1; t->gap1_1 = (uint8_t)g1e; t->gap2 = (uint8_t)g2; t->gap2_1 = (uint8_t)g2e;
+    return 0;
+}
+static range *make_ranges(const lexent *l, uint32_t nl, uint32_t nid) {
+    range *r = malloc(((size_t)nid + 1) * sizeof *r);
+    if (!r) return NULL;
+    for (uint32_t i = 0; i < nid; i++) r[i].down = r[i].up = -1;
+    for (uint32_t i = 0; i < nl; i++) { if (i == 0 || l[i].id != l[i - 1].id) r[l[i].id].down = (int32_t)i; r[l[i].id].up = (int32_t)i; }
+    return r;
+}
+
+static int build_lexicons(batch *b) {
+    const uint32_t G = b->g, D1 = b->d1, D2 = b->d2;
+    uint32_t taskcap = 0; grpmap gm; int32_t sym[48], src[8];
+    if (grp_init(&gm)) return CGX_ERR_NOMEM;
+    /* ---- one gap: [Xab (bnum) | abX (G+bnum)] ++ [aXb (2G+id)]  (ExtractPair.c:664-936) ---- */
+    int *fs = calloc((size_t)2 * G + D1 + 1, sizeof(int));
+    b->lex1 = malloc(((size_t)b->n1 + 1) * sizeof *b->lex1);
+    if (!fs || !b->lex1) return CGX_ERR_NOMEM;
+    for (uint32_t i = 0; i < b->n1; i++) fs[i < b->sep1 ? (uint32_t)b->r1[i].id : 2 * G + (uint32_t)b->r1[i].id]++;
+    uint32_t nl = 0, cid = 0; int nsrc = 0;
+    for (uint32_t i = 0; i < b->n1; i++) {
+        const cgx_rule1 *r = &b->r1[i];
+        if (i == 0 || r->id != b->r1[i - 1].id || i == b->sep1) {
+            gm.cur++;
+            if (i < b->sep1) { cid = (uint32_t)r->id; nsrc = block_src(b, cid < G ? cid : cid - G, src); }
+            else { cid = 2 * G + (uint32_t)r->id; nsrc = pattern_src(&b->p1[b->s1[r->id].position], src); }
+        }
+        int n = rule_symbols(b, 1, i, sym); uint64_t h = hash_syms(sym, n);
+        uint32_t hit = grp_find(&gm, b, 1, b->lex1, sym, n, h);
+        if (hit != UINT32_MAX) { b->lex1[hit].paircount++; continue; }
+        if (push_task(b, &taskcap, nl, src, nsrc, r->tstart, r->end, r->gap1, r->gap1_1, 0, 0)) return CGX_ERR_NOMEM;
+        lexent *e = &b->lex1[nl]; memset(e, 0, sizeof *e);
+        e->id = (int32_t)cid; e->rule = i; e->paircount = 1; e->f = fs[cid];
+        if (i < b->sep1) { uint32_t real = cid >= G ? cid - G : cid; e->fsample = 1 + b->blocks[real].end - b->blocks[real].start; }
+        else e->fsample = marker_fsample(b, (uint32_t)r->id);
+        if (e->fsample > SAMPLER) e->fsample = SAMPLER;
+        grp_add(&gm, h, nl); nl++;
+    }
+    scores(b->lex1, nl); b->nl1 = nl; free(fs);
+    if (!(b->rng1 = make_ranges(b->lex1, nl, 2 * G + D1))) return CGX_ERR_NOMEM;
+    /* ---- two gaps: [XabX (bnum)] ++ [aXbXc (G+id)] ++ [XaXb (G+D2+id) | aXbX (G+D2+D1+id)]  (ExtractPair.c:939-1276) ---- */
+    fs = calloc((size_t)G + 2 * D1 + D2 + 1, sizeof(int));
+    b->lex2 = malloc(((size_t)b->n2 + 1) * sizeof *b->lex2);
+    if (!fs || !b->lex2) return CGX_ERR_NOMEM;
+    for (uint32_t i = 0; i < b->n2; i++) fs[i < b->sep2a ? (uint32_t)b->r2[i].id : i < b->sep2b ? G + (uint32_t)b->r2[i].id : G + D2 + (uint32_t)b->r2[i].id]++;
+    nl = 0;
+    for (uint32_t i = 0; i < b->n2; i++) {
+        const cgx_rule2 *r = &b->r2[i];
+        if (i == 0 || r->id != b->r2[i - 1].id || i == b->sep2a || i == b->sep2b) {
+            gm.cur++;
+            if (i < b->sep2a) { cid = (uint32_t)r->id; nsrc = block_src(b, cid, src); }
+            else if (i < b->sep2b) { cid = G + (uint32_t)r->id; nsrc = pattern_src(&b->p1[b->s1[b->s2[r->id].blockid].position], src); src[nsrc++] = b->c2[b->s2[r->id].position]; }
+            else { cid = G + D2 + (uint32_t)r->id; uint32_t one = cid >= G + D2 + D1 ? (uint32_t)r->id - D1 : (uint32_t)r->id; nsrc = pattern_src(&b->p1[b->s1[one].position], src); }
+        }
+        int n = rule_symbols(b, 2, i, sym); uint64_t h = hash_syms(sym, n);
+        uint32_t hit = grp_find(&gm, b, 2, b->lex2, sym, n, h);
+        if (hit != UINT32_MAX) { b->lex2[hit].paircount++; continue; }
+        if (push_task(b, &taskcap, nl, src, nsrc, r->tstart, r->end, r->gap1, r->gap1_1, r->gap2, r->gap2_1)) return CGX_ERR_NOMEM;
+        lexent *e = &b->lex2[nl]; memset(e, 0, sizeof *e);
+        e->id = (int32_t)cid; e->rule = i; e->paircount = 1; e->f = fs[cid];
+        if (i < b->sep2a) e->fsample = 1 + b->blocks[r->id].end - b->blocks[r->id].start;
+        else if (i < b->sep2b) e->fsample = 1 + b->s2[r->id].sa_end - b->s2[r->id].sa_start;
+        else e->fsample = marker_fsample(b, cid >= G + D2 + D1 ? (uint32_t)r->id - D1 : (uint32_t)r->id);
+        if (e->fsample > SAMPLER) e->fsample = SAMPLER;
+        grp_add(&gm, h, nl); nl++;
+    }
+    scores(b->lex2, nl); b->nl2 = nl; free(fs);
+    if (!(b->rng2 = make_ranges(b->lex2, nl, G + 2 * D1 + D2))) return CGX_ERR_NOMEM;
+    /* ---- contiguous (ExtractPair.c:515-662) ---- */
+    fs = calloc((size_t)G + 1, sizeof(int));
+    b->lex0 = malloc(((size_t)b->n0 + 1) * sizeof *b->lex0);
+    if (!fs || !b->lex0) return CGX_ERR_NOMEM;
+    for (uint32_t i = 0; i < b->n0; i++) fs[b->r0[i].block]++;
+    nl = 0;
+    for (uint32_t i = 0; i < b->n0; i++) {
+        const cgx_rule0 *r = &b->r0[i];
+        if (i == 0 || r->block != b->r0[i - 1].block) { gm.cur++; nsrc = block_src(b, (uint32_t)r->block, src); }
+        int n = rule_symbols(b, 0, i, sym); uint64_t h = hash_syms(sym, n);
+        uint32_t hit = grp_find(&gm, b, 0, b->lex0, sym, n, h);
+        if (hit != UINT32_MAX) { b->lex0[hit].paircount++; continue; }
+        if (push_task(b, &taskcap, nl, src, nsrc, (uint32_t)r->tar_start, r->tar_end, 0, 0, 0, 0)) return CGX_ERR_NOMEM;
+        lexent *e = &b->lex0[nl]; memset(e, 0, sizeof *e);
+        e->id = r->block; e->rule = i; e->paircount = 1; e->f = fs[r->block];
+        e->fsample = 1 + b->blocks[r->block].end - b->blocks[r->block].start; if (e->fsample > SAMPLER) e->fsample = SAMPLER;
+        grp_add(&gm, h, nl); nl++;
+    }
+    scores(b->lex0, nl); b->nl0 = nl; free(fs);
+    if (!(b->rng0 = make_ranges(b->lex0, nl, G))) return CGX_ERR_NOMEM;
+    grp_free(&gm);
+    return CGX_OK;
+}
+
+/* ------------------------------------------------------------------ */
+/* grammar writer                                                      */
+/* ------------------------------------------------------------------ */
+typedef struct { char *p; size_t n, cap; } sbuf;
+static int sb_need(sbuf *s, size_t extra) { if (s->n + extra + 1 > s->cap) { size_t nc = s->cap ? s->cap : 1 << 16; while (nc < s->n + extra + 1) nc *= 2; s->p = realloc(s->p, nc); if (!s->p) return -1; s->cap = nc; } return 0; }
+static int sb_puts(sbuf *s, const char *x) { size_t L = strlen(x); if (sb_need(s, L)) return -1; memcpy(s->p + s->n, x, L); s->n += L; return 0; }
+static int sb_word(sbuf *s, const cgx_corpus *c, int target, int32_t id) {
+    char **voc = target ? c->tvocab : c->svocab; int32_t nv = target ? c->ntvocab : c->nsvocab;
+    if (voc && id >= 0 && id < nv && voc[id]) return sb_puts(s, voc[id]);
+    char tmp[24]; snprintf(tmp, sizeof tmp, "%c%d", target ? 't' : 's', id);
+    return sb_puts(s, tmp);
+}
+static int sb_block(sbuf *s, const batch *b, uint32_t bn) {
+    const cgx_block *k = &b->blocks[bn];
+    for (int i = 0; i < k->matchlen; i++) { if (i && sb_puts(s, " ")) return -1; if (sb_word(s, b->c, 0, b->c->str[k->string_start + i])) return -1; }
+    return 0;
+}
+static int sb_pattern(sbuf *s, const batch *b, uint32_t one, const char *gap, int lead_space) {
+    const cgx_gappat *p = &b->p1[b->s1[one].position];
+    for (int j = 0; j < p->number; j++) {
+        if ((j || lead_space) && sb_puts(s, " ")) return -1;
+        if (p->pat[j] >= 0) { if (sb_word(s, b->c, 0, p->pat[j])) return -1; } else if (sb_puts(s, gap)) return -1;
+    }
+    return 0;
+}
+/* source side of a rule group from its converted id (ExtractPair.c:743-796, 1021-1123) */
+static int sb_source(sbuf *s, const batch *b, int kind, uint32_t cid) {
+    const uint32_t G = b->g, D1 = b->d1, D2 = b->d2;
+    if (kind == 0) return sb_block(s, b, cid);
+    if (kind == 1) {
+        if (cid < G) return sb_puts(s, "[X,1] ") || sb_block(s, b, cid);
+        if (cid < 2 * G) return sb_block(s, b, cid - G) || sb_puts(s, " [X,1]");
+        return sb_pattern(s, b, cid - 2 * G, "[X,1]", 0);
+    }
+    if (cid < G) return sb_puts(s, "[X,1] ") || sb_block(s, b, cid) || sb_puts(s, " [X,2]");
+    if (cid < G + D2) {
+        const cgx_twogapsearch *t = &b->s2[cid - G];
+        return sb_pattern(s, b, t->blockid, "[X,1]", 0) || sb_puts(s, " [X,2] ") || sb_word(s, b->c, 0, b->c2[t->position]);
+    }
+    if (cid < G + D2 + D1) return sb_puts(s, "[X,1]") || sb_pattern(s, b, cid - G - D2, "[X,2]", 1);
+    return sb_pattern(s, b, cid - G - D2 - D1, "[X,1]", 0) || sb_puts(s, " [X,2]");
+}
+static int sb_target(sbuf *s, const batch *b, int kind, uint32_t rule) {
+    int32_t sym[48]; int n = rule_symbols(b, kind, rule, sym);
+    for (int i = 0; i < n; i++) {
+        if (i && sb_puts(s, " ")) return -1;
+        if (sym[i] == -1) { if (sb_puts(s, "[X,1]")) return -1; } else if (sym[i] == -2) { if (sb_puts(s, "[X,2]")) return -1; }
+        else if (sb_word(s, b->c, 1, sym[i])) return -1;
+    }
+    return 0;
+}
+static int emit_range(sbuf *s, const batch *b, int kind, const lexent *lex, const range *rng, uint32_t id, uint64_t *lines) {
+    if (rng[id].down == -1 || rng[id].up == -1) return 0;
+    for (int32_t i = rng[id].down; i <= rng[id].up; i++) {
+        const lexent *e = &lex[i];
+        if (sb_puts(s, "[X] ||| ") || sb_source(s, b, kind, (uint32_t)e->id) || sb_puts(s, " ||| ") || sb_target(s, b, kind, e->rule)) return -1;
+        if (sb_need(s, 320)) return -1;
+        s->n += (size_t)snprintf(s->p + s->n, 320, " ||| EgivenFCoherent=%f SampleCountF=%f CountEF=%f MaxLexFgivenE=%f MaxLexEgivenF=%f IsSingletonF=%d IsSingletonFE=%d\n",
+                                 e->aa, e->fscore, e->bb, e->fe, e->ef, e->f == 1, e->paircount == 1);
+        (*lines)++;
+    }
+    return 0;
+}
+static int write_grammars(const batch *b, const char *outdir, int32_t first, uint64_t *lines) {
+    const uint32_t G = b->g, D1 = b->d1, D2 = b->d2;
+    sbuf s; memset(&s, 0, sizeof s); char fn[4096];
+    for (int32_t q = 0; q < b->nq; q++) {
+        s.n = 0;
+        for (uint32_t k = 0; k < b->qblocks[q].n; k++) {
+            uint32_t p = b->qblocks[q].v[k];
+            if (emit_range(&s, b, 1, b->lex1, b->rng1, p + G, lines) || emit_range(&s, b, 1, b->lex1, b->rng1, p, lines) ||
+                emit_range(&s, b, 2, b->lex2, b->rng2, p, lines) || emit_range(&s, b, 0, b->lex0, b->rng0, p, lines)) { free(s.p); return CGX_ERR_NOMEM; }
+        }
+        for (uint32_t k = 0; b->qone && k < b->qone[q].n; k++) {
+            uint32_t id = b->qone[q].v[k];
+            if (emit_range(&s, b, 1, b->lex1, b->rng1, 2 * G + id, lines) || emit_range(&s, b, 2, b->lex2, b->rng2, G + D2 + id, lines) ||
+                emit_range(&s, b, 2, b->lex2, b->rng2, G + D2 + D1 + id, lines)) { free(s.p); return CGX_ERR_NOMEM; }
+        }
+        for (uint32_t k = 0; b->qtwo && k < b->qtwo[q].n; k++)
+            if (emit_range(&s, b, 2, b->lex2, b->rng2, G + b->qtwo[q].v[k], lines)) { free(s.p); return CGX_ERR_NOMEM; }
+        snprintf(fn, sizeof fn, "%s/grammar.%d.s", outdir, first + q);
+        FILE *fp = fopen(fn, "w");
+        if (!fp) { free(s.p); return CGX_ERR_IO; }
+        if (s.n && fwrite(s.p, 1, s.n, fp) != s.n) { fclose(fp); free(s.p); return CGX_ERR_IO; }
+        fclose(fp);
+    }
+    free(s.p);
+    return CGX_OK;
+}
+
+/* ------------------------------------------------------------------ */
+/* the whole path for one batch of queries                             */
+/* ------------------------------------------------------------------ */
+static int run_batch(cgx_ctx *ctx, const cgx_corpus *c, batch *b, const char *outdir, int32_t first, uint64_t *nrules) {
+    int rc; double t0 = now_ms(), t;
+    b->c = c;
+    if ((rc = cgx_upload_queries(ctx, b->qoff, b->nq, b->qtok, b->ntok)) != CGX_OK) return rc;
+    if ((rc = cgx_sa_lookup(ctx)) != CGX_OK) return rc;
+    if ((rc = fetch_alloc(ctx, "lm", (void **)&b->lm, 4, NULL)) || (rc = fetch_alloc(ctx, "up", (void **)&b->up, 4, NULL)) || (rc = fetch_alloc(ctx, "down", (void **)&b->down, 4, NULL))) return rc;
+    t = now_ms();
+    if ((rc = make_blocks(ctx, b)) != CGX_OK) return rc;
+    cgx__set_host_ms(ctx, "blocks", now_ms() - t);
+    if ((rc = cgx_set_blocks(ctx, b->blocks, b->g)) != CGX_OK) return rc;   /* also fills string_start = sa[start] (ExtractPair.cu:2798) */
+    if ((rc = cgx_gappy_search(ctx)) != CGX_OK) return rc;
+    if ((rc = cgx_extract(ctx)) != CGX_OK) return rc;
+    /* device results needed by the host stages */
+    uint32_t *pid1 = NULL, *pid2 = NULL; cgx_gappy *g1 = NULL; cgx_twogappy *g2 = NULL; uint32_t counts[16];
+    if (cgx_fetch(ctx, "counts", counts, sizeof counts) < 0) return CGX_ERR_HIP;
+    b->sep1 = counts[10]; b->sep2a = counts[11]; b->sep2b = counts[12];
+    if ((rc = fetch_alloc(ctx, "pid1", (void **)&pid1, 4, &b->e1)) || (rc = fetch_alloc(ctx, "g1", (void **)&g1, sizeof *g1, NULL)) ||
+        (rc = fetch_alloc(ctx, "p1", (void **)&b->p1, sizeof *b->p1, NULL)) || (rc = fetch_alloc(ctx, "s1", (void **)&b->s1, sizeof *b->s1, &b->d1)) ||
+        (rc = fetch_alloc(ctx, "hits1", (void **)&b->hits1, sizeof *b->hits1, &b->h1)) ||
+        (rc = fetch_alloc(ctx, "pid2", (void **)&pid2, 4, &b->e2)) || (rc = fetch_alloc(ctx, "g2", (void **)&g2, sizeof *g2, NULL)) ||
+        (rc = fetch_alloc(ctx, "c2", (void **)&b->c2, 4, NULL)) || (rc = fetch_alloc(ctx, "s2", (void **)&b->s2, sizeof *b->s2, &b->d2)) ||
+        (rc = fetch_alloc(ctx, "r0", (void **)&b->r0, sizeof *b->r0, &b->n0)) || (rc = fetch_alloc(ctx, "r1", (void **)&b->r1, sizeof *b->r1, &b->n1)) ||
+        (rc = fetch_alloc(ctx, "r2", (void **)&b->r2, sizeof *b->r2, &b->n2)) ||
+        (rc = fetch_alloc(ctx, "pidx", (void **)&b->pidx, 4, NULL)) || (rc = fetch_alloc(ctx, "miss", (void **)&b->miss, 4, NULL))) return rc;
+    t = now_ms();
+    {   /* per-query pattern lists */
+        int32_t *tok2q = malloc(((size_t)b->ntok + 1) * 4), *pos1 = malloc(((size_t)b->e1 + 1) * 4), *pos2 = malloc(((size_t)b->e2 + 1) * 4);
+        if (!tok2q || !pos1 || !pos2) return CGX_ERR_NOMEM;
+        for (int32_t q = 0; q < b->nq; q++) for (int32_t k = b->qoff[q]; k < b->qoff[q + 1]; k++) tok2q[k] = q;
+        for (uint32_t i = 0; i < b->e1; i++) pos1[i] = g1[i].qrystart;
+        for (uint32_t i = 0; i < b->e2; i++) pos2[i] = (int32_t)g2[i].gap2;
+        if ((rc = pattern_lists(b, pid1, pos1, b->e1, tok2q, &b->qone)) || (rc = pattern_lists(b, pid2, pos2, b->e2, tok2q, &b->qtwo))) return rc;
+        free(tok2q); free(pos1); free(pos2);
+    }
+    free(pid1); free(pid2); free(g1); free(g2);
+    cgx__set_host_ms(ctx, "lists", now_ms() - t);
+    t = now_ms();
+    if ((rc = build_lexicons(b)) != CGX_OK) return rc;
+    cgx__set_host_ms(ctx, "lexicon", now_ms() - t);
+    {   /* MaxLex features on the device, scattered back (ExtractPair.cu:3965-3982) */
+        float *fe = malloc(((size_t)b->ntask + 1) * 4), *ef = malloc(((size_t)b->ntask + 1) * 4);
+        if (!fe || !ef) return CGX_ERR_NOMEM;
+        if ((rc = cgx_lex_features(ctx, b->tasks, b->ntask, b->nl1, b->nl2, fe, ef)) != CGX_OK) return rc;
+        for (uint32_t i = 0; i < b->ntask; i++) {
+            lexent *e = i < b->nl1 ? &b->lex1[b->tasks[i].lexid] : i < b->nl1 + b->nl2 ? &b->lex2[b->tasks[i].lexid] : &b->lex0[b->tasks[i].lexid];
+            e->fe = fe[i]; e->ef = ef[i];
+        }
+        free(fe); free(ef);
+    }
+    uint64_t lines = 0;
+    t = now_ms();
+    if (outdir) {
+        fprintf(stderr, "Start Printing Gappy Phrases...\n");
+        if ((rc = write_grammars(b, outdir, first, &lines)) != CGX_OK) return rc;
+    } else lines = (uint64_t)b->nl0 + b->nl1 + b->nl2;
+    cgx__set_host_ms(ctx, "write", now_ms() - t);
+    cgx__set_host_ms(ctx, "total", now_ms() - t0);
+    if (nrules) *nrules = lines;
+    return CGX_OK;
+}
+
+int cgx_extract_grammars_ids(cgx_ctx *ctx, const cgx_corpus *c, const int32_t *qoff, int32_t nq, const int32_t *qtok, int32_t ntok,
+                             const char *outdir, int32_t first, uint64_t *nrules) {
+    if (!ctx || !c || nq < 0 || ntok < 0) return CGX_ERR_ARG;
+    batch b; memset(&b, 0, sizeof b);
+    b.nq = nq; b.ntok = ntok;
+    b.qoff = malloc(((size_t)nq + 1) * 4); b.qtok = malloc(((size_t)ntok + 1) * 4);
+    if (!b.qoff || !b.qtok) return CGX_ERR_NOMEM;
+    memcpy(b.qoff, qoff, (size_t)nq * 4); b.qoff[nq] = ntok; memcpy(b.qtok, qtok, (size_t)ntok * 4);
+    int rc = run_batch(ctx, c, &b, outdir, first, nrules);
+    batch_free(&b);
+    return rc;
+}
+
+int cgx_extract_grammars(cgx_ctx *ctx, const cgx_corpus *c, const char *qryfile, const char *outdir, int32_t q_begin, int32_t q_end, uint64_t *nrules) {
+    if (!ctx || !c || !qryfile) return CGX_ERR_ARG;
+    size_t len; char *buf = slurp(qryfile, &len);
+    if (!buf) return CGX_ERR_IO;
+    int32_t *off = NULL, *tok = NULL; size_t no = 0, co = 0, nt = 0, ct = 0; size_t i = 0; int32_t line = 0;
+    while (i < len) {                                     /* constructQryIndex, Start.cu:74-111 */
+        size_t e = i; while (e < len && buf[e] != '\n') e++;
+        int take = line >= q_begin && (q_end < 0 || line < q_end);
+        if (take) { if (no == co) { co = co ? co * 2 : 256; off = realloc(off, co * 4); if (!off) return CGX_ERR_NOMEM; } off[no++] = (int32_t)nt; }
+        size_t p = i;
+        for (; take;) {
+            while (p < e && buf[p] == ' ') p++;
+            if (p >= e) break;
+            size_t q = p; while (q < e && buf[q] != ' ') q++;
+            if (isspace((unsigned char)buf[p])) break;
+            int32_t id = wordmap_get(&c->smap, buf + p, q - p);
+            if (nt == ct) { ct = ct ? ct * 2 : 1024; tok = realloc(tok, ct * 4); if (!tok) return CGX_ERR_NOMEM; }
+            tok[nt++] = id < 0 ? -1 : id;
+            p = q;
+        }
+        line++; i = e + 1;
+    }
+    free(buf);
+    int rc = cgx_extract_grammars_ids(ctx, c, off, (int32_t)no, tok, (int32_t)nt, outdir, q_begin > 0 ? q_begin : 0, nrules);
+    free(off); free(tok);
+    return rc;
+}

@@ -1,0 +1,392 @@
+// cgx_rules.h -- per-occurrence alignment logic of the extraction and gap-validation kernels.
+//
+// Everything here is a pure function of the read-only index arrays, marked CGX_HD so the
+// same text compiles for gfx950 (hipcc) and, for the CPU sanitizer/unit-test build under
+// tests/cpu_sim only, for the host.  The product links only the device instantiation.
+//
+// Reference semantics followed (file:line in /root/reference):
+//   gap validity            checkBoundaryGap          GappyLook.cu:43-126
+//   tight back-projection   consistent                ExtractPair.cu:103-133
+//   span helpers            checkBoundaryFast/Fast2   ExtractPair.cu:135-250
+//   span with error codes   checkBoundary             ExtractPair.cu:252-342
+//   ab / Xab / abX / XabX   extractConsistentPairs_Gappy   ExtractPair.cu:1055-1795
+//   aXbXc                   extractConsistentPairs_TwoGap  ExtractPair.cu:891-1053
+//   aXb / XaXb / aXbX       extractConsistentPairs_OneGap  ExtractPair.cu:351-889
+//   sampling                ExtractPair.cu:1143-1160, 454-471, 955-972
+//   MaxLex features         lexicalTaskMaxEF          ExtractPair.cu:2144-2432
+#ifndef CGX_RULES_H
+#define CGX_RULES_H
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define CGX_HD __host__ __device__ __forceinline__
+#else
+#define CGX_HD inline
+#endif
+
+#define CGX_MAX_SPAN 15
+#define CGX_MAX_SYMBOLS 5
+#define CGX_TOP 100
+#define CGX_SAMPLER 300
+#define CGX_SAMPLER_ONEGAP 65
+#define CGX_SAMPLER_TWOGAP 70
+#define CGX_MAXSCORE 99.0f
+
+struct cgx_view {            // read-only index arrays (device pointers on the GPU)
+    const int32_t *str;      // source tokens
+    const uint32_t *rlp;     // (L<<24)|(R<<16)|(P<<8) per source token; delimiter slot = target offset of next sentence
+    const uint8_t *ltar;     // per target token: min aligned source position (in sentence), 255 = none
+    const uint8_t *rtar;
+    uint32_t n;
+};
+
+// running min/max of aligned target positions over a set of source tokens
+struct cgx_span {
+    int lo, hi;              // 255 / 0 when empty, like the reference's unsigned chars
+    CGX_HD void reset() { lo = 255; hi = 0; }
+    CGX_HD void add(int L, int R) { if (lo > L) lo = L; if (hi < R) hi = R; }
+    CGX_HD bool empty() const { return lo > hi; }
+};
+
+CGX_HD int cgx_L(uint32_t w) { return (int)((w >> 24) & 0xFF); }
+CGX_HD int cgx_R(uint32_t w) { return (int)((w >> 16) & 0xFF); }
+CGX_HD int cgx_P(uint32_t w) { return (int)((w >> 8) & 0xFF); }
+CGX_HD bool cgx_unaligned(uint32_t w) { return cgx_L(w) == 255 || cgx_R(w) == 255; }
+
+// sentence bookkeeping for the token at k: *src0 = index of the first token of its source
+// sentence, returns the offset of its target sentence (GappyLook.cu:70-77)
+CGX_HD int cgx_sentence(const cgx_view &v, int k, uint32_t w, int *src0) {
+    int prev_delim = k - cgx_P(w) - 1;
+    *src0 = prev_delim + 1;
+    return prev_delim == -1 ? 0 : (int)v.rlp[prev_delim];
+}
+
+// Does the target span [ts,te] project back exactly onto source [s_chk,e_chk]?  Unaligned
+// target words inside the span are ignored (ExtractPair.cu:103-133).
+CGX_HD bool cgx_tight(const cgx_view &v, int ts, int te, int s_chk, int e_chk, int src0) {
+    int lo = 255, hi = 0;
+    for (int k = ts; k <= te; k++) {
+        int L = v.ltar[k], R = v.rtar[k];
+        if (L == 255 || R == 255) continue;
+        if (k == ts) { lo = L; hi = R; } else { if (lo > L) lo = L; if (hi < R) hi = R; }
+    }
+    return src0 + lo == s_chk && src0 + hi == e_chk;
+}
+
+// Source span [start,ender] accumulated into a target span.  Returns false when an edge
+// token is unaligned (ExtractPair.cu:154-181).  *src0/*tb are set from the first token.
+CGX_HD bool cgx_edge_span(const cgx_view &v, uint32_t start, uint32_t ender, cgx_span *sp, int *src0, int *tb) {
+    sp->reset(); *src0 = 0; *tb = -1;
+    for (uint32_t k = start; k <= ender; k++) {
+        uint32_t w = v.rlp[k];
+        bool un = cgx_unaligned(w);
+        if (un && (k == start || k == ender)) return false;
+        if (un) continue;
+        if (k == start) { *tb = cgx_sentence(v, (int)k, w, src0); sp->lo = cgx_L(w); sp->hi = cgx_R(w); }
+        else sp->add(cgx_L(w), cgx_R(w));
+    }
+    return true;
+}
+
+// checkBoundaryGap: is [start,ender] a valid gap (edges aligned, target width < 15, tight)?
+CGX_HD bool cgx_gap_ok(const cgx_view &v, uint32_t start, uint32_t ender) {
+    cgx_span sp; int src0, tb;
+    if (!cgx_edge_span(v, start, ender, &sp, &src0, &tb)) return false;
+    if (sp.empty() || sp.hi - sp.lo >= CGX_MAX_SPAN) return false;
+    return cgx_tight(v, sp.lo + tb, sp.hi + tb, (int)start, (int)ender, src0);
+}
+
+// checkBoundary: whole-phrase span with the reference's result codes
+//   0 not consistent, 1 consistent, 2 first token unaligned, 3 last token unaligned, 4 both.
+// *ts/*te receive the target span computed from the aligned tokens even when the code != 1.
+CGX_HD int cgx_span_code(const cgx_view &v, uint32_t start, uint32_t ender, uint32_t *ts, uint32_t *te) {
+    int lo = 255, hi = 0, src0 = 0, tb = -1, wrong = 0;
+    for (uint32_t k = start; k <= ender; k++) {
+        uint32_t w = v.rlp[k];
+        bool un = cgx_unaligned(w);
+        if (un && (k == start || k == ender)) {
+            if (start == ender && wrong == 0) wrong = 4;
+            else if (wrong == 0 && k == start) wrong = 2;
+            else if (wrong == 0 && k == ender) wrong = 3;
+            else wrong = 4;
+            if (k == start) tb = cgx_sentence(v, (int)k, w, &src0);
+        } else if (un) {
+        } else if (k == start) { tb = cgx_sentence(v, (int)k, w, &src0); lo = cgx_L(w); hi = cgx_R(w); }
+        else { if (lo > cgx_L(w)) lo = cgx_L(w); if (hi < cgx_R(w)) hi = cgx_R(w); }
+    }
+    *ts = (uint32_t)(lo + tb); *te = (uint32_t)(hi + tb);
+    if (wrong) return wrong;
+    if (lo <= hi && hi - lo < CGX_MAX_SPAN && cgx_tight(v, (int)*ts, (int)*te, (int)start, (int)ender, src0)) return 1;
+    return 0;
+}
+
+// index of the k-th sampled occurrence out of n with cap S (n > S): ROUND(k * (float)n/(float)S)
+CGX_HD int cgx_sample_index(int n, int S, int k) {
+    if (n <= S) return k;
+    float step = (float)n / (float)S;
+    return (int)((double)((float)k * step) + 0.5);
+}
+
+// ---- outputs of one occurrence ----
+struct cgx_r0 { int32_t tar_start, block; uint8_t tar_end; uint8_t valid; };
+struct cgx_r1 { int32_t id; uint32_t tstart; uint8_t end, gap1, gap1_1, valid; };
+struct cgx_r2 { int32_t id; uint32_t tstart; uint8_t end, gap1, gap1_1, gap2, gap2_1, valid; };
+
+CGX_HD void cgx_put1(cgx_r1 *o, int32_t id, uint32_t ts, uint32_t te, uint32_t gs, uint32_t ge) {
+    o->id = id; o->tstart = ts; o->end = (uint8_t)(te - ts); o->gap1 = (uint8_t)(gs - ts); o->gap1_1 = (uint8_t)(ge - ts); o->valid = 1;
+}
+CGX_HD void cgx_put2(cgx_r2 *o, int32_t id, uint32_t ts, uint32_t te, uint32_t g1s, uint32_t g1e, uint32_t g2s, uint32_t g2e) {
+    o->id = id; o->tstart = ts; o->end = (uint8_t)(te - ts); o->gap1 = (uint8_t)(g1s - ts); o->gap1_1 = (uint8_t)(g1e - ts);
+    o->gap2 = (uint8_t)(g2s - ts); o->gap2_1 = (uint8_t)(g2e - ts); o->valid = 1;
+}
+
+// One sampled corpus occurrence (starting at source position cur, lm tokens) of contiguous
+// block bnum: emits ab, the first consistent Xab and abX, and the first consistent XabX.
+// Returns true when the reference thread would have taken one of its `printf; return;`
+// exits (ExtractPair.cu:1306-1314 etc.), which also cancels its later strided occurrences.
+CGX_HD bool cgx_extract_contig(const cgx_view &v, int32_t bnum, int32_t G, int lm, int cur,
+                               cgx_r0 *o_ab, cgx_r1 *o_Xab, cgx_r1 *o_abX, cgx_r2 *o_XabX) {
+    o_ab->valid = 0; o_Xab->valid = 0; o_abX->valid = 0; o_XabX->valid = 0;
+    const int ender = cur + lm - 1;
+    int src0 = 0, tb = -1;
+    cgx_span body; body.reset();
+    bool abX = true, Xab = true, XabX = true, ab = true, XabOpen = true, abXOpen = true;
+    for (int k = cur; k <= ender; k++) {
+        uint32_t w = v.rlp[k];
+        if (k == cur) tb = cgx_sentence(v, k, w, &src0);
+        if (cgx_unaligned(w)) {
+            if (k == cur || k == ender) { ab = false; if (k == cur) abXOpen = false; else XabOpen = false; }
+        } else body.add(cgx_L(w), cgx_R(w));
+    }
+    if (body.empty() || body.hi - body.lo >= CGX_MAX_SPAN) { abX = Xab = XabX = ab = false; }
+    if (ab && cgx_tight(v, body.lo + tb, body.hi + tb, cur, ender, src0)) {
+        o_ab->tar_start = body.lo + tb; o_ab->tar_end = (uint8_t)(body.hi - body.lo); o_ab->block = bnum; o_ab->valid = 1;
+    }
+    if (lm + 1 > CGX_MAX_SYMBOLS) { abX = false; Xab = false; }
+    if (lm + 2 > CGX_MAX_SYMBOLS) XabX = false;
+    cgx_span left, right, other; left.reset(); right.reset(); other.reset();
+    int leftLen = 0, rightLen = 0;                 // XabCount / abXCount: widest tight gap seen so far on each side
+    uint32_t gs = 0, ge = 0, ts = 0, te = 0;
+    for (int i = 1; lm + i <= CGX_MAX_SPAN && (abXOpen || XabOpen || XabX); i++) {
+        if (Xab && cur - i >= 0 && v.str[cur - i] >= 2) {                // widen the left gap by one token
+            bool next = true;
+            uint32_t w = v.rlp[cur - i];
+            if (cgx_unaligned(w)) { next = false; if (i == 1) { Xab = false; XabX = false; } }
+            else left.add(cgx_L(w), cgx_R(w));
+            if (next && left.empty()) return true;
+            if (left.hi - left.lo >= CGX_MAX_SPAN) { next = false; Xab = false; }
+            if (next) {
+                gs = (uint32_t)(tb + left.lo); ge = (uint32_t)(tb + left.hi);
+                next = cgx_tight(v, (int)gs, (int)ge, cur - i, cur - 1, src0);
+                if (next) leftLen = i;
+            }
+            if (XabOpen && next) {
+                ts = (uint32_t)(tb + (left.lo < body.lo ? left.lo : body.lo));
+                te = (uint32_t)(tb + (left.hi < body.hi ? body.hi : left.hi));
+                if (ts > te) return true;
+                if (te - ts >= CGX_MAX_SPAN) { next = false; Xab = false; }
+                if (next) next = cgx_tight(v, (int)ts, (int)te, cur - i, ender, src0);
+                if (next) { cgx_put1(o_Xab, bnum, ts, te, gs, ge); XabOpen = false; }
+            }
+        } else Xab = false;
+
+        if (abX && v.str[ender + i] >= 2) {                              // widen the right gap by one token
+            bool next = true;
+            uint32_t w = v.rlp[ender + i];
+            if (cgx_unaligned(w)) { next = false; if (i == 1) { abX = false; XabX = false; } }
+            else right.add(cgx_L(w), cgx_R(w));
+            if (next && right.empty()) return true;
+            if (right.hi - right.lo >= CGX_MAX_SPAN) { next = false; abX = false; }
+            if (next) {
+                gs = (uint32_t)(tb + right.lo); ge = (uint32_t)(tb + right.hi);
+                next = cgx_tight(v, (int)gs, (int)ge, ender + 1, ender + i, src0);
+                if (next) rightLen = i;
+            }
+            if (abXOpen && next) {
+                ts = (uint32_t)(tb + (right.lo < body.lo ? right.lo : body.lo));
+                te = (uint32_t)(tb + (right.hi < body.hi ? body.hi : right.hi));
+                if (ts > te) return true;
+                if (te - ts >= CGX_MAX_SPAN) { next = false; abX = false; }
+                if (next) next = cgx_tight(v, (int)ts, (int)te, cur, ender + i, src0);
+                if (next) { cgx_put1(o_abX, G + bnum, ts, te, gs, ge); abXOpen = false; }
+            }
+        } else abX = false;
+
+        if (XabX && (abX || Xab)) {
+            if (leftLen == i) {                    // the left gap of width i is tight: pair it with right gaps 1..rightLen
+                other.reset();
+                for (int ic = 1; XabX && ic <= rightLen; ic++) {
+                    bool next = true;
+                    if (ic + leftLen + lm <= CGX_MAX_SPAN) {
+                        uint32_t w = v.rlp[ender + ic];
+                        if (cgx_unaligned(w)) { next = false; if (i == 1) return true; }
+                        else other.add(cgx_L(w), cgx_R(w));
+                    } else { next = false; ic = rightLen + 1; }
+                    if (next && other.hi - other.lo >= CGX_MAX_SPAN) { next = false; ic = rightLen + 1; }
+                    uint32_t g2s = 0, g2e = 0;
+                    if (next) {
+                        if (other.empty()) return true;
+                        g2s = (uint32_t)(tb + other.lo); g2e = (uint32_t)(tb + other.hi);
+                        next = cgx_tight(v, (int)g2s, (int)g2e, ender + 1, ender + ic, src0);
+                    }
+                    if (next) {
+                        int lo = other.lo < left.lo ? other.lo : left.lo; if (lo > body.lo) lo = body.lo;
+                        int hi = other.hi < left.hi ? left.hi : other.hi; if (hi < body.hi) hi = body.hi;
+                        ts = (uint32_t)(tb + lo); te = (uint32_t)(tb + hi);
+                        if (ts > te) return true;
+                        if (te - ts >= CGX_MAX_SPAN) { next = false; ic = rightLen + 1; }
+                        if (next) next = cgx_tight(v, (int)ts, (int)te, cur - leftLen, ender + ic, src0);
+                        if (next) { cgx_put2(o_XabX, bnum, ts, te, (uint32_t)(tb + left.lo), (uint32_t)(tb + left.hi), g2s, g2e); XabX = false; }
+                    }
+                }
+            }
+            if (XabX && rightLen == i) {           // the right gap of width i is tight: pair it with left gaps 1..leftLen
+                other.reset();
+                for (int ic = 1; XabX && ic <= leftLen; ic++) {
+                    bool next = true;
+                    if (ic + rightLen + lm <= CGX_MAX_SPAN) {
+                        uint32_t w = v.rlp[cur - ic];
+                        if (cgx_unaligned(w)) { next = false; if (i == 1) return true; }
+                        else other.add(cgx_L(w), cgx_R(w));
+                    } else { ic = leftLen + 1; next = false; }
+                    if (next && other.hi - other.lo >= CGX_MAX_SPAN) { ic = leftLen + 1; next = false; }
+                    uint32_t g1s = 0, g1e = 0;
+                    if (next) {
+                        if (other.empty()) return true;
+                        g1s = (uint32_t)(tb + other.lo); g1e = (uint32_t)(tb + other.hi);
+                        next = cgx_tight(v, (int)g1s, (int)g1e, cur - ic, cur - 1, src0);
+                    }
+                    if (next) {
+                        int lo = other.lo < right.lo ? other.lo : right.lo; if (lo > body.lo) lo = body.lo;
+                        int hi = other.hi < right.hi ? right.hi : other.hi; if (hi < body.hi) hi = body.hi;
+                        ts = (uint32_t)(tb + lo); te = (uint32_t)(tb + hi);
+                        if (ts > te) return true;
+                        if (te - ts >= CGX_MAX_SPAN) { next = false; ic = leftLen + 1; }
+                        if (next) next = cgx_tight(v, (int)ts, (int)te, cur - ic, ender + rightLen, src0);
+                        if (next) { cgx_put2(o_XabX, bnum, ts, te, g1s, g1e, (uint32_t)(tb + right.lo), (uint32_t)(tb + right.hi)); XabX = false; }
+                    }
+                }
+            }
+        } else XabX = false;
+
+        if (!XabX) { if (!Xab && XabOpen) XabOpen = false; if (!abX && abXOpen) abXOpen = false; }
+    }
+    return false;
+}
+
+// One sampled occurrence of aXbXc: (cur, firstEnd = offset of b's last token, secondEnd = offset of c's last token)
+CGX_HD bool cgx_extract_twogap(const cgx_view &v, int32_t id, int a_len, int b_len, int c_len,
+                               uint32_t cur, uint32_t firstEnd, uint32_t secondEnd, cgx_r2 *o) {
+    o->valid = 0;
+    cgx_span g1, g2; int src0, tb, tb2;
+    if (!cgx_edge_span(v, cur + a_len, cur + firstEnd - b_len, &g1, &src0, &tb)) return true;
+    if (g1.empty() || g1.hi - g1.lo >= CGX_MAX_SPAN) return true;
+    if (!cgx_edge_span(v, cur + firstEnd + 1, cur + secondEnd - c_len, &g2, &src0, &tb2)) return true;
+    if (g2.empty() || g2.hi - g2.lo >= CGX_MAX_SPAN) return true;
+    uint32_t ts, te;
+    if (cgx_span_code(v, cur, cur + secondEnd, &ts, &te) == 1)
+        cgx_put2(o, id, ts, te, (uint32_t)(g1.lo + tb), (uint32_t)(g1.hi + tb), (uint32_t)(g2.lo + tb2), (uint32_t)(g2.hi + tb2));
+    return false;
+}
+
+// One sampled occurrence of aXb: emits aXb, then the first consistent XaXb and aXbX.
+CGX_HD bool cgx_extract_onegap(const cgx_view &v, int32_t id, int32_t D1, int a_len, int b_len,
+                               uint32_t cur, int firstEnd, cgx_r1 *o_aXb, cgx_r2 *o_XaXb, cgx_r2 *o_aXbX) {
+    o_aXb->valid = 0; o_XaXb->valid = 0; o_aXbX->valid = 0;
+    if (cur + (uint32_t)firstEnd - (uint32_t)b_len > v.n) return true;
+    const uint32_t ender = cur + (uint32_t)firstEnd;
+    cgx_span gap; int src0, tb;
+    if (!cgx_edge_span(v, cur + a_len, ender - b_len, &gap, &src0, &tb)) return true;
+    if (gap.empty() || gap.hi - gap.lo >= CGX_MAX_SPAN) return true;
+    const uint32_t g0s = (uint32_t)(gap.lo + tb), g0e = (uint32_t)(gap.hi + tb);
+    uint32_t ts, te;
+    int code = cgx_span_code(v, cur, ender, &ts, &te);
+    // whole-phrase span in sentence coordinates, truncated to a byte like the reference
+    int bodyLo = (int)(uint8_t)(ts - (uint32_t)tb), bodyHi = (int)(uint8_t)(te - (uint32_t)tb);
+    bool left = !(code == 3 || code == 4), right = !(code == 2 || code == 4);
+    if ((ts == 0 && te == 0) || bodyLo > bodyHi || g0s < ts || g0e > te) return true;
+    if (code == 1) cgx_put1(o_aXb, id, ts, te, g0s, g0e);
+    if (a_len + b_len + 2 > CGX_MAX_SYMBOLS) return false;
+    cgx_span L, R; L.reset(); R.reset();
+    for (int i = 1; firstEnd + 1 + i <= CGX_MAX_SPAN && (left || right); i++) {
+        if (left && (int)(cur - (uint32_t)i) >= 0 && v.str[cur - i] >= 2) {
+            bool next = true;
+            uint32_t w = v.rlp[cur - i];
+            if (cgx_unaligned(w)) { next = false; if (i == 1) left = false; }
+            else L.add(cgx_L(w), cgx_R(w));
+            if (next && L.empty()) return true;
+            if (L.hi - L.lo >= CGX_MAX_SPAN) { next = false; left = false; }
+            uint32_t gs = 0, ge = 0;
+            if (next) { gs = (uint32_t)(tb + L.lo); ge = (uint32_t)(tb + L.hi); next = cgx_tight(v, (int)gs, (int)ge, (int)(cur - i), (int)cur - 1, src0); }
+            if (next) {
+                ts = (uint32_t)(tb + (L.lo < bodyLo ? L.lo : bodyLo)); te = (uint32_t)(tb + (L.hi < bodyHi ? bodyHi : L.hi));
+                if (ts > te) return true;
+                if (te - ts >= CGX_MAX_SPAN) { next = false; left = false; }
+                if (next) next = cgx_tight(v, (int)ts, (int)te, (int)(cur - i), (int)ender, src0);
+            }
+            if (next) { cgx_put2(o_XaXb, id, ts, te, gs, ge, g0s, g0e); left = false; }
+        } else left = false;
+        if (right && v.str[ender + i] >= 2) {
+            bool next = true;
+            uint32_t w = v.rlp[ender + i];
+            if (cgx_unaligned(w)) { next = false; if (i == 1) right = false; }
+            else R.add(cgx_L(w), cgx_R(w));
+            if (next && R.empty()) return true;
+            if (R.hi - R.lo >= CGX_MAX_SPAN) { next = false; right = false; }
+            uint32_t gs = 0, ge = 0;
+            if (next) { gs = (uint32_t)(tb + R.lo); ge = (uint32_t)(tb + R.hi); next = cgx_tight(v, (int)gs, (int)ge, (int)ender + 1, (int)(ender + i), src0); }
+            if (next) {
+                ts = (uint32_t)(tb + (R.lo < bodyLo ? R.lo : bodyLo)); te = (uint32_t)(tb + (R.hi < bodyHi ? bodyHi : R.hi));
+                if (ts > te) return true;
+                if (te - ts >= CGX_MAX_SPAN) { next = false; right = false; }
+                if (next) next = cgx_tight(v, (int)ts, (int)te, (int)cur, (int)(ender + i), src0);
+            }
+            if (next) { cgx_put2(o_aXbX, D1 + id, ts, te, g0s, g0e, gs, ge); right = false; }
+        } else right = false;
+    }
+    return false;
+}
+
+// ---- lexical table: keys packed (src+1)<<32 | (tgt+1), sorted ascending ----
+struct cgx_lexview { const uint64_t *key; const float *v1, *v2, *n1, *n2; uint32_t n; };  // n1/n2 = -log10f(v1/v2), precomputed on the host
+CGX_HD uint64_t cgx_lexkey_pack(int32_t src, int32_t tgt) { return ((uint64_t)(uint32_t)(src + 1) << 32) | (uint32_t)(tgt + 1); }
+CGX_HD int64_t cgx_lex_find(const cgx_lexview &t, int32_t src, int32_t tgt) {
+    uint64_t k = cgx_lexkey_pack(src, tgt);
+    int64_t lo = 0, hi = (int64_t)t.n - 1;
+    while (lo <= hi) { int64_t m = lo + ((hi - lo) >> 1); uint64_t x = t.key[m]; if (k < x) hi = m - 1; else if (k > x) lo = m + 1; else return m; }
+    return -1;
+}
+
+// MaxLexFgivenE / MaxLexEgivenF of one rule (kind 0: one gap, 1: two gaps, 2: contiguous).
+// The reference adds -log10(max) per word in float; the log of every table value is
+// precomputed by the host libm, so the kernel only picks the arg-max and adds.
+CGX_HD void cgx_maxlex(const cgx_lexview &t, const int32_t *tstr, const int32_t *src, int nsrc, uint32_t tstart,
+                       int end, int gap1, int gap1_1, int gap2, int gap2_1, int kind, float *fe, float *ef) {
+    float fgivene = 0.0f, egivenf = 0.0f;
+    const int t0 = (int)tstart, tend = t0 + end, g1s = t0 + gap1, g1e = t0 + gap1_1, g2s = t0 + gap2, g2e = t0 + gap2_1;
+    for (int j = 0; j < nsrc; j++) {
+        float mx = 0.0f, neg = 0.0f; bool first = true;
+        for (int jj = t0; jj <= tend; jj++) {
+            bool outside = kind == 2 || ((jj < g1s || jj > g1e) && (kind == 0 || jj < g2s || jj > g2e));
+            if (!outside) continue;
+            if (first) { int64_t m = cgx_lex_find(t, src[j], -1); if (m >= 0 && t.v2[m] > mx) { mx = t.v2[m]; neg = t.n2[m]; } first = false; }
+            int64_t m = cgx_lex_find(t, src[j], tstr[jj]);
+            if (m >= 0 && t.v2[m] > mx) { mx = t.v2[m]; neg = t.n2[m]; }
+        }
+        fgivene += mx > 0.0f ? neg : CGX_MAXSCORE;
+    }
+    for (int jj = t0; jj <= tend; jj++) {
+        bool outside = kind == 2 || ((jj < g1s || jj > g1e) && (kind == 0 || jj < g2s || jj > g2e));
+        if (!outside) continue;
+        float mx = 0.0f, neg = 0.0f; bool first = true;
+        for (int j = 0; j < nsrc; j++) {
+            if (first) { int64_t m = cgx_lex_find(t, -1, tstr[jj]); if (m >= 0 && t.v1[m] > mx) { mx = t.v1[m]; neg = t.n1[m]; } first = false; }
+            int64_t m = cgx_lex_find(t, src[j], tstr[jj]);
+            if (m >= 0 && t.v1[m] > mx) { mx = t.v1[m]; neg = t.n1[m]; }
+        }
+        egivenf += mx > 0.0f ? neg : CGX_MAXSCORE;
+    }
+    *fe = fgivene; *ef = egivenf;
+}
+
+#endif

@@ -1,0 +1,78 @@
+/*
+ * strmatchcuda.c -- command line of the MI355X extractor; same interface as the reference's
+ * bin/strmatchcuda (Main.c:29-86):
+ *   strmatchcuda [-h] [-l minmatchlen] [-t fingerlen] [-s timefile] <src> <query> <tgt> <align> <lex> <outdir>
+ * Extra, optional: --device N (default 0), --shard i/n (this process handles the i-th of n
+ * contiguous query shards; one process per GPU).
+ */
+#include "../../include/cgx.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+#include <sys/stat.h>
+
+static void print_help(void) {
+    printf("\nGPU source codes for gappy extraction. Please check your input arguments.\n\n");
+    exit(0);
+}
+
+int main(int argc, char **argv) {
+    int minmatchlen = 1, fingerlen = 10, device = 0, shard = 0, nshard = 1; const char *timefile = NULL;
+    /* pull the long options out first so getopt sees the reference's grammar only */
+    char **av = malloc(sizeof(char *) * (size_t)(argc + 1)); int ac = 0;
+    for (int i = 0; i < argc; i++) {
+        if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--shard") && i + 1 < argc) { if (sscanf(argv[++i], "%d/%d", &shard, &nshard) != 2 || nshard < 1 || shard < 0 || shard >= nshard) print_help(); }
+        else av[ac++] = argv[i];
+    }
+    av[ac] = NULL;
+    int ch, errflg = 0;
+    while (!errflg && (ch = getopt(ac, av, "hl:t:s:")) != EOF) {
+        switch (ch) {
+        case 'h': print_help(); break;
+        case '?': fprintf(stderr, "Unknown option %c\n", optopt); errflg = 1; break;
+        case 'l': minmatchlen = atoi(optarg); break;
+        case 't': fingerlen = atoi(optarg); break;
+        case 's': timefile = optarg; break;
+        default: errflg = 1; break;
+        }
+    }
+    if (optind != ac - 6 || errflg) print_help();
+    if (fingerlen > 10 || fingerlen <= 0) { fprintf(stderr, "finger length must be between 1 and 10\n"); exit(0); }
+    const char *src = av[optind], *qry = av[optind + 1], *tgt = av[optind + 2], *ali = av[optind + 3], *lex = av[optind + 4], *out = av[optind + 5];
+    (void)timefile;                                       /* parsed, unused: recordTime is commented out in the reference (Start.cu:621) */
+    fprintf(stderr, "reference file: %s\nquery file: %s\nref target file: %s\nalign file: %s\nMinimum match length: %d\n", src, qry, tgt, ali, minmatchlen);
+
+    FILE *qf = fopen(qry, "r");
+    if (!qf) { fprintf(stderr, "Can not open query file \"%s\"\n", qry); return 0; }   /* diskInit failure: start() returns (Start.cu:528) */
+    int32_t nlines = 0; for (int c; (c = fgetc(qf)) != EOF;) if (c == '\n') nlines++;
+    fseek(qf, -1, SEEK_END); if (ftell(qf) >= 0 && fgetc(qf) != '\n') nlines++;
+    fclose(qf);
+
+    char err[512];
+    cgx_corpus *corpus = cgx_corpus_load(src, tgt, ali, lex, err, sizeof err);
+    if (!corpus) {
+        if (!strncmp(err, "Not possible, too long", 22)) { printf("%s\n", err); return 1; }
+        if (!strcmp(err, "Not possible!")) { printf("%s\n", err); return 0; }
+        fprintf(stderr, "%s\n", err); return 0;
+    }
+    struct stat sb;
+    if (stat(out, &sb) || !S_ISDIR(sb.st_mode)) {           /* PrintResults.c:443-446 */
+        fprintf(stderr, "Please check your file directory address for grammar rule files output. It is not valid. Program Exits.\n");
+        return 0;
+    }
+    cgx_ctx *ctx = cgx_create(device);
+    if (!ctx) { fprintf(stderr, "strmatchcuda: no usable MI355X/HIP device %d\n", device); return 2; }
+    int rc = cgx_corpus_upload(ctx, corpus);
+    if (rc != CGX_OK) { fprintf(stderr, "strmatchcuda: %s\n", cgx_last_error(ctx)); return 2; }
+    int32_t qb = (int32_t)((int64_t)nlines * shard / nshard), qe = (int32_t)((int64_t)nlines * (shard + 1) / nshard);
+    uint64_t nrules = 0;
+    rc = cgx_extract_grammars(ctx, corpus, qry, out, qb, nshard == 1 ? -1 : qe, &nrules);
+    if (rc != CGX_OK) { fprintf(stderr, "strmatchcuda: %s (%d)\n", cgx_last_error(ctx), rc); return rc == CGX_ERR_IO ? 0 : 2; }
+    fprintf(stderr, "strmatchcuda: %llu rules | index build %.1f ms, precompute %.1f ms | lookup %.3f ms, gappy %.3f ms, extract %.3f ms, features %.3f ms | host: blocks %.1f lists %.1f lexicon %.1f write %.1f ms\n",
+            (unsigned long long)nrules, cgx_stage_ms(ctx, "build_sa"), cgx_stage_ms(ctx, "precompute"), cgx_stage_ms(ctx, "sa_lookup"), cgx_stage_ms(ctx, "gappy"),
+            cgx_stage_ms(ctx, "extract"), cgx_stage_ms(ctx, "lex"), cgx_host_ms(ctx, "blocks"), cgx_host_ms(ctx, "lists"), cgx_host_ms(ctx, "lexicon"), cgx_host_ms(ctx, "write"));
+    cgx_destroy(ctx); cgx_corpus_free(corpus); free(av);
+    return 0;
+}

@@ -1,0 +1,130 @@
+/*
+ * cgx.h -- C ABI of the MI355X-native hierarchical grammar extractor (libcgx_hip.so).
+ *
+ * Drop-in boundary for the reference's  suffix-array lookup -> gappy-phrase search ->
+ * rule extraction  path.  Plain pointers and sizes only; every entry point returns 0 on
+ * success and a negative code on failure, with the text available from cgx_last_error().
+ * There is NO CPU fallback: without a HIP device cgx_create() fails.
+ *
+ * Reference interfaces replaced (all C++ linkage, results passed through qry_set_t fields):
+ *   suffixArraySearchInit / suffixArraySearchFinalize[_One]   SuffixArray.h:9-22, SuffixArray.cu:769-813
+ *   suffixArraySearch                                         SuffixArray.h:11-16, SuffixArray.cu:1342-2269
+ *   ExtractPairs_Large_Data_Gappy / extractPairFinalize       ExtractPair.h:179-185,33, ExtractPair.cu:3215-4001
+ *   initWordPossibilityIntKey (device part: table sort)       ExtractPair.h:20-21, ExtractPair.cu:2528-2537
+ *   suffixArrayConstruct                                      SuffixArray.h:7, SuffixArray.c:196-242
+ */
+#ifndef CGX_H
+#define CGX_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CGX_OK 0
+#define CGX_ERR_ARG (-1)
+#define CGX_ERR_HIP (-2)
+#define CGX_ERR_STATE (-3)
+#define CGX_ERR_NOMEM (-4)
+#define CGX_ERR_IO (-5)
+#define CGX_ERR_ALIGN_RANGE (-6)  /* alignment index >= 255: the reference prints "Not possible, too long sentence" and exits 1 (ExtractPair.cu:2683) */
+#define CGX_ERR_ALIGN_PAIR (-7)   /* dangling "i-" without j: "Not possible!" and exit 0 (ExtractPair.cu:2676) */
+
+typedef struct cgx_ctx cgx_ctx;
+
+/* ---- wire records handed back to the host side (packed, little endian) ---- */
+#pragma pack(push, 1)
+typedef struct { int32_t qrystart; uint8_t a_len, b_len, gap; } cgx_gappy;            /* one query instance of aXb   (ComTypes.h:142) */
+typedef struct { int32_t pat[5]; uint8_t number; } cgx_gappat;                        /* its symbols, gap = -1, pad = -2 (:194)       */
+typedef struct { uint32_t blockid, gap2; uint8_t c_len; } cgx_twogappy;               /* one query instance of aXbXc (:151)           */
+typedef struct { uint32_t position, str_position; uint8_t length; } cgx_hit1;         /* corpus occurrence of aXb    (:179)           */
+typedef struct { uint32_t position, str_position; uint8_t length, length2; } cgx_hit2;/* corpus occurrence of aXbXc  (:186)           */
+typedef struct { int32_t id; uint32_t tstart; uint8_t end, gap1, gap1_1; } cgx_rule1; /* one-gap rule                (:224)           */
+typedef struct { int32_t id; uint32_t tstart; uint8_t end, gap1, gap1_1, gap2, gap2_1; } cgx_rule2; /* two-gap rule  (:233)           */
+typedef struct { int32_t tar_start; int32_t block; uint8_t tar_end; } cgx_rule0;      /* contiguous rule             (:349)           */
+typedef struct { uint32_t lexid; int32_t src[5]; uint8_t nsrc; uint32_t tstart;
+                 uint8_t end, gap1, gap1_1, gap2, gap2_1; } cgx_lextask;              /* MaxLex work item            (:376)           */
+#pragma pack(pop)
+typedef struct { int32_t qrystart; int32_t a_len, b_len, gap; uint32_t position; int32_t sa_start, sa_end; int32_t marker; } cgx_gapsearch; /* distinct aXb   (:168) */
+typedef struct { uint32_t blockid, gap2; int32_t c_len; uint32_t position; int32_t sa_start, sa_end; } cgx_twogapsearch;                  /* distinct aXbXc (:158) */
+typedef struct { int32_t start, end, matchlen, string_start; } cgx_block;            /* distinct contiguous phrase (saind_t, :342)    */
+typedef struct { int32_t src, tgt; } cgx_lexkey;                                      /* (:355) -1 = NULL word */
+typedef struct { float v1, v2; } cgx_lexval;                                          /* (:360) */
+
+/* ---- corpus-side index, host view used by cgx_upload_index ---- */
+typedef struct {
+    const int32_t *str;      /* source token ids, n entries: words >= 2, 1 closes a sentence, trailing "1,last" (Start.cu:306-327) */
+    uint32_t n;
+    const uint32_t *rlp;     /* per source token (L<<24)|(R<<16)|(P<<8); delimiter slots hold the next sentence's target offset (ExtractPair.cu:2717-2731) */
+    const int32_t *tstr;     /* target token ids */
+    uint32_t nt;
+    const uint8_t *ltar, *rtar; /* per target token min/max aligned source position, 255 = unaligned */
+    const cgx_lexkey *lexk;  /* lexical table rows in file order (no duplicates) */
+    const cgx_lexval *lexv;
+    uint32_t nlex;
+    const int32_t *sa;       /* optional prebuilt suffix array (NULL: built on the device) */
+} cgx_index_host;
+
+/* ---- lifetime ---- */
+cgx_ctx *cgx_create(int device);                       /* replaces suffixArraySearchInit (SuffixArray.cu:769) */
+void cgx_destroy(cgx_ctx *ctx);                        /* replaces suffixArraySearchFinalize*, extractPairFinalize */
+const char *cgx_last_error(cgx_ctx *ctx);
+int cgx_set_option(cgx_ctx *ctx, const char *name, int64_t value); /* "k1_limit" (default 128), "chunk_items" */
+
+/* ---- index: upload, device suffix-array construction, frequent-pair precomputation ---- */
+int cgx_upload_index(cgx_ctx *ctx, const cgx_index_host *ix);   /* H2D of the index (SuffixArray.cu:1396-1412, ExtractPair.cu:3279-3282) */
+int cgx_build_sa(cgx_ctx *ctx);                                 /* replaces suffixArrayConstruct (SuffixArray.c:196-242) on the device */
+int cgx_precompute(cgx_ctx *ctx);                               /* replaces preComputation + precomp kernel (SuffixArray.cu:1132-1340) */
+/* multi-GPU: allocate an empty replica of given sizes, then move buffers device-to-device
+ * (dir 0: index buffer -> dptr, dir 1: dptr -> index buffer) around a collective broadcast. */
+int cgx_index_alloc(cgx_ctx *ctx, uint32_t n, uint32_t nt, uint32_t nlex, uint32_t nphits, int32_t last);
+int cgx_index_nbuffers(cgx_ctx *ctx);
+int cgx_index_buffer(cgx_ctx *ctx, int i, const char **name, uint64_t *nbytes);
+int cgx_index_d2d(cgx_ctx *ctx, int i, void *dptr, int dir);
+int cgx_index_finalize(cgx_ctx *ctx);                           /* after the last d2d on a replica */
+/* one-time broadcast of every index buffer from rank `root` over an existing RCCL communicator */
+int cgx_broadcast_index(cgx_ctx *ctx, void *nccl_comm, int root, int rank);
+
+/* ---- per batch of query sentences ---- */
+int cgx_upload_queries(cgx_ctx *ctx, const int32_t *qoff, int32_t nq, const int32_t *qtok, int32_t ntok); /* constructQryIndex output (Start.cu:50-132) */
+int cgx_sa_lookup(cgx_ctx *ctx);        /* K1 + K2: SuffixArray.cu:402-767, 109-400 */
+int cgx_gappy_search(cgx_ctx *ctx);     /* enumeration, sorts, lookups: SuffixArray.cu:1530-2256, GappyLook.cu:128-737 */
+int cgx_set_blocks(cgx_ctx *ctx, cgx_block *blocks, uint32_t g);   /* distinct contiguous phrases (GenerateBlocks, ExtractPair.cu:2742-2903); fills blocks[i].string_start = sa[start] */
+int cgx_extract(cgx_ctx *ctx);          /* three extraction launches + sorts: ExtractPair.cu:3336-3670 */
+int cgx_lex_features(cgx_ctx *ctx, const cgx_lextask *tasks, uint32_t ntask, uint32_t n_onegap, uint32_t n_twogap,
+                     float *max_fe, float *max_ef);             /* lexicalTaskMaxEF: ExtractPair.cu:2144-2432 */
+
+/* ---- results: copy a named device/host result into caller memory.
+ * dst == NULL returns the size in bytes; otherwise returns bytes written, or < 0. Names:
+ *   "sa" "tokstart" "freq" "pidx" "miss" "phit_start" "phit_len"
+ *   "lm" "up" "down" "g1" "p1" "pid1" "s1" "hits1" "g2" "c2" "pid2" "s2" "hits2" "r0" "r1" "r2" "counts" */
+int64_t cgx_fetch(cgx_ctx *ctx, const char *name, void *dst, int64_t cap);
+/* last-stage timings in milliseconds (hipEvent): "sa_lookup" "gappy" "extract" "lex" "build_sa" "precompute";
+ * "sa_lookup_kernel" is the batched interval-search kernel alone */
+double cgx_stage_ms(cgx_ctx *ctx, const char *name);
+
+/* ---- whole-path host driver (what the CLI calls): text files in, grammar files out ---- */
+typedef struct cgx_corpus cgx_corpus;
+cgx_corpus *cgx_corpus_load(const char *src, const char *tgt, const char *align, const char *lex, char *err, size_t errcap);
+void cgx_corpus_free(cgx_corpus *c);
+int cgx_corpus_upload(cgx_ctx *ctx, const cgx_corpus *c);
+/* runs lookup -> gappy search -> extraction -> features for the query file and writes
+ * <outdir>/grammar.<q>.s; queries [q_begin, q_end) only (q_end < 0: all) for query sharding */
+int cgx_extract_grammars(cgx_ctx *ctx, const cgx_corpus *c, const char *qryfile, const char *outdir,
+                         int32_t q_begin, int32_t q_end, uint64_t *nrules);
+/* same on an id-level batch (bench / tests): corpus may have no spellings, words print as s<id>/t<id> */
+int cgx_extract_grammars_ids(cgx_ctx *ctx, const cgx_corpus *c, const int32_t *qoff, int32_t nq, const int32_t *qtok,
+                             int32_t ntok, const char *outdir, int32_t first_query_index, uint64_t *nrules);
+cgx_corpus *cgx_corpus_from_ids(const int32_t *str, uint32_t n, const int32_t *sentind, int32_t nsent,
+                                const int32_t *tstr, uint32_t nt, const int32_t *tsentind,
+                                const uint8_t *lsrc, const uint8_t *rsrc, const uint8_t *ltar, const uint8_t *rtar,
+                                const cgx_lexkey *lexk, const cgx_lexval *lexv, uint32_t nlex);
+/* host stage timings of the last cgx_extract_grammars* call, milliseconds:
+ * "blocks" "lists" "lexicon" "write" "total" */
+double cgx_host_ms(cgx_ctx *ctx, const char *name);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
