@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py -- query sentences/sec + rules/sec of the hot path on N MI355X, one JSON line.
+
+A step = one pass of the whole hot path (H2D of the query ids, batched SA interval search,
+gappy-phrase search, rule extraction, lexicon + MaxLex features, grammar files written) over
+one batch of synthetic query sentences, with the corpus index already resident in HBM.
+Index construction (device suffix array, frequent-pair precomputation) and, for N > 1, the
+one-time RCCL broadcast of the index are outside the timed region and reported separately.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Weak scaling: every rank processes `--queries` sentences per step against a full replica of
+the index; value = (N * queries * steps) / max-over-ranks wall time.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import shutil
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def algorithmic_bytes(n_tokens, lm):
+    """B(N,l) = 2*ceil(log2 N)*(4+4l) + 4l + 8 bytes per interval lookup (t,l), l <= 5."""
+    lg = int(np.ceil(np.log2(max(n_tokens, 2))))
+    total = 0; lookups = 0
+    for l in range(1, 6):
+        c = int((lm >= l).sum())
+        total += c * (2 * lg * (4 + 4 * l) + 4 * l + 8); lookups += c
+    return total, lookups
+
+
+def cpu_baseline(corpus, args):
+    """The CPU oracle (kind "port") timed on a bounded sample: a prefix of the same corpus and
+    queries drawn from it by the same recipe.  Index build is excluded, as for the GPU."""
+    from cgx_amd import synth
+    import cgx_amd
+    lib_path = os.path.join(ROOT, "oracle", "liboracle.so")
+    if not os.path.exists(lib_path):
+        import subprocess
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"], check=True, stdout=subprocess.DEVNULL)
+    lib = C.CDLL(lib_path)
+    sub = synth.prefix(corpus, min(args.cpu_pairs, corpus["pairs"]))
+    qoff, qtok = synth.make_queries(sub, args.cpu_queries, args.seed + 99)
+    # suffix array of the sample from the device builder (index construction is not what is timed)
+    ex = cgx_amd.Extractor(0)
+    P = np.zeros(len(sub["str"]), np.uint32)
+    ex.upload_index(sub["str"], P, sub["tstr"], sub["ltar"], sub["rtar"], sub["lexk"][:1], sub["lexv"][:1])
+    ex.build_sa(); sa = ex.fetch("sa"); ex.close()
+    vp = C.c_void_p
+    lib.orc_index_from_arrays.restype = vp
+    lib.orc_index_from_arrays.argtypes = [vp, C.c_uint32, vp, C.c_int32, vp, C.c_uint32, vp, vp, vp, vp, vp, vp, vp, C.c_uint32, vp]
+    lib.orc_batch_from_ids.restype = vp; lib.orc_batch_from_ids.argtypes = [vp, C.c_int32, vp, C.c_int32]
+    lib.orc_run_all.argtypes = [vp, vp, C.c_char_p]; lib.orc_batch_free.argtypes = [vp]; lib.orc_index_free.argtypes = [vp]
+    p = lambda a: a.ctypes.data_as(vp)
+    arrs = [np.ascontiguousarray(sub[k]) for k in ("str", "sentind", "tstr", "tsentind", "lsrc", "rsrc", "ltar", "rtar", "lexk", "lexv")]
+    ix = lib.orc_index_from_arrays(p(arrs[0]), len(arrs[0]), p(arrs[1]), len(arrs[1]) - 1, p(arrs[2]), len(arrs[2]), p(arrs[3]), p(arrs[4]), p(arrs[5]),
+                                   p(arrs[6]), p(arrs[7]), p(arrs[8]), p(arrs[9]), len(arrs[8]), p(sa))
+    out = tempfile.mkdtemp(prefix="cgx_cpu_")
+    b = lib.orc_batch_from_ids(p(qoff), len(qoff), p(qtok), len(qtok))
+    t0 = time.perf_counter()
+    lib.orc_run_all(ix, b, out.encode())
+    dt = time.perf_counter() - t0
+    lines = sum(sum(1 for _ in open(os.path.join(out, f), "rb")) for f in os.listdir(out))
+    lib.orc_batch_free(b); lib.orc_index_free(ix); shutil.rmtree(out, ignore_errors=True)
+    return {"value": round(len(qoff) / dt, 3), "unit": "query sentences/s", "cores": 1, "kind": "port",
+            "rules_per_s": round(lines / dt, 1), "seconds": round(dt, 3),
+            "sample": "%d-pair prefix of the corpus (N=%d source tokens), %d queries by the same recipe, single-thread C oracle, index build excluded"
+                      % (sub["pairs"], len(sub["str"]), len(qoff))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pairs", type=int, default=1000000, help="sentence pairs in the synthetic corpus")
+    ap.add_argument("--vocab", type=int, default=200000)
+    ap.add_argument("--queries", type=int, default=2000, help="query sentences per rank per step")
+    ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--cpu-pairs", type=int, default=100000)
+    ap.add_argument("--cpu-queries", type=int, default=48)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-write", action="store_true", help="format nothing, write no files (kernel-side study only; not the headline)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from cgx_amd import synth, shard
+    import cgx_amd
+
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the extractor has no CPU fallback")
+    torch.cuda.set_device(local)
+    ex = cgx_amd.Extractor(local)
+
+    # ---- synthetic corpus (same seed on every rank: host arrays are needed by the host stages) ----
+    t0 = time.perf_counter()
+    corpus = synth.make_corpus(args.pairs, args.vocab, args.seed)
+    host = cgx_amd.Corpus.from_ids(corpus["str"], corpus["sentind"], corpus["tstr"], corpus["tsentind"], corpus["lsrc"], corpus["rsrc"],
+                                   corpus["ltar"], corpus["rtar"], corpus["lexk"], corpus["lexv"])
+    t_gen = time.perf_counter() - t0
+    # ---- index: built on rank 0, broadcast once over RCCL/xGMI ----
+    t0 = time.perf_counter(); t_bcast = 0.0
+    if rank == 0:
+        ex.upload_corpus(host)
+    if world > 1:
+        meta = [None]
+        if rank == 0:
+            c = ex.counts(); meta = [(len(corpus["str"]), len(corpus["tstr"]), len(corpus["lexk"]), c["nphits"], c["last"])]
+        dist.broadcast_object_list(meta, src=0)
+        if rank != 0:
+            ex.index_alloc(*meta[0])
+        torch.cuda.synchronize(); dist.barrier(); tb = time.perf_counter()
+        for i, (name, nbytes) in enumerate(ex.index_buffers()):
+            if nbytes == 0:
+                continue
+            stage = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                ex.index_d2d(i, stage.data_ptr(), 0)
+            dist.broadcast(stage, src=0)
+            torch.cuda.synchronize()
+            if rank != 0:
+                ex.index_d2d(i, stage.data_ptr(), 1)
+            del stage
+        if rank != 0:
+            ex.index_finalize()
+        torch.cuda.synchronize(); dist.barrier(); t_bcast = time.perf_counter() - tb
+    t_index = time.perf_counter() - t0
+
+    # ---- queries: every rank gets its own shard of the global batch (weak scaling) ----
+    gq_off, gq_tok = synth.make_queries(corpus, args.queries * world, args.seed + 3087)
+    first, qoff, qtok = shard.take_shard(gq_off, gq_tok, rank, world)
+    outdir = None if args.no_write else tempfile.mkdtemp(prefix="cgx_bench_r%d_" % rank)
+
+    def step():
+        return ex.extract_grammars_ids(host, qoff, qtok, outdir, first)
+
+    for _ in range(args.warmup):
+        step()
+    kernel_ms = []; stage = {k: 0.0 for k in ("sa_lookup", "gappy", "extract", "lex")}; hoststage = {k: 0.0 for k in ("blocks", "lists", "lexicon", "write")}
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter(); rules = 0
+    for _ in range(args.steps):
+        rules += step()
+        kernel_ms.append(ex.stage_ms("sa_lookup_kernel"))
+        for k in stage: stage[k] += ex.stage_ms(k)
+        for k in hoststage: hoststage[k] += ex.host_ms(k)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = shard.max_over_ranks(time.perf_counter() - t0, dist if world > 1 else None)
+    total_q = shard.sum_over_ranks(len(qoff) * args.steps, dist if world > 1 else None)
+    total_rules = shard.sum_over_ranks(rules, dist if world > 1 else None)
+
+    if rank == 0:
+        lm = ex.fetch("lm"); c = ex.counts()
+        abytes, lookups = algorithmic_bytes(len(corpus["str"]), lm)
+        kms = float(np.mean(kernel_ms))
+        ach = abytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+        line = {
+            "metric": "query sentences/sec", "value": round(total_q / dt, 3), "unit": "query sentences/s",
+            "rules_per_s": round(total_rules / dt, 1), "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "i32", "data": "synthetic",
+            "config": {"workload": "synthetic Zipf parallel corpus (BASELINE configs[2] recipe, %d sentence pairs), %d queries per GPU per step"
+                                   % (args.pairs, args.queries),
+                       "sentence_pairs": args.pairs, "source_tokens": int(len(corpus["str"])), "vocab": args.vocab,
+                       "queries_per_gpu": int(len(qoff)), "query_tokens_per_gpu": int(len(qtok)), "parallelism": "query-shard x%d, index replicated" % world,
+                       "grammar_files_written": not args.no_write},
+            "roofline": {"bound": "hbm", "kernel": "k_sa_lookup (batched SA interval search)", "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(ach / 8000.0, 4), "traffic": None, "algorithmic_bytes_per_launch": int(abytes), "lookups_per_launch": int(lookups),
+                         "kernel_ms": round(kms, 4)},
+            "stages_ms_per_step": {k: round(v / args.steps, 3) for k, v in {**stage, **{"host_" + k: v for k, v in hoststage.items()}}.items()},
+            "index": {"build_sa_ms": round(ex.stage_ms("build_sa"), 1), "precompute_ms": round(ex.stage_ms("precompute"), 1),
+                      "broadcast_s": round(t_bcast, 3), "total_s": round(t_index, 2), "corpus_gen_s": round(t_gen, 2), "frequent_pair_hits": c["nphits"]},
+            "counts": {k: c[k] for k in ("d1", "d2", "h1", "h2", "g", "n0", "n1", "n2", "guard_exits")},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(corpus, args)
+        print(json.dumps(line))
+    if outdir:
+        shutil.rmtree(outdir, ignore_errors=True)
+    ex.close()
+    if world > 1:
+        dist.barrier(); dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

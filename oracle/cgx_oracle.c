@@ -890,6 +890,15 @@ int orc_sample_hit(int n, int sampler, int idx) {
     return 0;
 }
 
+/* The indices with orc_sample_hit(n,S,x) == 1 in ascending order: all of 0..n-1 when n <= S,
+ * else ROUND(k*step) for k = 0..S-1 (strictly increasing because step > 1).  Walking them in
+ * ascending order visits every CUDA thread's occurrences in that thread's own order. */
+static int nsamples(int n, int sampler) { return n <= sampler ? n : sampler; }
+static int sample_at(int n, int sampler, int k) {
+    if (n <= sampler) return k;
+    float step = (float)n / (float)sampler;
+    return (int)(k * step + 0.5);
+}
 typedef struct { VEC(orc_rule0) r0; VEC(orc_rule1) r1; VEC(orc_rule2) r2; } rulebuf;
 #define KTHREADS 512   /* THREADS_PER_BLOCK, ExtractPair.cu:9 */
 
@@ -1166,8 +1175,9 @@ void orc_extract(const orc_index *ix, orc_batch *b) {
         int32_t start = b->blocks[bn].start, end = b->blocks[bn].end; int lm = b->blocks[bn].matchlen;
         if (lm < 1) continue;
         int n = 1 + end - start; memset(dead, 0, sizeof dead);
-        for (int x = 0; x < n; x++) {
-            if (dead[x % KTHREADS] || !orc_sample_hit(n, ORC_SAMPLER, x)) continue;
+        for (int k = 0, ns = nsamples(n, ORC_SAMPLER); k < ns; k++) {      /* sampled indices in ascending order */
+            int x = sample_at(n, ORC_SAMPLER, k);
+            if (dead[x % KTHREADS]) continue;
             if (gappy_occurrence(ix, bn, b->g, lm, start + x, &A)) dead[x % KTHREADS] = 1;
         }
     }
@@ -1175,8 +1185,9 @@ void orc_extract(const orc_index *ix, orc_batch *b) {
         int32_t s0 = b->s2[id].sa_start, e0 = b->s2[id].sa_end;
         if (s0 == -1 && e0 == -1) continue;
         int n = e0 - s0 + 1; memset(dead, 0, sizeof dead);
-        for (int x = 0; x < n; x++) {
-            if (dead[x % KTHREADS] || !orc_sample_hit(n, ORC_SAMPLER_TWOGAP, x)) continue;
+        for (int k = 0, ns = nsamples(n, ORC_SAMPLER_TWOGAP); k < ns; k++) {
+            int x = sample_at(n, ORC_SAMPLER_TWOGAP, k);
+            if (dead[x % KTHREADS]) continue;
             if (twogap_occurrence(ix, b, id, &b->hits2[s0 + x], &B)) dead[x % KTHREADS] = 1;
         }
     }
@@ -1191,8 +1202,9 @@ void orc_extract(const orc_index *ix, orc_batch *b) {
             if (gs->a_len != 1 || gs->b_len != 1) continue;
         }
         memset(dead, 0, sizeof dead);
-        for (int x = 0; x < n; x++) {
-            if (dead[x % KTHREADS] || !orc_sample_hit(n, ORC_SAMPLER_ONEGAP, x)) continue;
+        for (int k = 0, ns = nsamples(n, ORC_SAMPLER_ONEGAP); k < ns; k++) {
+            int x = sample_at(n, ORC_SAMPLER_ONEGAP, k);
+            if (dead[x % KTHREADS]) continue;
             uint32_t cur; unsigned char fe;
             if (marker) { cur = ix->phits[base + x].start; fe = ix->phits[base + x].length; }
             else { if (b->hits1[base + x].position != id) { dead[x % KTHREADS] = 1; continue; } cur = b->hits1[base + x].str_position; fe = b->hits1[base + x].length; }

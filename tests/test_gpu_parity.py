@@ -1,0 +1,165 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path through the C ABI must be
+bit-exact against the CPU oracle, stage by stage and in the final grammar files."""
+import json
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_py as op
+from test_oracle import META, make_fixture
+
+pytestmark = pytest.mark.gpu
+ROOT = op.ROOT
+
+
+@pytest.fixture(scope="module")
+def cgx():
+    import cgx_amd
+    cgx_amd.load_library()
+    return cgx_amd
+
+
+def run_product(cgx, fx, outdir, **opts):
+    files = op.fixture_args(fx)
+    ex = cgx.Extractor(0)
+    for k, v in opts.items():
+        ex.set_option(k, v)
+    corpus = cgx.Corpus.load(files[0], files[2], files[3], files[4])
+    ex.upload_corpus(corpus)
+    os.makedirs(outdir, exist_ok=True)
+    n = ex.extract_grammars(corpus, files[1], outdir)
+    return ex, corpus, n
+
+
+@pytest.mark.parametrize("name", ["tiny", "toy", "mid"])
+def test_grammar_files_bit_exact(name, cgx, oracle_bin, fixtures_dir, tmp_path):
+    fx = make_fixture(name, fixtures_dir)
+    op.run_oracle(oracle_bin, fx, str(tmp_path / "o"))
+    ex, corpus, n = run_product(cgx, fx, str(tmp_path / "p"))
+    nq = META[name]["spec"][2]
+    assert op.sha_dir(str(tmp_path / "p"), nq) == op.sha_dir(str(tmp_path / "o"), nq) == META[name]["grammar"]
+    assert ex.counts()["guard_exits"] == 0
+    ex.close(); corpus.close()
+
+
+def test_cli_is_a_drop_in(cgx, oracle_bin, fixtures_dir, tmp_path):
+    """bin/strmatchcuda with the reference's six positionals writes the same files."""
+    fx = make_fixture("tiny", fixtures_dir); out = tmp_path / "cli"; out.mkdir()
+    r = subprocess.run([os.path.join(ROOT, "bin", "strmatchcuda")] + op.fixture_args(fx) + [str(out)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "Start Printing Gappy Phrases..." in r.stderr
+    assert op.sha_dir(str(out), 7) == META["tiny"]["grammar"]
+    r = subprocess.run([os.path.join(ROOT, "bin", "strmatchcuda")] + op.fixture_args(fx) + [str(tmp_path / "missing_dir")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "It is not valid" in r.stderr          # PrintResults.c:443-446
+
+
+@pytest.mark.parametrize("name", ["tiny", "mid"])
+def test_every_stage_matches_the_oracle(name, cgx, oracle_bin, fixtures_dir, tmp_path):
+    fx = make_fixture(name, fixtures_dir); dump = str(tmp_path / "d.bin")
+    op.run_oracle(oracle_bin, fx, str(tmp_path / "o"), dump)
+    d = op.read_dump(dump); h = d["hdr"]; n, nt = h["n"], h["nt"]
+    ex = cgx.Extractor(0)
+    ex.upload_index(d["str"][:n], d["rlp"], d["tstr"][:nt], d["ltar"], d["rtar"], d["lexk"], d["lexv"])
+    ex.build_sa()
+    assert np.array_equal(ex.fetch("sa"), d["sa"])
+    ex.precompute()
+    assert np.array_equal(ex.fetch("freq"), d["freq"])
+    assert np.array_equal(ex.fetch("pidx"), d["pidx"])
+    assert np.array_equal(ex.fetch("miss"), d["miss"])
+    assert np.array_equal(ex.fetch("phit_start"), d["phits"]["start"]) and np.array_equal(ex.fetch("phit_len"), d["phits"]["length"])
+    ex.upload_queries(d["qoff"][:-1], d["qtok"])
+    ex.sa_lookup()
+    lm5 = np.minimum(d["lm"], 5)
+    assert np.array_equal(ex.fetch("lm"), lm5)
+    assert np.array_equal(ex.fetch("up"), d["up"]) and np.array_equal(ex.fetch("down"), d["down"])
+    blocks = ex.set_blocks(d["blocks"])
+    assert np.array_equal(blocks["string_start"], d["blocks"]["string_start"])
+    ex.gappy_search()
+    for k in ("g1", "p1", "hits1", "g2", "hits2"):
+        assert np.array_equal(ex.fetch(k), d[k]), k
+    s1 = ex.fetch("s1")
+    for f in ("qrystart", "a_len", "b_len", "gap", "position", "sa_start", "sa_end"):
+        assert np.array_equal(s1[f], d["s1"][f].astype(s1[f].dtype)), f
+    s2 = ex.fetch("s2")
+    for f in ("blockid", "gap2", "c_len", "position", "sa_start", "sa_end"):
+        assert np.array_equal(s2[f], d["s2"][f].astype(s2[f].dtype)), f
+    assert np.array_equal(ex.fetch("c2"), d["p2"]["pat"][:, 0])
+    ex.extract()
+    c = ex.counts()
+    assert (c["sep1"], c["sep2a"], c["sep2b"], c["guard_exits"]) == (h["sep1"], h["sep2a"], h["sep2b"], 0)
+    for k in ("r0", "r1", "r2"):
+        assert np.array_equal(ex.fetch(k), d[k]), k
+    nl1 = len(d["lex1_int"]) // 4; nl2 = len(d["lex2_int"]) // 4
+    fe, ef = ex.lex_features(d["tasks"], nl1, nl2)
+    assert np.array_equal(fe.view(np.uint32), d["task_fe"].view(np.uint32))      # bit patterns
+    assert np.array_equal(ef.view(np.uint32), d["task_ef"].view(np.uint32))
+    ex.close()
+
+
+def test_edge_case_queries(cgx, oracle_bin, tmp_path):
+    fx = os.path.join(ROOT, "tests", "golden", "tiny"); d = tmp_path / "fx"; d.mkdir()
+    for n in ("corpus.f", "corpus.e", "corpus.a", "lex.txt"):
+        shutil.copy(os.path.join(fx, n), d / n)
+    (d / "query.f").write_text("\nOOV1 OOV2\ns1\ns1 s1 s1 s1 s1 s1\ns0 s2 OOV s1 s0\n\n")
+    op.run_oracle(oracle_bin, str(d), str(tmp_path / "o"))
+    ex, corpus, n = run_product(cgx, str(d), str(tmp_path / "p"))
+    assert op.sha_dir(str(tmp_path / "p"), 6) == op.sha_dir(str(tmp_path / "o"), 6)
+    ex.close(); corpus.close()
+    (d / "query.f").write_text("")                                       # empty query file: nothing to do, no crash
+    ex, corpus, n = run_product(cgx, str(d), str(tmp_path / "p2"))
+    assert n == 0
+    ex.close(); corpus.close()
+
+
+def test_chunking_and_sharding_do_not_change_results(cgx, fixtures_dir, tmp_path):
+    """Size-independent properties at a larger size: tiny work chunks, and a 2-way query split, give the same files."""
+    fx = make_fixture("toy", fixtures_dir)
+    ex, corpus, n = run_product(cgx, fx, str(tmp_path / "a"))
+    ex.close()
+    ex, corpus2, n2 = run_product(cgx, fx, str(tmp_path / "b"), chunk_items=4096)
+    assert n == n2 and op.sha_dir(str(tmp_path / "a"), 7) == op.sha_dir(str(tmp_path / "b"), 7) == META["toy"]["grammar"]
+    os.makedirs(str(tmp_path / "c"))
+    files = op.fixture_args(fx)
+    ex.extract_grammars(corpus2, files[1], str(tmp_path / "c"), 0, 4)
+    ex.extract_grammars(corpus2, files[1], str(tmp_path / "c"), 4, 7)
+    assert op.sha_dir(str(tmp_path / "c"), 7) == META["toy"]["grammar"]
+    ex.close(); corpus.close(); corpus2.close()
+
+
+def test_id_level_batch_on_synthetic_corpus(cgx, tmp_path):
+    """bench.py's path: corpus from id arrays; suffix array property check + oracle parity through liboracle."""
+    import ctypes as C
+    from cgx_amd import synth
+    corpus = synth.make_corpus(3000, 400, 5)
+    qoff, qtok = synth.make_queries(corpus, 12, 6)
+    host = cgx.Corpus.from_ids(corpus["str"], corpus["sentind"], corpus["tstr"], corpus["tsentind"], corpus["lsrc"], corpus["rsrc"],
+                               corpus["ltar"], corpus["rtar"], corpus["lexk"], corpus["lexv"])
+    ex = cgx.Extractor(0); ex.upload_corpus(host)
+    sa = ex.fetch("sa"); s = corpus["str"]; n = len(s)
+    assert np.array_equal(np.sort(sa), np.arange(n))
+    pad = np.concatenate((s, np.zeros(64, np.int32)))
+    for i in np.random.default_rng(0).integers(0, n - 1, 2000):      # adjacent suffixes are in order
+        a, b = int(sa[i]), int(sa[i + 1]); k = 0
+        while pad[a + k] == pad[b + k]:
+            k += 1
+        assert pad[a + k] < pad[b + k]
+    out = tmp_path / "p"; out.mkdir()
+    nrules = ex.extract_grammars_ids(host, qoff, qtok, str(out), 0)
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so")); vp = C.c_void_p
+    lib.orc_index_from_arrays.restype = vp
+    lib.orc_index_from_arrays.argtypes = [vp, C.c_uint32, vp, C.c_int32, vp, C.c_uint32, vp, vp, vp, vp, vp, vp, vp, C.c_uint32, vp]
+    lib.orc_batch_from_ids.restype = vp; lib.orc_batch_from_ids.argtypes = [vp, C.c_int32, vp, C.c_int32]
+    lib.orc_run_all.argtypes = [vp, vp, C.c_char_p]
+    p = lambda a: a.ctypes.data_as(vp)
+    arrs = [np.ascontiguousarray(corpus[k]) for k in ("str", "sentind", "tstr", "tsentind", "lsrc", "rsrc", "ltar", "rtar", "lexk", "lexv")]
+    ix = lib.orc_index_from_arrays(p(arrs[0]), len(arrs[0]), p(arrs[1]), len(arrs[1]) - 1, p(arrs[2]), len(arrs[2]), p(arrs[3]), p(arrs[4]), p(arrs[5]),
+                                   p(arrs[6]), p(arrs[7]), p(arrs[8]), p(arrs[9]), len(arrs[8]), None)
+    oout = tmp_path / "o"; oout.mkdir()
+    b = lib.orc_batch_from_ids(p(qoff), len(qoff), p(qtok), len(qtok))
+    assert lib.orc_run_all(ix, b, str(oout).encode()) == 0
+    assert op.sha_dir(str(out), 12) == op.sha_dir(str(oout), 12)
+    assert nrules == sum(sum(1 for _ in open(oout / f, "rb")) for f in os.listdir(oout))
+    ex.close(); host.close()
