@@ -27,6 +27,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <pthread.h>
+#include <unistd.h>
 
 #define SAMPLER 300
 #define LONGEST_SRC 5
@@ -406,13 +408,6 @@ static void scores(lexent *l, uint32_t n) {
 static int pattern_src(const cgx_gappat *p, int32_t *src) { int n = 0; for (int j = 0; j < p->number; j++) if (p->pat[j] >= 0) src[n++] = p->pat[j]; return n; }
 static int block_src(const batch *b, uint32_t bn, int32_t *src) { const cgx_block *k = &b->blocks[bn]; for (int s = 0; s < k->matchlen; s++) src[s] = b->c->str[k->string_start + s]; return k->matchlen; }
 
-static int push_task(batch *b, uint32_t *cap, uint32_t lexid, const int32_t *src, int nsrc, uint32_t tstart, int end, int g1, int g1e, int g2, int g2e) {
-    if (b->ntask == *cap) { *cap = *cap ? *cap * 2 : 4096; b->tasks = realloc(b->tasks, (size_t)*cap * sizeof *b->tasks); if (!b->tasks) return -1; }
-    cgx_lextask *t = &b->tasks[b->ntask++]; memset(t, 0, sizeof *t);
-    t->lexid = lexid; t->nsrc = (uint8_t)nsrc; for (int j = 0; j < nsrc; j++) t->src[j] = src[j];
-    t->tstart = tstart; t->end = (uint8_t)end; t->gap1 = (uint8_t)g1; t->gap1_1 = (uint8_t)g1e; t->gap2 = (uint8_t)g2; t->gap2_1 = (uint8_t)g2e;
-    return 0;
-}
 static range *make_ranges(const lexent *l, uint32_t nl, uint32_t nid) {
     range *r = malloc(((size_t)nid + 1) * sizeof *r);
     if (!r) return NULL;
@@ -421,86 +416,114 @@ static range *make_ranges(const lexent *l, uint32_t nl, uint32_t nid) {
     return r;
 }
 
-static int build_lexicons(batch *b) {
+/* converted id of rule i (ExtractPair.c:724-728, 1000-1006) */
+static uint32_t rule_cid(const batch *b, int kind, uint32_t i) {
+    const uint32_t G = b->g, D2 = b->d2;
+    if (kind == 0) return (uint32_t)b->r0[i].block;
+    if (kind == 1) return i < b->sep1 ? (uint32_t)b->r1[i].id : 2 * G + (uint32_t)b->r1[i].id;
+    return i < b->sep2a ? (uint32_t)b->r2[i].id : i < b->sep2b ? G + (uint32_t)b->r2[i].id : G + D2 + (uint32_t)b->r2[i].id;
+}
+/* source words of the group with converted id cid (for the MaxLex task) */
+static int group_src(const batch *b, int kind, uint32_t cid, int32_t *src) {
     const uint32_t G = b->g, D1 = b->d1, D2 = b->d2;
-    uint32_t taskcap = 0; grpmap gm; int32_t sym[48], src[8];
-    if (grp_init(&gm)) return CGX_ERR_NOMEM;
-    /* ---- one gap: [Xab (bnum) | abX (G+bnum)] ++ [aXb (2G+id)]  (ExtractPair.c:664-936) ---- */
-    int *fs = calloc((size_t)2 * G + D1 + 1, sizeof(int));
-    b->lex1 = malloc(((size_t)b->n1 + 1) * sizeof *b->lex1);
-    if (!fs || !b->lex1) return CGX_ERR_NOMEM;
-    for (uint32_t i = 0; i < b->n1; i++) fs[i < b->sep1 ? (uint32_t)b->r1[i].id : 2 * G + (uint32_t)b->r1[i].id]++;
-    uint32_t nl = 0, cid = 0; int nsrc = 0;
-    for (uint32_t i = 0; i < b->n1; i++) {
-        const cgx_rule1 *r = &b->r1[i];
-        if (i == 0 || r->id != b->r1[i - 1].id || i == b->sep1) {
-            gm.cur++;
-            if (i < b->sep1) { cid = (uint32_t)r->id; nsrc = block_src(b, cid < G ? cid : cid - G, src); }
-            else { cid = 2 * G + (uint32_t)r->id; nsrc = pattern_src(&b->p1[b->s1[r->id].position], src); }
-        }
-        int n = rule_symbols(b, 1, i, sym); uint64_t h = hash_syms(sym, n);
-        uint32_t hit = grp_find(&gm, b, 1, b->lex1, sym, n, h);
-        if (hit != UINT32_MAX) { b->lex1[hit].paircount++; continue; }
-        if (push_task(b, &taskcap, nl, src, nsrc, r->tstart, r->end, r->gap1, r->gap1_1, 0, 0)) return CGX_ERR_NOMEM;
-        lexent *e = &b->lex1[nl]; memset(e, 0, sizeof *e);
-        e->id = (int32_t)cid; e->rule = i; e->paircount = 1; e->f = fs[cid];
-        if (i < b->sep1) { uint32_t real = cid >= G ? cid - G : cid; e->fsample = 1 + b->blocks[real].end - b->blocks[real].start; }
-        else e->fsample = marker_fsample(b, (uint32_t)r->id);
-        if (e->fsample > SAMPLER) e->fsample = SAMPLER;
-        grp_add(&gm, h, nl); nl++;
+    if (kind == 0) return block_src(b, cid, src);
+    if (kind == 1) return cid < 2 * G ? block_src(b, cid < G ? cid : cid - G, src) : pattern_src(&b->p1[b->s1[cid - 2 * G].position], src);
+    if (cid < G) return block_src(b, cid, src);
+    if (cid < G + D2) { const cgx_twogapsearch *t = &b->s2[cid - G]; int n = pattern_src(&b->p1[b->s1[t->blockid].position], src); src[n++] = b->c2[t->position]; return n; }
+    return pattern_src(&b->p1[b->s1[cid < G + D2 + D1 ? cid - G - D2 : cid - G - D2 - D1].position], src);
+}
+static int group_fsample(const batch *b, int kind, uint32_t cid) {
+    const uint32_t G = b->g, D1 = b->d1, D2 = b->d2; int fs;
+    if (kind == 0) fs = 1 + b->blocks[cid].end - b->blocks[cid].start;
+    else if (kind == 1) { if (cid < 2 * G) { uint32_t r = cid >= G ? cid - G : cid; fs = 1 + b->blocks[r].end - b->blocks[r].start; } else fs = marker_fsample(b, cid - 2 * G); }
+    else if (cid < G) fs = 1 + b->blocks[cid].end - b->blocks[cid].start;
+    else if (cid < G + D2) fs = 1 + b->s2[cid - G].sa_end - b->s2[cid - G].sa_start;
+    else fs = marker_fsample(b, cid < G + D2 + D1 ? cid - G - D2 : cid - G - D2 - D1);
+    return fs > SAMPLER ? SAMPLER : fs;
+}
+
+typedef struct {
+    const batch *b; int kind; uint32_t lo, hi;       /* rule range, aligned to group starts */
+    lexent *lex; uint32_t nl, cap; cgx_lextask *tasks; int rc;
+} lexjob;
+static void *lex_worker(void *arg) {
+    lexjob *j = arg; const batch *b = j->b; const int kind = j->kind;
+    grpmap gm; int32_t sym[48], src[8]; int nsrc = 0; uint32_t cid = 0; int fsample = 0;
+    j->rc = CGX_ERR_NOMEM; j->nl = 0; j->cap = j->hi - j->lo + 1;
+    j->lex = malloc((size_t)j->cap * sizeof *j->lex); j->tasks = malloc((size_t)j->cap * sizeof *j->tasks);
+    if (!j->lex || !j->tasks || grp_init(&gm)) return NULL;
+    for (uint32_t i = j->lo; i < j->hi; i++) {
+        uint32_t c = rule_cid(b, kind, i);
+        if (i == j->lo || c != cid) { cid = c; gm.cur++; nsrc = group_src(b, kind, cid, src); fsample = group_fsample(b, kind, cid); }
+        int n = rule_symbols(b, kind, i, sym); uint64_t h = hash_syms(sym, n);
+        uint32_t hit = grp_find(&gm, b, kind, j->lex, sym, n, h);
+        if (hit != UINT32_MAX) { j->lex[hit].paircount++; continue; }
+        lexent *e = &j->lex[j->nl]; memset(e, 0, sizeof *e);
+        e->id = (int32_t)cid; e->rule = i; e->paircount = 1; e->fsample = fsample;
+        cgx_lextask *t = &j->tasks[j->nl]; memset(t, 0, sizeof *t);
+        t->lexid = j->nl; t->nsrc = (uint8_t)nsrc; for (int q = 0; q < nsrc; q++) t->src[q] = src[q];
+        if (kind == 0) { t->tstart = (uint32_t)b->r0[i].tar_start; t->end = b->r0[i].tar_end; }
+        else if (kind == 1) { t->tstart = b->r1[i].tstart; t->end = b->r1[i].end; t->gap1 = b->r1[i].gap1; t->gap1_1 = b->r1[i].gap1_1; }
+        else { t->tstart = b->r2[i].tstart; t->end = b->r2[i].end; t->gap1 = b->r2[i].gap1; t->gap1_1 = b->r2[i].gap1_1; t->gap2 = b->r2[i].gap2; t->gap2_1 = b->r2[i].gap2_1; }
+        grp_add(&gm, h, j->nl); j->nl++;
     }
-    scores(b->lex1, nl); b->nl1 = nl; free(fs);
-    if (!(b->rng1 = make_ranges(b->lex1, nl, 2 * G + D1))) return CGX_ERR_NOMEM;
-    /* ---- two gaps: [XabX (bnum)] ++ [aXbXc (G+id)] ++ [XaXb (G+D2+id) | aXbX (G+D2+D1+id)]  (ExtractPair.c:939-1276) ---- */
-    fs = calloc((size_t)G + 2 * D1 + D2 + 1, sizeof(int));
-    b->lex2 = malloc(((size_t)b->n2 + 1) * sizeof *b->lex2);
-    if (!fs || !b->lex2) return CGX_ERR_NOMEM;
-    for (uint32_t i = 0; i < b->n2; i++) fs[i < b->sep2a ? (uint32_t)b->r2[i].id : i < b->sep2b ? G + (uint32_t)b->r2[i].id : G + D2 + (uint32_t)b->r2[i].id]++;
-    nl = 0;
-    for (uint32_t i = 0; i < b->n2; i++) {
-        const cgx_rule2 *r = &b->r2[i];
-        if (i == 0 || r->id != b->r2[i - 1].id || i == b->sep2a || i == b->sep2b) {
-            gm.cur++;
-            if (i < b->sep2a) { cid = (uint32_t)r->id; nsrc = block_src(b, cid, src); }
-            else if (i < b->sep2b) { cid = G + (uint32_t)r->id; nsrc = pattern_src(&b->p1[b->s1[b->s2[r->id].blockid].position], src); src[nsrc++] = b->c2[b->s2[r->id].position]; }
-            else { cid = G + D2 + (uint32_t)r->id; uint32_t one = cid >= G + D2 + D1 ? (uint32_t)r->id - D1 : (uint32_t)r->id; nsrc = pattern_src(&b->p1[b->s1[one].position], src); }
-        }
-        int n = rule_symbols(b, 2, i, sym); uint64_t h = hash_syms(sym, n);
-        uint32_t hit = grp_find(&gm, b, 2, b->lex2, sym, n, h);
-        if (hit != UINT32_MAX) { b->lex2[hit].paircount++; continue; }
-        if (push_task(b, &taskcap, nl, src, nsrc, r->tstart, r->end, r->gap1, r->gap1_1, r->gap2, r->gap2_1)) return CGX_ERR_NOMEM;
-        lexent *e = &b->lex2[nl]; memset(e, 0, sizeof *e);
-        e->id = (int32_t)cid; e->rule = i; e->paircount = 1; e->f = fs[cid];
-        if (i < b->sep2a) e->fsample = 1 + b->blocks[r->id].end - b->blocks[r->id].start;
-        else if (i < b->sep2b) e->fsample = 1 + b->s2[r->id].sa_end - b->s2[r->id].sa_start;
-        else e->fsample = marker_fsample(b, cid >= G + D2 + D1 ? (uint32_t)r->id - D1 : (uint32_t)r->id);
-        if (e->fsample > SAMPLER) e->fsample = SAMPLER;
-        grp_add(&gm, h, nl); nl++;
-    }
-    scores(b->lex2, nl); b->nl2 = nl; free(fs);
-    if (!(b->rng2 = make_ranges(b->lex2, nl, G + 2 * D1 + D2))) return CGX_ERR_NOMEM;
-    /* ---- contiguous (ExtractPair.c:515-662) ---- */
-    fs = calloc((size_t)G + 1, sizeof(int));
-    b->lex0 = malloc(((size_t)b->n0 + 1) * sizeof *b->lex0);
-    if (!fs || !b->lex0) return CGX_ERR_NOMEM;
-    for (uint32_t i = 0; i < b->n0; i++) fs[b->r0[i].block]++;
-    nl = 0;
-    for (uint32_t i = 0; i < b->n0; i++) {
-        const cgx_rule0 *r = &b->r0[i];
-        if (i == 0 || r->block != b->r0[i - 1].block) { gm.cur++; nsrc = block_src(b, (uint32_t)r->block, src); }
-        int n = rule_symbols(b, 0, i, sym); uint64_t h = hash_syms(sym, n);
-        uint32_t hit = grp_find(&gm, b, 0, b->lex0, sym, n, h);
-        if (hit != UINT32_MAX) { b->lex0[hit].paircount++; continue; }
-        if (push_task(b, &taskcap, nl, src, nsrc, (uint32_t)r->tar_start, r->tar_end, 0, 0, 0, 0)) return CGX_ERR_NOMEM;
-        lexent *e = &b->lex0[nl]; memset(e, 0, sizeof *e);
-        e->id = r->block; e->rule = i; e->paircount = 1; e->f = fs[r->block];
-        e->fsample = 1 + b->blocks[r->block].end - b->blocks[r->block].start; if (e->fsample > SAMPLER) e->fsample = SAMPLER;
-        grp_add(&gm, h, nl); nl++;
-    }
-    scores(b->lex0, nl); b->nl0 = nl; free(fs);
-    if (!(b->rng0 = make_ranges(b->lex0, nl, G))) return CGX_ERR_NOMEM;
     grp_free(&gm);
-    return CGX_OK;
+    j->rc = CGX_OK;
+    return NULL;
+}
+/* f = number of rules in the entry's id group (fsample_arr, ExtractPair.c:718-730) */
+static void fill_group_sizes(const batch *b, int kind, lexent *lex, uint32_t nl, uint32_t nrules) {
+    uint32_t i = 0;
+    while (i < nl) {
+        uint32_t k = i; while (k < nl && lex[k].id == lex[i].id) k++;
+        uint32_t first = lex[i].rule, r = first, cid = (uint32_t)lex[i].id;   /* a group's first entry is made by its first rule */
+        while (r < nrules && rule_cid(b, kind, r) == cid) r++;
+        for (uint32_t q = i; q < k; q++) lex[q].f = (int32_t)(r - first);
+        i = k;
+    }
+}
+static int nthreads_host(void) {
+    const char *e = getenv("CGX_THREADS"); int n = e ? atoi(e) : 0;
+    if (n <= 0) { long c = sysconf(_SC_NPROCESSORS_ONLN); n = c > 16 ? 16 : (int)c; }
+    return n < 1 ? 1 : n > 64 ? 64 : n;
+}
+static int build_lex_kind(batch *b, int kind, uint32_t nrules, lexent **out, uint32_t *nout, uint32_t nid, range **rng, uint32_t *taskcap) {
+    int nt = nthreads_host(); if ((uint32_t)nt > nrules / 4096 + 1) nt = (int)(nrules / 4096 + 1);
+    lexjob jobs[64]; pthread_t th[64]; uint32_t cut[65]; cut[0] = 0;
+    for (int t = 1; t < nt; t++) {                    /* cut points moved forward to the next group start */
+        uint32_t c = (uint32_t)((uint64_t)nrules * (uint64_t)t / (uint64_t)nt);
+        if (c < cut[t - 1]) c = cut[t - 1];
+        while (c > 0 && c < nrules && rule_cid(b, kind, c) == rule_cid(b, kind, c - 1)) c++;
+        cut[t] = c;
+    }
+    cut[nt] = nrules;
+    for (int t = 0; t < nt; t++) { memset(&jobs[t], 0, sizeof jobs[t]); jobs[t].b = b; jobs[t].kind = kind; jobs[t].lo = cut[t]; jobs[t].hi = cut[t + 1]; }
+    for (int t = 1; t < nt; t++) if (pthread_create(&th[t], NULL, lex_worker, &jobs[t])) return CGX_ERR_NOMEM;
+    lex_worker(&jobs[0]);
+    for (int t = 1; t < nt; t++) pthread_join(th[t], NULL);
+    uint32_t total = 0;
+    for (int t = 0; t < nt; t++) { if (jobs[t].rc != CGX_OK) return jobs[t].rc; total += jobs[t].nl; }
+    lexent *lex = malloc(((size_t)total + 1) * sizeof *lex);
+    if (!lex) return CGX_ERR_NOMEM;
+    if (b->ntask + total > *taskcap) { *taskcap = b->ntask + total + 1; b->tasks = realloc(b->tasks, (size_t)*taskcap * sizeof *b->tasks); if (!b->tasks) return CGX_ERR_NOMEM; }
+    uint32_t o = 0;
+    for (int t = 0; t < nt; t++) {
+        memcpy(lex + o, jobs[t].lex, (size_t)jobs[t].nl * sizeof *lex);
+        for (uint32_t k = 0; k < jobs[t].nl; k++) { cgx_lextask x = jobs[t].tasks[k]; x.lexid += o; b->tasks[b->ntask + o + k] = x; }
+        o += jobs[t].nl; free(jobs[t].lex); free(jobs[t].tasks);
+    }
+    b->ntask += total;
+    fill_group_sizes(b, kind, lex, total, nrules);
+    scores(lex, total);
+    *out = lex; *nout = total;
+    return (*rng = make_ranges(lex, total, nid)) ? CGX_OK : CGX_ERR_NOMEM;
+}
+static int build_lexicons(batch *b) {
+    const uint32_t G = b->g, D1 = b->d1, D2 = b->d2; uint32_t taskcap = 0; int rc;
+    /* task order = one gap, two gaps, contiguous (the shared lexicalTaskCounter, ExtractPair.cu:3708-3868) */
+    if ((rc = build_lex_kind(b, 1, b->n1, &b->lex1, &b->nl1, 2 * G + D1, &b->rng1, &taskcap)) != CGX_OK) return rc;
+    if ((rc = build_lex_kind(b, 2, b->n2, &b->lex2, &b->nl2, G + 2 * D1 + D2, &b->rng2, &taskcap)) != CGX_OK) return rc;
+    return build_lex_kind(b, 0, b->n0, &b->lex0, &b->nl0, G, &b->rng0, &taskcap);
 }
 
 /* ------------------------------------------------------------------ */
@@ -554,42 +577,74 @@ static int sb_target(sbuf *s, const batch *b, int kind, uint32_t rule) {
     }
     return 0;
 }
+/* "%f" of a float: the value times 10^6 is exact in double (24 + 14 significant bits), so
+ * rounding it to nearest-even is exactly what printf does; odd cases fall back to snprintf. */
+static int sb_f6(sbuf *s, float x) {
+    if (sb_need(s, 64)) return -1;
+    double v = (double)x;
+    if (!(fabs(v) < 1e12)) { s->n += (size_t)snprintf(s->p + s->n, 64, "%f", v); return 0; }
+    char *p = s->p + s->n;
+    if (signbit(v)) { *p++ = '-'; v = -v; }
+    uint64_t m = (uint64_t)rint(v * 1e6), ip = m / 1000000u, fp = m % 1000000u;
+    char tmp[24]; int k = 0; do { tmp[k++] = (char)('0' + ip % 10); ip /= 10; } while (ip);
+    while (k) *p++ = tmp[--k];
+    *p++ = '.';
+    for (int d = 5; d >= 0; d--) { p[d] = (char)('0' + fp % 10); fp /= 10; }
+    p += 6; s->n = (size_t)(p - s->p);
+    return 0;
+}
 static int emit_range(sbuf *s, const batch *b, int kind, const lexent *lex, const range *rng, uint32_t id, uint64_t *lines) {
     if (rng[id].down == -1 || rng[id].up == -1) return 0;
     for (int32_t i = rng[id].down; i <= rng[id].up; i++) {
         const lexent *e = &lex[i];
         if (sb_puts(s, "[X] ||| ") || sb_source(s, b, kind, (uint32_t)e->id) || sb_puts(s, " ||| ") || sb_target(s, b, kind, e->rule)) return -1;
-        if (sb_need(s, 320)) return -1;
-        s->n += (size_t)snprintf(s->p + s->n, 320, " ||| EgivenFCoherent=%f SampleCountF=%f CountEF=%f MaxLexFgivenE=%f MaxLexEgivenF=%f IsSingletonF=%d IsSingletonFE=%d\n",
-                                 e->aa, e->fscore, e->bb, e->fe, e->ef, e->f == 1, e->paircount == 1);
+        if (sb_puts(s, " ||| EgivenFCoherent=") || sb_f6(s, e->aa) || sb_puts(s, " SampleCountF=") || sb_f6(s, e->fscore) || sb_puts(s, " CountEF=") || sb_f6(s, e->bb) ||
+            sb_puts(s, " MaxLexFgivenE=") || sb_f6(s, e->fe) || sb_puts(s, " MaxLexEgivenF=") || sb_f6(s, e->ef) ||
+            sb_puts(s, e->f == 1 ? " IsSingletonF=1" : " IsSingletonF=0") || sb_puts(s, e->paircount == 1 ? " IsSingletonFE=1\n" : " IsSingletonFE=0\n")) return -1;
         (*lines)++;
     }
     return 0;
 }
-static int write_grammars(const batch *b, const char *outdir, int32_t first, uint64_t *lines) {
+typedef struct { const batch *b; const char *outdir; int32_t first; int32_t *next; uint64_t lines; int rc; } writejob;
+static void *write_worker(void *arg) {
+    writejob *w = arg; const batch *b = w->b;
     const uint32_t G = b->g, D1 = b->d1, D2 = b->d2;
-    sbuf s; memset(&s, 0, sizeof s); char fn[4096];
-    for (int32_t q = 0; q < b->nq; q++) {
-        s.n = 0;
-        for (uint32_t k = 0; k < b->qblocks[q].n; k++) {
+    sbuf s; memset(&s, 0, sizeof s); char fn[4096]; uint64_t *lines = &w->lines;
+    w->rc = CGX_OK;
+    for (;;) {
+        int32_t q = __atomic_fetch_add(w->next, 1, __ATOMIC_RELAXED);
+        if (q >= b->nq) break;
+        s.n = 0; int bad = 0;
+        for (uint32_t k = 0; !bad && k < b->qblocks[q].n; k++) {
             uint32_t p = b->qblocks[q].v[k];
-            if (emit_range(&s, b, 1, b->lex1, b->rng1, p + G, lines) || emit_range(&s, b, 1, b->lex1, b->rng1, p, lines) ||
-                emit_range(&s, b, 2, b->lex2, b->rng2, p, lines) || emit_range(&s, b, 0, b->lex0, b->rng0, p, lines)) { free(s.p); return CGX_ERR_NOMEM; }
+            bad = emit_range(&s, b, 1, b->lex1, b->rng1, p + G, lines) || emit_range(&s, b, 1, b->lex1, b->rng1, p, lines) ||
+                  emit_range(&s, b, 2, b->lex2, b->rng2, p, lines) || emit_range(&s, b, 0, b->lex0, b->rng0, p, lines);
         }
-        for (uint32_t k = 0; b->qone && k < b->qone[q].n; k++) {
+        for (uint32_t k = 0; !bad && b->qone && k < b->qone[q].n; k++) {
             uint32_t id = b->qone[q].v[k];
-            if (emit_range(&s, b, 1, b->lex1, b->rng1, 2 * G + id, lines) || emit_range(&s, b, 2, b->lex2, b->rng2, G + D2 + id, lines) ||
-                emit_range(&s, b, 2, b->lex2, b->rng2, G + D2 + D1 + id, lines)) { free(s.p); return CGX_ERR_NOMEM; }
+            bad = emit_range(&s, b, 1, b->lex1, b->rng1, 2 * G + id, lines) || emit_range(&s, b, 2, b->lex2, b->rng2, G + D2 + id, lines) ||
+                  emit_range(&s, b, 2, b->lex2, b->rng2, G + D2 + D1 + id, lines);
         }
-        for (uint32_t k = 0; b->qtwo && k < b->qtwo[q].n; k++)
-            if (emit_range(&s, b, 2, b->lex2, b->rng2, G + b->qtwo[q].v[k], lines)) { free(s.p); return CGX_ERR_NOMEM; }
-        snprintf(fn, sizeof fn, "%s/grammar.%d.s", outdir, first + q);
+        for (uint32_t k = 0; !bad && b->qtwo && k < b->qtwo[q].n; k++) bad = emit_range(&s, b, 2, b->lex2, b->rng2, G + b->qtwo[q].v[k], lines);
+        if (bad) { w->rc = CGX_ERR_NOMEM; break; }
+        snprintf(fn, sizeof fn, "%s/grammar.%d.s", w->outdir, w->first + q);
         FILE *fp = fopen(fn, "w");
-        if (!fp) { free(s.p); return CGX_ERR_IO; }
-        if (s.n && fwrite(s.p, 1, s.n, fp) != s.n) { fclose(fp); free(s.p); return CGX_ERR_IO; }
+        if (!fp) { w->rc = CGX_ERR_IO; break; }
+        if (s.n && fwrite(s.p, 1, s.n, fp) != s.n) { fclose(fp); w->rc = CGX_ERR_IO; break; }
         fclose(fp);
     }
     free(s.p);
+    return NULL;
+}
+/* one file per query (PrintResults.c:434-446); queries are independent, so a pool of host threads formats them */
+static int write_grammars(const batch *b, const char *outdir, int32_t first, uint64_t *lines) {
+    int nt = nthreads_host(); if (nt > b->nq) nt = b->nq > 0 ? b->nq : 1;
+    writejob jobs[64]; pthread_t th[64]; int32_t next = 0;
+    for (int t = 0; t < nt; t++) { jobs[t].b = b; jobs[t].outdir = outdir; jobs[t].first = first; jobs[t].next = &next; jobs[t].lines = 0; jobs[t].rc = CGX_OK; }
+    for (int t = 1; t < nt; t++) if (pthread_create(&th[t], NULL, write_worker, &jobs[t])) return CGX_ERR_NOMEM;
+    write_worker(&jobs[0]);
+    for (int t = 1; t < nt; t++) pthread_join(th[t], NULL);
+    for (int t = 0; t < nt; t++) { if (jobs[t].rc != CGX_OK) return jobs[t].rc; *lines += jobs[t].lines; }
     return CGX_OK;
 }
 

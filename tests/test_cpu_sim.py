@@ -16,3 +16,11 @@ def test_device_rule_functions_on_host(oracle_bin, tmp_path):
     op.run_oracle(oracle_bin, os.path.join(ROOT, "tests", "golden", "tiny"), str(tmp_path / "o"), dump)
     r = subprocess.run([exe, dump], capture_output=True, text=True)
     assert r.returncode == 0 and "SIM OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_writer_float_formatting_equals_printf(tmp_path):
+    exe = str(tmp_path / "f6test")
+    subprocess.run(["gcc", "-O1", "-std=gnu11", "-w", os.path.join(ROOT, "tests", "cpu_sim", "f6test.c"), "-lm", "-lpthread",
+                    "-Wl,--unresolved-symbols=ignore-all", "-o", exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and "F6 OK" in r.stdout, r.stdout
