@@ -640,97 +640,132 @@ template <class T> __global__ void k_permute(const T *src, const uint32_t *perm,
 }
 
 // ------------------------------------------------------------------------------------
-// one-gap lookup (oneGapLookUpSA, GappyLook.cu:128-474).  Plan: per distinct pattern pick the
-// occurrence list to drive from (frequent-pair list, a's SA interval or b's, whichever the
-// reference picks); the work items (pattern, occurrence) are flattened with a scan so that
-// heavy patterns spread over the whole chip instead of one block each.
+// one-gap lookup (oneGapLookUpSA, GappyLook.cu:128-474), inverted.
+// The reference scans, for EVERY distinct pattern aXb, the whole occurrence list of its rarer
+// side (one CUDA block per pattern).  Here the patterns are first grouped by the phrase they
+// would scan from: every occurrence of a driving phrase is visited ONCE, its <= 13-token window
+// is walked once, and each window token is looked up (binary search) among the group's
+// patterns keyed by the first token of their other side.  The hit set per pattern is the same
+// set {(start,len)} whichever side drives (the reference's three strategies are equivalent),
+// and the result is sorted on the full record afterwards, so the output is unchanged while the
+// work drops from sum_patterns |driver list| to sum_distinct-drivers |driver list|.
+//   record key: mode(1) | driver SA start(32) | driver length(3) | other side's first token(w<=25)
+// Frequent-pair "marker" patterns (single frequent a and b) keep the reference's one-record
+// representation pointing at the precomputed list (GappyLook.cu:258-272).
 // ------------------------------------------------------------------------------------
-struct plan1 { int32_t mode; uint32_t base; };          // mode 0 marker, 1 frequent-pair list, 2 forward from a, 3 backward from b
 __device__ __forceinline__ int pre_index_dev(const int8_t *tokrank, int32_t a, int32_t b) {
     int ra = tokrank[a], rb = tokrank[b];
     return (ra >= 0 && rb >= 0) ? ra * CGX_TOP + rb : -1;
 }
+#define REC_TOKBITS 25
 __global__ void k_plan1(cgx_gapsearch *s1, uint32_t d1, const int32_t *qtok, const int32_t *lm, const int32_t *up, const int32_t *down,
-                        const int8_t *tokrank, const uint32_t *pidx, plan1 *plan, uint64_t *work) {
+                        const int8_t *tokrank, const uint32_t *pidx, uint64_t *reckey, uint32_t *recpid, unsigned int *nrec,
+                        uint64_t *markkey, unsigned int *nmark) {
     uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= d1) return;
-    cgx_gapsearch s = s1[id];
-    int al = s.a_len, bl = s.b_len; int32_t t = s.qrystart, sb = t + s.gap + al;
-    plan1 pl; pl.mode = -1; pl.base = 0; uint64_t w = 0;
-    if (s.gap != 0 && t >= 0 && lm[sb] >= bl && lm[t] >= al) {
-        int pre = pre_index_dev(tokrank, qtok[t + al - 1], qtok[sb]);
-        if (pre == -1) {
-            int64_t u1 = up[(size_t)t * 5 + al - 1], d1_ = down[(size_t)t * 5 + al - 1], u2 = up[(size_t)sb * 5 + bl - 1], d2 = down[(size_t)sb * 5 + bl - 1];
-            if (d1_ - u1 <= d2 - u2) { pl.mode = 2; pl.base = (uint32_t)u1; w = (uint64_t)(d1_ - u1 + 1); }
-            else { pl.mode = 3; pl.base = (uint32_t)u2; w = (uint64_t)(d2 - u2 + 1); }
-        } else {
-            int64_t ps = pidx[2 * pre], pe = pidx[2 * pre + 1], dis = pe - ps;
-            if (al == 1 && bl == 1 && dis >= 0) { pl.mode = 0; pl.base = (uint32_t)pre; w = 1; s1[id].marker = 1; }
-            else { pl.mode = 1; pl.base = (uint32_t)ps; w = dis >= 0 ? (uint64_t)(dis + 1) : 0; }
+    bool isrec = false, ismark = false; uint64_t key = 0, mkey = 0;
+    if (id < d1) {
+        cgx_gapsearch s = s1[id];
+        int al = s.a_len, bl = s.b_len; int32_t t = s.qrystart, sb = t + s.gap + al;
+        if (s.gap != 0 && t >= 0 && lm[sb] >= bl && lm[t] >= al) {
+            int pre = pre_index_dev(tokrank, qtok[t + al - 1], qtok[sb]);
+            if (pre != -1 && al == 1 && bl == 1) {
+                if ((int64_t)pidx[2 * pre + 1] - (int64_t)pidx[2 * pre] >= 0) { ismark = true; mkey = ((uint64_t)id << 36) | ((uint64_t)(uint32_t)pre << 4); s1[id].marker = 1; }
+            } else {
+                int64_t u1 = up[(size_t)t * 5 + al - 1], e1 = down[(size_t)t * 5 + al - 1], u2 = up[(size_t)sb * 5 + bl - 1], e2 = down[(size_t)sb * 5 + bl - 1];
+                isrec = true;
+                if (e1 - u1 <= e2 - u2) key = (0ull << 63) | ((uint64_t)(uint32_t)u1 << (3 + REC_TOKBITS)) | ((uint64_t)al << REC_TOKBITS) | (uint64_t)(uint32_t)qtok[sb];
+                else key = (1ull << 63) | ((uint64_t)(uint32_t)u2 << (3 + REC_TOKBITS)) | ((uint64_t)bl << REC_TOKBITS) | (uint64_t)(uint32_t)qtok[t + al - 1];
+            }
         }
     }
-    plan[id] = pl; work[id] = w;
+    uint32_t slot = wave_append(nrec, isrec);
+    if (isrec) { reckey[slot] = key; recpid[slot] = id; }
+    slot = wave_append(nmark, ismark);
+    if (ismark) markkey[slot] = mkey;
 }
-// hit record key: pattern id (28 bits) | corpus start (32) | length (4)
+struct grp1 { uint32_t rec0, rec1; uint32_t base; uint32_t len; uint32_t backward; };   // records [rec0,rec1), driver SA interval start, phrase length
+__global__ void k_groups1(const uint64_t *reckey, const uint32_t *flags, const uint32_t *incl, uint32_t nrec, grp1 *groups) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= nrec) return;
+    uint32_t g = incl[i] - 1;
+    if (flags[i]) { uint64_t k = reckey[i]; groups[g].rec0 = (uint32_t)i; groups[g].base = (uint32_t)((k >> (3 + REC_TOKBITS)) & 0xFFFFFFFFu); groups[g].len = (uint32_t)((k >> REC_TOKBITS) & 7); groups[g].backward = (uint32_t)(k >> 63); }
+    if (i + 1 == nrec || flags[i + 1]) groups[g].rec1 = (uint32_t)i + 1;
+}
+__global__ void k_grpflags1(const uint64_t *reckey, uint32_t *flags, uint32_t nrec) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < nrec) flags[i] = (i == 0 || (reckey[i] >> REC_TOKBITS) != (reckey[i - 1] >> REC_TOKBITS)) ? 1u : 0u;
+}
+__global__ void k_grpwork1(const grp1 *groups, uint32_t ng, const uint32_t *grp_down, uint64_t *work) {
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < ng) work[g] = (uint64_t)grp_down[g] - groups[g].base + 1;
+}
+// SA interval end of each group's driving phrase: taken from any of its patterns
+__global__ void k_grpdown1(const grp1 *groups, uint32_t ng, const uint32_t *recpid, const cgx_gapsearch *s1, const int32_t *down, uint32_t *grp_down) {
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ng) return;
+    cgx_gapsearch s = s1[recpid[groups[g].rec0]];
+    grp_down[g] = groups[g].backward ? (uint32_t)down[(size_t)(s.qrystart + s.gap + s.a_len) * 5 + s.b_len - 1] : (uint32_t)down[(size_t)s.qrystart * 5 + s.a_len - 1];
+}
 #define HITKEY(id, start, len) (((uint64_t)(id) << 36) | ((uint64_t)(uint32_t)(start) << 4) | (uint64_t)(len))
+// first record of [r0,r1) whose other-side first token is >= tk
+__device__ __forceinline__ uint32_t rec_lower(const uint64_t *reckey, uint32_t r0, uint32_t r1, uint32_t tk) {
+    while (r0 < r1) { uint32_t m = (r0 + r1) >> 1; if ((uint32_t)(reckey[m] & ((1u << REC_TOKBITS) - 1)) < tk) r0 = m + 1; else r1 = m; }
+    return r0;
+}
 template <bool FILL>
-__global__ void k_look1(cgx_view v, const int32_t *sa, const cgx_gapsearch *s1, const plan1 *plan, const uint64_t *woff, uint32_t d1,
-                        uint64_t w0, uint64_t nw, const int32_t *qtok, const uint32_t *phs, const uint8_t *phl,
+__global__ void k_look1(cgx_view v, const int32_t *sa, const cgx_gapsearch *s1, const grp1 *groups, const uint64_t *woff, uint32_t ng,
+                        uint64_t w0, uint64_t nw, const int32_t *qtok, const uint64_t *reckey, const uint32_t *recpid,
                         uint8_t *count, const uint32_t *offset, uint64_t *keys) {
     uint64_t wi = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (wi >= nw) return;
-    uint32_t id = seg_of(woff, d1, w0 + wi);
-    uint64_t x = w0 + wi - woff[id];
-    cgx_gapsearch s = s1[id]; plan1 pl = plan[id];
-    const int al = s.a_len, bl = s.b_len; const int32_t t = s.qrystart, sb = t + s.gap + al;
+    uint32_t g = seg_of(woff, ng, w0 + wi);
+    uint64_t x = w0 + wi - woff[g];
+    grp1 gr = groups[g];
+    const int dl = (int)gr.len;                            // length of the driving phrase
+    int64_t go = sa[gr.base + x];
     uint32_t n = 0; uint32_t o = FILL ? offset[wi] : 0;
-    if (pl.mode == 0) {
-        if (FILL) keys[o] = HITKEY(id, pl.base, 0);
-        n = 1;
-    } else if (pl.mode == 1) {                            // frequent-pair list entry: check the rest of a and b around it
-        int64_t ps = phs[pl.base + x]; int plen = phl[pl.base + x]; bool ok = plen + al + bl - 1 <= CGX_MAX_SPAN;
-        for (int k = 1; ok && k < al; k++) if (ps - k < 0 || v.str[ps - k] != qtok[t + al - 1 - k]) ok = false;
-        for (int k = 2; ok && k <= bl; k++) if (v.str[ps + plen + k - 1] != qtok[sb + k - 1]) ok = false;
-        if (ok) { if (FILL) keys[o] = HITKEY(id, ps - al + 1, plen + al - 1 + bl - 1); n = 1; }
-    } else if (pl.mode == 2) {                            // scan right from an occurrence of a
-        int64_t go = sa[pl.base + x];
-        if (v.str[go + al] >= 2) {
-            const int32_t b0 = qtok[sb];
-            for (int move = 0; al + 1 + move + bl <= CGX_MAX_SPAN || move == 0; move++) {
-                int32_t tk = v.str[go + al + 1 + move];
+    if (!gr.backward) {                                    // driving phrase is a: walk right (GappyLook.cu:335-396)
+        if (v.str[go + dl] >= 2) {
+            for (int move = 0; dl + 1 + move + 1 <= CGX_MAX_SPAN; move++) {
+                int64_t pos = go + dl + 1 + move;
+                int32_t tk = v.str[pos];
                 if (tk < 2) break;
-                if (tk == b0) {
-                    int mc = 1; bool dead = false;
-                    while (mc < bl) { int32_t r = v.str[go + al + 1 + move + mc]; if (r < 2) { dead = true; break; } if (r != qtok[sb + mc]) break; mc++; }
-                    if (dead) break;
-                    if (mc == bl && cgx_gap_ok(v, (uint32_t)(go + al), (uint32_t)(go + al + move))) {
-                        if (FILL) keys[o + n] = HITKEY(id, go, al + 1 + move + bl - 1);
-                        n++;
-                    }
+                uint32_t r = rec_lower(reckey, gr.rec0, gr.rec1, (uint32_t)tk);
+                int gapok = -1;
+                for (; r < gr.rec1 && (uint32_t)(reckey[r] & ((1u << REC_TOKBITS) - 1)) == (uint32_t)tk; r++) {
+                    uint32_t id = recpid[r]; cgx_gapsearch s = s1[id];
+                    const int bl = s.b_len; const int32_t sb = s.qrystart + s.gap + s.a_len;
+                    if (dl + 1 + move + bl > CGX_MAX_SPAN) continue;
+                    bool ok = true;
+                    for (int k = 1; ok && k < bl; k++) ok = v.str[pos + k] == qtok[sb + k];
+                    if (!ok) continue;
+                    if (gapok < 0) gapok = cgx_gap_ok(v, (uint32_t)(go + dl), (uint32_t)(go + dl + move)) ? 1 : 0;
+                    if (gapok) { if (FILL) keys[o + n] = HITKEY(id, go, dl + 1 + move + bl - 1); n++; }
                 }
             }
         }
-    } else if (pl.mode == 3) {                            // scan left from an occurrence of b
-        int64_t go = sa[pl.base + x];
+    } else {                                               // driving phrase is b: walk left (GappyLook.cu:397-470)
         if (go - 1 >= 0 && v.str[go - 1] >= 2) {
-            const int32_t a_last = qtok[t + al - 1];
-            for (int move = 0; al + 1 + move + bl <= CGX_MAX_SPAN || move == 0; move++) {
+            for (int move = 0; dl + 1 + move + 1 <= CGX_MAX_SPAN; move++) {
                 int64_t pa = go - 2 - move;
                 int32_t tk = pa < 0 ? -1 : v.str[pa];
                 if (tk < 2) break;
-                if (tk == a_last) {
-                    int mc = 1; bool dead = false;
-                    while (mc < al) { int32_t r = pa - mc < 0 ? -1 : v.str[pa - mc]; if (r < 2) { dead = true; break; } if (r != qtok[t + al - 1 - mc]) break; mc++; }
-                    if (dead) break;
-                    if (mc == al && cgx_gap_ok(v, (uint32_t)(pa + 1), (uint32_t)(go - 1))) {
-                        if (FILL) keys[o + n] = HITKEY(id, pa - al + 1, bl + 1 + move + al - 1);
-                        n++;
-                    }
+                uint32_t r = rec_lower(reckey, gr.rec0, gr.rec1, (uint32_t)tk);
+                int gapok = -1;
+                for (; r < gr.rec1 && (uint32_t)(reckey[r] & ((1u << REC_TOKBITS) - 1)) == (uint32_t)tk; r++) {
+                    uint32_t id = recpid[r]; cgx_gapsearch s = s1[id];
+                    const int al = s.a_len; const int32_t t = s.qrystart;
+                    if (al + 1 + move + dl > CGX_MAX_SPAN) continue;
+                    bool ok = true;
+                    for (int k = 1; ok && k < al; k++) ok = pa - k >= 0 && v.str[pa - k] == qtok[t + al - 1 - k];
+                    if (!ok) continue;
+                    if (gapok < 0) gapok = cgx_gap_ok(v, (uint32_t)(pa + 1), (uint32_t)(go - 1)) ? 1 : 0;
+                    if (gapok) { if (FILL) keys[o + n] = HITKEY(id, pa - al + 1, dl + 1 + move + al - 1); n++; }
                 }
             }
         }
     }
-    if (!FILL) count[wi] = (uint8_t)n;
+    if (!FILL) count[wi] = (uint8_t)(n > 255 ? 255 : n);
 }
 __global__ void k_unpack_hits1(const uint64_t *keys, uint32_t n, cgx_hit1 *hits, cgx_gapsearch *s1) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -814,50 +849,74 @@ __global__ void k_make_s2(const cgx_twogappy *g, const uint32_t *flags, const ui
     uint32_t id = incl[i] - 1; pid[i] = id;
     if (flags[i]) { cgx_twogappy x = g[i]; cgx_twogapsearch s; s.blockid = x.blockid; s.gap2 = x.gap2; s.c_len = x.c_len; s.position = (uint32_t)i; s.sa_start = -1; s.sa_end = -1; s2[id] = s; }
 }
-// two-gap lookup (twoGapLookUpSA, GappyLook.cu:476-737): extend every occurrence of aXb to the right
-__global__ void k_plan2(const cgx_twogapsearch *s2, uint32_t d2, const cgx_gapsearch *s1, const uint32_t *pidx, const cgx_hit1 *hits1, uint64_t *work) {
-    uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= d2) return;
-    cgx_gapsearch g = s1[s2[id].blockid]; uint64_t w = 0;
-    if (g.sa_start != -1 && s2[id].c_len == 1) {
+// two-gap lookup (twoGapLookUpSA, GappyLook.cu:476-737), inverted the same way: the distinct
+// aXbXc patterns are sorted by (one-gap id, c), so all patterns extending the same aXb form one
+// segment.  Every occurrence of that aXb is extended to the right ONCE; each window token is
+// binary-searched among the segment's c tokens.  Emission order is (one-gap id, occurrence,
+// window offset); a stable radix sort on the two-gap id alone then yields the canonical
+// (pattern, start, length, length2) order.
+struct grp2 { uint32_t s0, s1; uint32_t one; };          // s2 segment [s0,s1) of one-gap pattern `one`
+__global__ void k_grpflags2(const cgx_twogapsearch *s2, uint32_t d2, uint32_t *flags) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < d2) flags[i] = (i == 0 || s2[i].blockid != s2[i - 1].blockid) ? 1u : 0u;
+}
+__global__ void k_groups2(const cgx_twogapsearch *s2, const uint32_t *flags, const uint32_t *incl, uint32_t d2, grp2 *groups) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d2) return;
+    uint32_t g = incl[i] - 1;
+    if (flags[i]) { groups[g].s0 = i; groups[g].one = s2[i].blockid; }
+    if (i + 1 == d2 || flags[i + 1]) groups[g].s1 = i + 1;
+}
+__global__ void k_grpwork2(const grp2 *groups, uint32_t ng, const cgx_gapsearch *s1, const uint32_t *pidx, const cgx_hit1 *hits1, uint64_t *work) {
+    uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi >= ng) return;
+    cgx_gapsearch g = s1[groups[gi].one]; uint64_t w = 0;
+    if (g.sa_start != -1) {
         if (g.marker) { uint32_t pre = hits1[g.sa_start].str_position; int64_t ps = pidx[2 * pre], pe = pidx[2 * pre + 1]; w = pe >= ps ? (uint64_t)(pe - ps + 1) : 0; }
         else w = (uint64_t)(g.sa_end - g.sa_start + 1);
     }
-    work[id] = w;
+    work[gi] = w;
 }
 template <bool FILL>
-__global__ void k_look2(cgx_view v, const cgx_twogapsearch *s2, const cgx_gapsearch *s1, const uint64_t *woff, uint32_t d2, uint64_t w0, uint64_t nw,
-                        const int32_t *qtok, const cgx_hit1 *hits1, const uint32_t *pidx, const uint32_t *phs, const uint8_t *phl,
-                        uint8_t *count, const uint32_t *offset, cgx_hit2 *out) {
+__global__ void k_look2(cgx_view v, const cgx_twogapsearch *s2, const int32_t *s2c, const cgx_gapsearch *s1, const grp2 *groups, const uint64_t *woff, uint32_t ng,
+                        uint64_t w0, uint64_t nw, const cgx_hit1 *hits1, const uint32_t *pidx, const uint32_t *phs, const uint8_t *phl,
+                        uint8_t *count, const uint32_t *offset, uint32_t *okey, uint64_t *oval) {
     uint64_t wi = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (wi >= nw) return;
-    uint32_t id = seg_of(woff, d2, w0 + wi);
-    uint64_t x = w0 + wi - woff[id];
-    cgx_twogapsearch ts = s2[id]; cgx_gapsearch g = s1[ts.blockid];
+    uint32_t gi = seg_of(woff, ng, w0 + wi);
+    uint64_t x = w0 + wi - woff[gi];
+    grp2 gr = groups[gi]; cgx_gapsearch g = s1[gr.one];
     uint32_t ps; int pl;
     if (g.marker) { uint32_t pre = hits1[g.sa_start].str_position; uint32_t b = pidx[2 * pre]; ps = phs[b + x]; pl = phl[b + x]; }
     else { cgx_hit1 h = hits1[g.sa_start + x]; ps = h.str_position; pl = h.length; }
     uint32_t n = 0; uint32_t o = FILL ? offset[wi] : 0;
-    const int32_t c = qtok[ts.gap2];
     int64_t go = (int64_t)ps + pl;
-    if (c >= 2 && pl > 0 && v.str[go + 1] >= 2) {
+    if (pl > 0 && v.str[go + 1] >= 2) {
         for (int move = 0; pl + 3 + move <= CGX_MAX_SPAN; move++) {
             int32_t tk = v.str[go + 2 + move];
             if (tk < 2) break;
-            if (tk == c && cgx_gap_ok(v, ps + pl + 1, (uint32_t)(ps + pl + 1 + move))) {
-                if (FILL) { cgx_hit2 h; h.position = id; h.str_position = ps; h.length = (uint8_t)pl; h.length2 = (uint8_t)(pl + 2 + move); out[o + n] = h; }
+            uint32_t a = gr.s0, z = gr.s1;                   // segment sorted by c
+            while (a < z) { uint32_t m = (a + z) >> 1; if (s2c[m] < tk) a = m + 1; else z = m; }
+            if (a < gr.s1 && s2c[a] == tk && s2[a].c_len == 1 && cgx_gap_ok(v, ps + pl + 1, (uint32_t)(ps + pl + 1 + move))) {
+                if (FILL) { okey[o + n] = a; oval[o + n] = ((uint64_t)ps << 8) | ((uint64_t)pl << 4) | (uint64_t)(pl + 2 + move); }
                 n++;
             }
         }
     }
     if (!FILL) count[wi] = (uint8_t)n;
 }
-__global__ void k_ranges2(const cgx_hit2 *hits, uint32_t n, cgx_twogapsearch *s2) {
+__global__ void k_s2c(const cgx_twogapsearch *s2, const int32_t *c2, uint32_t d2, int32_t *s2c) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < d2) s2c[i] = c2[s2[i].position];
+}
+__global__ void k_unpack_hits2(const uint32_t *key, const uint64_t *val, uint32_t n, cgx_hit2 *hits, cgx_twogapsearch *s2) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
-    uint32_t id = hits[i].position;
-    if (i == 0 || hits[i - 1].position != id) s2[id].sa_start = (int32_t)i;
-    if (i + 1 == n || hits[i + 1].position != id) s2[id].sa_end = (int32_t)i;
+    uint32_t id = key[i]; uint64_t w = val[i];
+    cgx_hit2 h; h.position = id; h.str_position = (uint32_t)(w >> 8); h.length = (uint8_t)((w >> 4) & 15); h.length2 = (uint8_t)(w & 15);
+    hits[i] = h;
+    if (i == 0 || key[i - 1] != id) s2[id].sa_start = (int32_t)i;
+    if (i + 1 == n || key[i + 1] != id) s2[id].sa_end = (int32_t)i;
 }
 
 extern "C" int cgx_gappy_search(cgx_ctx *ctx) {
@@ -914,21 +973,40 @@ extern "C" int cgx_gappy_search(cgx_ctx *ctx) {
     ctx->d1 = D1;
     if (D1 >= (1u << 28)) { snprintf(ctx->err, sizeof ctx->err, "too many distinct one-gap patterns"); return CGX_ERR_NOMEM; }
 
-    // ---- one-gap lookup ----
+    // ---- one-gap lookup (patterns grouped by driving phrase) ----
     if (D1) {
-        plan1 *plan = nullptr; uint64_t *work = nullptr, *woff = nullptr;
-        TRY(dalloc(ctx, &plan, D1)); TRY(dalloc(ctx, &work, (size_t)D1 + 1)); TRY(dalloc(ctx, &woff, (size_t)D1 + 1));
-        HIPCHK(hipMemsetAsync(work, 0, ((size_t)D1 + 1) * 8, st));
-        k_plan1<<<nblocks(D1, 256), 256, 0, st>>>(ctx->d_s1, D1, ctx->d_qtok, ctx->d_lm, ctx->d_up, ctx->d_down, ctx->d_tokrank, ctx->d_pidx, plan, work);
-        TRY(excl_scan(ctx, work, woff, (size_t)D1 + 1));
-        uint64_t W = 0; TRY(d2h(ctx, &W, woff + D1, 1));
-        ctx->ms["look1_items"] = (double)W;
+        uint64_t *reckey = nullptr, *sreckey = nullptr, *markkey = nullptr; uint32_t *recpid = nullptr, *srecpid = nullptr; unsigned int *ctr = nullptr;
+        TRY(dalloc(ctx, &reckey, D1)); TRY(dalloc(ctx, &sreckey, D1)); TRY(dalloc(ctx, &markkey, D1)); TRY(dalloc(ctx, &recpid, D1)); TRY(dalloc(ctx, &srecpid, D1)); TRY(dalloc(ctx, &ctr, 2));
+        HIPCHK(hipMemsetAsync(ctr, 0, 8, st));
+        if (bits_for((uint64_t)ctx->last + 1) > REC_TOKBITS) { snprintf(ctx->err, sizeof ctx->err, "vocabulary too large for the lookup record key"); return CGX_ERR_ARG; }
+        k_plan1<<<nblocks(D1, 256), 256, 0, st>>>(ctx->d_s1, D1, ctx->d_qtok, ctx->d_lm, ctx->d_up, ctx->d_down, ctx->d_tokrank, ctx->d_pidx, reckey, recpid, ctr, markkey, ctr + 1);
+        unsigned int hc[2] = {0, 0}; TRY(d2h(ctx, hc, ctr, 2));
+        uint32_t NR = hc[0], NM = hc[1];
         dvec64 keys;
-        cgx_gapsearch *s1 = ctx->d_s1; const int32_t *sa = ctx->d_sa, *qtok = ctx->d_qtok; const uint32_t *phs = ctx->d_phit_start; const uint8_t *phl = ctx->d_phit_len;
-        TRY(chunked_count_fill(ctx, W, keys, [&](bool fill, uint64_t w0, uint64_t nw, uint8_t *c, uint32_t *o, uint64_t *out) {
-            if (fill) k_look1<true><<<nblocks(nw, 256), 256, 0, st>>>(v, sa, s1, plan, woff, D1, w0, nw, qtok, phs, phl, c, o, out);
-            else k_look1<false><<<nblocks(nw, 256), 256, 0, st>>>(v, sa, s1, plan, woff, D1, w0, nw, qtok, phs, phl, c, o, out);
-        }));
+        TRY(dvec_reserve(ctx, keys, (size_t)NM + 1));
+        if (NM) { HIPCHK(hipMemcpyAsync(keys.p, markkey, (size_t)NM * 8, hipMemcpyDeviceToDevice, st)); keys.n = NM; }
+        if (NR) {
+            TRY(sort_pairs(ctx, reckey, sreckey, recpid, srecpid, NR, 0, 64));
+            uint32_t *flags = nullptr, *incl = nullptr; TRY(dalloc(ctx, &flags, NR)); TRY(dalloc(ctx, &incl, NR));
+            k_grpflags1<<<nblocks(NR, 256), 256, 0, st>>>(sreckey, flags, NR);
+            TRY(incl_scan(ctx, flags, incl, NR));
+            uint32_t NG = 0; TRY(d2h(ctx, &NG, incl + (NR - 1), 1));
+            grp1 *groups = nullptr; uint32_t *gdown = nullptr; uint64_t *work = nullptr, *woff = nullptr;
+            TRY(dalloc(ctx, &groups, NG)); TRY(dalloc(ctx, &gdown, NG)); TRY(dalloc(ctx, &work, (size_t)NG + 1)); TRY(dalloc(ctx, &woff, (size_t)NG + 1));
+            HIPCHK(hipMemsetAsync(work, 0, ((size_t)NG + 1) * 8, st));
+            k_groups1<<<nblocks(NR, 256), 256, 0, st>>>(sreckey, flags, incl, NR, groups);
+            k_grpdown1<<<nblocks(NG, 256), 256, 0, st>>>(groups, NG, srecpid, ctx->d_s1, ctx->d_down, gdown);
+            k_grpwork1<<<nblocks(NG, 256), 256, 0, st>>>(groups, NG, gdown, work);
+            TRY(excl_scan(ctx, work, woff, (size_t)NG + 1));
+            uint64_t W = 0; TRY(d2h(ctx, &W, woff + NG, 1));
+            ctx->ms["look1_items"] = (double)W; ctx->ms["look1_groups"] = (double)NG;
+            const cgx_gapsearch *s1 = ctx->d_s1; const int32_t *sa = ctx->d_sa, *qtok = ctx->d_qtok;
+            TRY(chunked_count_fill(ctx, W, keys, [&](bool fill, uint64_t w0, uint64_t nw, uint8_t *c, uint32_t *o, uint64_t *out) {
+                if (fill) k_look1<true><<<nblocks(nw, 256), 256, 0, st>>>(v, sa, s1, groups, woff, NG, w0, nw, qtok, sreckey, srecpid, c, o, out);
+                else k_look1<false><<<nblocks(nw, 256), 256, 0, st>>>(v, sa, s1, groups, woff, NG, w0, nw, qtok, sreckey, srecpid, c, o, out);
+            }));
+            dfree(flags); dfree(incl); dfree(groups); dfree(gdown); dfree(work); dfree(woff);
+        }
         if (keys.n > 0xFFFFFFF0ull) { snprintf(ctx->err, sizeof ctx->err, "too many one-gap occurrences"); return CGX_ERR_NOMEM; }
         uint32_t H1 = (uint32_t)keys.n; ctx->h1 = H1;
         TRY(dalloc(ctx, &ctx->d_hits1, H1));
@@ -939,7 +1017,7 @@ extern "C" int cgx_gappy_search(cgx_ctx *ctx) {
             HIPCHK(hipStreamSynchronize(st));
             dfree(sk);
         }
-        dfree(keys.p); dfree(plan); dfree(work); dfree(woff);
+        dfree(keys.p); dfree(reckey); dfree(sreckey); dfree(markkey); dfree(recpid); dfree(srecpid); dfree(ctr);
     }
 
     // ---- two-gap enumeration ----
@@ -977,42 +1055,54 @@ extern "C" int cgx_gappy_search(cgx_ctx *ctx) {
     }
     ctx->e2 = E2; ctx->d2 = D2;
 
-    // ---- two-gap lookup: ordered compaction keeps (pattern, start, length, length2) order, no sort needed ----
+    // ---- two-gap lookup (patterns grouped by the aXb they extend) ----
+    TRY(dalloc(ctx, &ctx->d_hits2, 1)); ctx->h2 = 0;
     if (D2) {
-        uint64_t *work = nullptr, *woff = nullptr;
-        TRY(dalloc(ctx, &work, (size_t)D2 + 1)); TRY(dalloc(ctx, &woff, (size_t)D2 + 1));
-        HIPCHK(hipMemsetAsync(work, 0, ((size_t)D2 + 1) * 8, st));
-        k_plan2<<<nblocks(D2, 256), 256, 0, st>>>(ctx->d_s2, D2, ctx->d_s1, ctx->d_pidx, ctx->d_hits1, work);
-        TRY(excl_scan(ctx, work, woff, (size_t)D2 + 1));
-        uint64_t W = 0; TRY(d2h(ctx, &W, woff + D2, 1));
-        ctx->ms["look2_items"] = (double)W;
-        // hit2 records are 10 bytes; reuse the chunk driver with a byte-pair trick: collect per-chunk outputs in a vector of chunks
+        int32_t *s2c = nullptr; uint32_t *flags = nullptr, *incl = nullptr;
+        TRY(dalloc(ctx, &s2c, D2)); TRY(dalloc(ctx, &flags, D2)); TRY(dalloc(ctx, &incl, D2));
+        k_s2c<<<nblocks(D2, 256), 256, 0, st>>>(ctx->d_s2, ctx->d_c2, D2, s2c);
+        k_grpflags2<<<nblocks(D2, 256), 256, 0, st>>>(ctx->d_s2, D2, flags);
+        TRY(incl_scan(ctx, flags, incl, D2));
+        uint32_t NG = 0; TRY(d2h(ctx, &NG, incl + (D2 - 1), 1));
+        grp2 *groups = nullptr; uint64_t *work = nullptr, *woff = nullptr;
+        TRY(dalloc(ctx, &groups, NG)); TRY(dalloc(ctx, &work, (size_t)NG + 1)); TRY(dalloc(ctx, &woff, (size_t)NG + 1));
+        HIPCHK(hipMemsetAsync(work, 0, ((size_t)NG + 1) * 8, st));
+        k_groups2<<<nblocks(D2, 256), 256, 0, st>>>(ctx->d_s2, flags, incl, D2, groups);
+        k_grpwork2<<<nblocks(NG, 256), 256, 0, st>>>(groups, NG, ctx->d_s1, ctx->d_pidx, ctx->d_hits1, work);
+        TRY(excl_scan(ctx, work, woff, (size_t)NG + 1));
+        uint64_t W = 0; TRY(d2h(ctx, &W, woff + NG, 1));
+        ctx->ms["look2_items"] = (double)W; ctx->ms["look2_groups"] = (double)NG;
         uint64_t chunk = ctx->chunk_items; uint64_t cw = W < chunk ? W : chunk;
         uint8_t *c8 = nullptr; uint32_t *o32 = nullptr; TRY(dalloc(ctx, &c8, cw + 1)); TRY(dalloc(ctx, &o32, cw + 1));
-        cgx_hit2 *acc = nullptr; size_t accn = 0, acccap = 0;
+        uint32_t *ak = nullptr; uint64_t *av = nullptr; size_t accn = 0, acccap = 0;
         for (uint64_t w0 = 0; w0 < W; w0 += chunk) {
             uint64_t nw = W - w0 < chunk ? W - w0 : chunk;
             HIPCHK(hipMemsetAsync(c8 + nw, 0, 1, st));
-            k_look2<false><<<nblocks(nw, 256), 256, 0, st>>>(v, ctx->d_s2, ctx->d_s1, woff, D2, w0, nw, ctx->d_qtok, ctx->d_hits1, ctx->d_pidx, ctx->d_phit_start, ctx->d_phit_len, c8, o32, nullptr);
+            k_look2<false><<<nblocks(nw, 256), 256, 0, st>>>(v, ctx->d_s2, s2c, ctx->d_s1, groups, woff, NG, w0, nw, ctx->d_hits1, ctx->d_pidx, ctx->d_phit_start, ctx->d_phit_len, c8, o32, nullptr, nullptr);
             TRY(excl_scan(ctx, c8, o32, nw + 1));
             uint32_t total = 0; TRY(d2h(ctx, &total, o32 + nw, 1));
             if (accn + total > acccap) {
                 size_t nc = acccap ? acccap : 1024; while (nc < accn + total) nc *= 2;
-                cgx_hit2 *np = nullptr; TRY(dalloc(ctx, &np, nc));
-                if (accn) HIPCHK(hipMemcpyAsync(np, acc, accn * sizeof(cgx_hit2), hipMemcpyDeviceToDevice, st));
-                HIPCHK(hipStreamSynchronize(st)); dfree(acc); acc = np; acccap = nc;
+                uint32_t *nk = nullptr; uint64_t *nv = nullptr; TRY(dalloc(ctx, &nk, nc)); TRY(dalloc(ctx, &nv, nc));
+                if (accn) { HIPCHK(hipMemcpyAsync(nk, ak, accn * 4, hipMemcpyDeviceToDevice, st)); HIPCHK(hipMemcpyAsync(nv, av, accn * 8, hipMemcpyDeviceToDevice, st)); }
+                HIPCHK(hipStreamSynchronize(st)); dfree(ak); dfree(av); ak = nk; av = nv; acccap = nc;
             }
-            if (total) k_look2<true><<<nblocks(nw, 256), 256, 0, st>>>(v, ctx->d_s2, ctx->d_s1, woff, D2, w0, nw, ctx->d_qtok, ctx->d_hits1, ctx->d_pidx, ctx->d_phit_start, ctx->d_phit_len, c8, o32, acc + accn);
+            if (total) k_look2<true><<<nblocks(nw, 256), 256, 0, st>>>(v, ctx->d_s2, s2c, ctx->d_s1, groups, woff, NG, w0, nw, ctx->d_hits1, ctx->d_pidx, ctx->d_phit_start, ctx->d_phit_len, c8, o32, ak + accn, av + accn);
             HIPCHK(hipGetLastError());
             accn += total;
         }
         HIPCHK(hipStreamSynchronize(st));
         if (accn > 0xFFFFFFF0ull) { snprintf(ctx->err, sizeof ctx->err, "too many two-gap occurrences"); return CGX_ERR_NOMEM; }
-        ctx->d_hits2 = acc; ctx->h2 = (uint32_t)accn;
-        if (!acc) TRY(dalloc(ctx, &ctx->d_hits2, 1));
-        if (accn) k_ranges2<<<nblocks(accn, 256), 256, 0, st>>>(ctx->d_hits2, (uint32_t)accn, ctx->d_s2);
-        HIPCHK(hipStreamSynchronize(st));
-        dfree(c8); dfree(o32); dfree(work); dfree(woff);
+        if (accn) {
+            uint32_t *sk = nullptr; uint64_t *sv = nullptr; TRY(dalloc(ctx, &sk, accn)); TRY(dalloc(ctx, &sv, accn));
+            TRY(sort_pairs(ctx, ak, sk, av, sv, accn, 0, (unsigned)bits_for(D2)));          // stable: keeps (start, length, length2) order inside a pattern
+            dfree(ctx->d_hits2); TRY(dalloc(ctx, &ctx->d_hits2, accn));
+            k_unpack_hits2<<<nblocks(accn, 256), 256, 0, st>>>(sk, sv, (uint32_t)accn, ctx->d_hits2, ctx->d_s2);
+            HIPCHK(hipStreamSynchronize(st));
+            dfree(sk); dfree(sv);
+        }
+        ctx->h2 = (uint32_t)accn;
+        dfree(ak); dfree(av); dfree(c8); dfree(o32); dfree(work); dfree(woff); dfree(groups); dfree(s2c); dfree(flags); dfree(incl);
     }
     HIPCHK(hipGetLastError());
     ctx->ms["gappy"] = tm.stop();
