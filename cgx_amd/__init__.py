@@ -29,6 +29,8 @@ LEXTASK = np.dtype([("lexid", "<u4"), ("src", "<i4", (5,)), ("nsrc", "u1"), ("ts
 GAPSEARCH = np.dtype([("qrystart", "<i4"), ("a_len", "<i4"), ("b_len", "<i4"), ("gap", "<i4"), ("position", "<u4"),
                       ("sa_start", "<i4"), ("sa_end", "<i4"), ("marker", "<i4")])
 TWOGAPSEARCH = np.dtype([("blockid", "<u4"), ("gap2", "<u4"), ("c_len", "<i4"), ("position", "<u4"), ("sa_start", "<i4"), ("sa_end", "<i4")])
+LEXENT = np.dtype([("id", "<i4"), ("tstart", "<u4"), ("end", "u1"), ("gap1", "u1"), ("gap1_1", "u1"), ("gap2", "u1"), ("gap2_1", "u1"), ("kind", "u1"),
+                   ("f", "<u2"), ("fsample", "<u2"), ("paircount", "<u2"), ("pad", "<u2"), ("pad2", "<u2"), ("fe", "<f4"), ("ef", "<f4")])
 BLOCK = np.dtype([("start", "<i4"), ("end", "<i4"), ("matchlen", "<i4"), ("string_start", "<i4")])
 LEXKEY = np.dtype([("src", "<i4"), ("tgt", "<i4")])
 LEXVAL = np.dtype([("v1", "<f4"), ("v2", "<f4")])
@@ -37,7 +39,8 @@ FETCH_DTYPES = {
     "sa": np.int32, "tokstart": np.int32, "freq": np.int32, "pidx": np.uint32, "miss": np.int32, "phit_start": np.uint32,
     "phit_len": np.uint8, "lm": np.int32, "up": np.int32, "down": np.int32, "g1": GAPPY, "p1": GAPPAT, "pid1": np.uint32,
     "s1": GAPSEARCH, "hits1": HIT1, "g2": TWOGAPPY, "c2": np.int32, "pid2": np.uint32, "s2": TWOGAPSEARCH, "hits2": HIT2,
-    "r0": RULE0, "r1": RULE1, "r2": RULE2, "counts": np.uint32,
+    "r0": RULE0, "r1": RULE1, "r2": RULE2, "counts": np.uint32, "p1d": GAPPAT, "c2d": np.int32, "one2": np.uint32,
+    "lex0": LEXENT, "lex1": LEXENT, "lex2": LEXENT,
 }
 COUNT_NAMES = ["e1", "d1", "h1", "e2", "d2", "h2", "g", "n0", "n1", "n2", "sep1", "sep2a", "sep2b", "nphits", "guard_exits", "last"]
 
@@ -45,7 +48,7 @@ COUNT_NAMES = ["e1", "d1", "h1", "e2", "d2", "h2", "g", "n0", "n1", "n2", "sep1"
 ABI = [
     "cgx_create", "cgx_destroy", "cgx_last_error", "cgx_set_option", "cgx_upload_index", "cgx_build_sa", "cgx_precompute",
     "cgx_index_alloc", "cgx_index_nbuffers", "cgx_index_buffer", "cgx_index_d2d", "cgx_index_finalize", "cgx_broadcast_index",
-    "cgx_upload_queries", "cgx_sa_lookup", "cgx_gappy_search", "cgx_set_blocks", "cgx_extract", "cgx_lex_features", "cgx_fetch",
+    "cgx_upload_queries", "cgx_sa_lookup", "cgx_gappy_search", "cgx_set_blocks", "cgx_extract", "cgx_lexicon", "cgx_lex_features", "cgx_fetch",
     "cgx_stage_ms", "cgx_corpus_load", "cgx_corpus_free", "cgx_corpus_upload", "cgx_extract_grammars", "cgx_extract_grammars_ids",
     "cgx_corpus_from_ids", "cgx_host_ms",
 ]
@@ -77,7 +80,7 @@ def load_library():
     lib.cgx_last_error.restype = C.c_char_p; lib.cgx_last_error.argtypes = [C.c_void_p]
     lib.cgx_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
     lib.cgx_upload_index.argtypes = [C.c_void_p, C.POINTER(IndexHost)]
-    for f in ("cgx_build_sa", "cgx_precompute", "cgx_sa_lookup", "cgx_gappy_search", "cgx_extract", "cgx_index_finalize", "cgx_index_nbuffers"):
+    for f in ("cgx_build_sa", "cgx_precompute", "cgx_sa_lookup", "cgx_gappy_search", "cgx_extract", "cgx_lexicon", "cgx_index_finalize", "cgx_index_nbuffers"):
         getattr(lib, f).argtypes = [C.c_void_p]
     lib.cgx_index_alloc.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32]
     lib.cgx_index_buffer.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64)]
@@ -226,6 +229,9 @@ class Extractor:
 
     def extract(self):
         self._chk(self.lib.cgx_extract(self.h), "cgx_extract")
+
+    def lexicon(self):
+        self._chk(self.lib.cgx_lexicon(self.h), "cgx_lexicon")
 
     def lex_features(self, tasks, n_onegap, n_twogap):
         tasks = _c(tasks, LEXTASK)

@@ -13,6 +13,7 @@ struct cgx_ctx {
     hipStream_t stream = nullptr;
     char err[512] = {0};
     int k1_limit = 128;                 // K1 launches 128 threads per query sentence (SuffixArray.cu:1374-1378)
+    bool force_host_lexicon = false;    // test hook: take the exact host lexicon path
     uint64_t chunk_items = 1ull << 26;  // work items per count/fill chunk
     std::map<std::string, double> ms;   // stage timings
 
@@ -35,9 +36,11 @@ struct cgx_ctx {
     uint32_t e1 = 0, d1 = 0, h1 = 0, e2 = 0, d2 = 0, h2 = 0;
     cgx_gappy *d_g1 = nullptr; cgx_gappat *d_p1 = nullptr; uint32_t *d_pid1 = nullptr; cgx_gapsearch *d_s1 = nullptr; cgx_hit1 *d_hits1 = nullptr;
     cgx_twogappy *d_g2 = nullptr; int32_t *d_c2 = nullptr; uint32_t *d_pid2 = nullptr; cgx_twogapsearch *d_s2 = nullptr; cgx_hit2 *d_hits2 = nullptr;
+    cgx_gappat *d_p1d = nullptr; int32_t *d_c2d = nullptr; uint32_t *d_one2 = nullptr;   // per distinct pattern
     uint32_t g = 0; cgx_block *d_blocks = nullptr;
     uint32_t n0 = 0, n1 = 0, n2 = 0, sep1 = 0, sep2a = 0, sep2b = 0, guard_exits = 0;
     cgx_rule0 *d_r0 = nullptr; cgx_rule1 *d_r1 = nullptr; cgx_rule2 *d_r2 = nullptr;
+    cgx_lexent *d_lex0 = nullptr, *d_lex1 = nullptr, *d_lex2 = nullptr; uint32_t nl0 = 0, nl1 = 0, nl2 = 0;
 
     // ---- host-side stage timings of the whole-path driver ----
     std::map<std::string, double> host_ms;

@@ -131,7 +131,8 @@ template <class T> __global__ void k_head_flags(const T *keys, uint32_t *flags, 
 
 // stable sort of n records by the 128-bit key (hi,lo): two LSD radix passes.  On return
 // hi/lo hold the sorted keys (buffers are swapped with freshly allocated ones).
-static int sort128(cgx_ctx *ctx, uint64_t *&hi, uint64_t *&lo, size_t n, unsigned lo_bits, unsigned hi_bits) {
+static int sort128(cgx_ctx *ctx, uint64_t *&hi, uint64_t *&lo, size_t n, unsigned lo_bits, unsigned hi_bits, uint32_t **perm_out = nullptr) {
+    if (perm_out) *perm_out = nullptr;
     if (n == 0) return CGX_OK;
     uint32_t *p0 = nullptr, *p1 = nullptr; uint64_t *k1 = nullptr, *k2 = nullptr;
     TRY(dalloc(ctx, &p0, n)); TRY(dalloc(ctx, &p1, n)); TRY(dalloc(ctx, &k1, n)); TRY(dalloc(ctx, &k2, n));
@@ -141,7 +142,8 @@ static int sort128(cgx_ctx *ctx, uint64_t *&hi, uint64_t *&lo, size_t n, unsigne
     TRY(sort_pairs(ctx, k2, hi, p1, p0, n, 0, hi_bits));                    // hi = sorted hi, p0 = final permutation
     k_gather<<<nblocks(n, 256), 256, 0, ctx->stream>>>(lo, p0, k1, n);      // k1 = lo in final order
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    dfree(lo); lo = k1; dfree(k2); dfree(p0); dfree(p1);
+    dfree(lo); lo = k1; dfree(k2); dfree(p1);
+    if (perm_out) *perm_out = p0; else dfree(p0);
     return CGX_OK;
 }
 
@@ -163,8 +165,8 @@ extern "C" cgx_ctx *cgx_create(int device) {
 static void free_batch(cgx_ctx *c) {
     dfree(c->d_qoff); dfree(c->d_qtok); dfree(c->d_tok2q); dfree(c->d_lm); dfree(c->d_up); dfree(c->d_down);
     dfree(c->d_g1); dfree(c->d_p1); dfree(c->d_pid1); dfree(c->d_s1); dfree(c->d_hits1);
-    dfree(c->d_g2); dfree(c->d_c2); dfree(c->d_pid2); dfree(c->d_s2); dfree(c->d_hits2);
-    dfree(c->d_blocks); dfree(c->d_r0); dfree(c->d_r1); dfree(c->d_r2);
+    dfree(c->d_g2); dfree(c->d_c2); dfree(c->d_pid2); dfree(c->d_s2); dfree(c->d_hits2); dfree(c->d_p1d); dfree(c->d_c2d); dfree(c->d_one2);
+    dfree(c->d_blocks); dfree(c->d_r0); dfree(c->d_r1); dfree(c->d_r2); dfree(c->d_lex0); dfree(c->d_lex1); dfree(c->d_lex2); c->nl0 = c->nl1 = c->nl2 = 0;
     c->e1 = c->d1 = c->h1 = c->e2 = c->d2 = c->h2 = c->g = c->n0 = c->n1 = c->n2 = c->sep1 = c->sep2a = c->sep2b = 0;
     c->guard_exits = 0;
 }
@@ -186,6 +188,7 @@ extern "C" const char *cgx_last_error(cgx_ctx *c) { return c ? c->err : "null co
 extern "C" int cgx_set_option(cgx_ctx *c, const char *name, int64_t value) {
     if (!c || !name) return CGX_ERR_ARG;
     if (!strcmp(name, "k1_limit")) { c->k1_limit = (int)value; return CGX_OK; }
+    if (!strcmp(name, "force_host_lexicon")) { c->force_host_lexicon = value != 0; return CGX_OK; }
     if (!strcmp(name, "chunk_items")) { if (value < 1024) return CGX_ERR_ARG; c->chunk_items = (uint64_t)value; return CGX_OK; }
     snprintf(c->err, sizeof c->err, "unknown option %s", name);
     return CGX_ERR_ARG;
@@ -919,6 +922,12 @@ __global__ void k_unpack_hits2(const uint32_t *key, const uint64_t *val, uint32_
     if (i + 1 == n || key[i + 1] != id) s2[id].sa_end = (int32_t)i;
 }
 
+__global__ void k_compact1(const cgx_gapsearch *s1, const cgx_gappat *p1, uint32_t d1, cgx_gappat *out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < d1) out[i] = p1[s1[i].position];
+}
+__global__ void k_compact2(const cgx_twogapsearch *s2, const int32_t *c2, uint32_t d2, int32_t *c2d, uint32_t *one2) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < d2) { c2d[i] = c2[s2[i].position]; one2[i] = s2[i].blockid; }
+}
 extern "C" int cgx_gappy_search(cgx_ctx *ctx) {
     if (!ctx || !ctx->d_lm || !ctx->have_pre) return CGX_ERR_STATE;
     HIPCHK(hipSetDevice(ctx->device));
@@ -926,7 +935,7 @@ extern "C" int cgx_gappy_search(cgx_ctx *ctx) {
     const int32_t T = ctx->ntok; hipStream_t st = ctx->stream;
     cgx_view v{ctx->d_str, ctx->d_rlp, ctx->d_ltar, ctx->d_rtar, ctx->n};
     dfree(ctx->d_g1); dfree(ctx->d_p1); dfree(ctx->d_pid1); dfree(ctx->d_s1); dfree(ctx->d_hits1);
-    dfree(ctx->d_g2); dfree(ctx->d_c2); dfree(ctx->d_pid2); dfree(ctx->d_s2); dfree(ctx->d_hits2);
+    dfree(ctx->d_g2); dfree(ctx->d_c2); dfree(ctx->d_pid2); dfree(ctx->d_s2); dfree(ctx->d_hits2); dfree(ctx->d_p1d); dfree(ctx->d_c2d); dfree(ctx->d_one2);
     ctx->e1 = ctx->d1 = ctx->h1 = ctx->e2 = ctx->d2 = ctx->h2 = 0;
     if (T == 0) { ctx->ms["gappy"] = tm.stop(); return CGX_OK; }
 
@@ -1104,6 +1113,11 @@ extern "C" int cgx_gappy_search(cgx_ctx *ctx) {
         ctx->h2 = (uint32_t)accn;
         dfree(ak); dfree(av); dfree(c8); dfree(o32); dfree(work); dfree(woff); dfree(groups); dfree(s2c); dfree(flags); dfree(incl);
     }
+    // compact per-distinct-pattern views for the host writer
+    TRY(dalloc(ctx, &ctx->d_p1d, D1)); TRY(dalloc(ctx, &ctx->d_c2d, D2)); TRY(dalloc(ctx, &ctx->d_one2, D2));
+    if (D1) k_compact1<<<nblocks(D1, 256), 256, 0, st>>>(ctx->d_s1, ctx->d_p1, D1, ctx->d_p1d);
+    if (D2) k_compact2<<<nblocks(D2, 256), 256, 0, st>>>(ctx->d_s2, ctx->d_c2, D2, ctx->d_c2d, ctx->d_one2);
+    HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipGetLastError());
     ctx->ms["gappy"] = tm.stop();
     return CGX_OK;
@@ -1356,6 +1370,177 @@ extern "C" int cgx_lex_features(cgx_ctx *ctx, const cgx_lextask *tasks, uint32_t
 }
 
 // ------------------------------------------------------------------------------------
+// device lexicon (replaces createLexiconGappyFast / TwoGapFast / Fast, ExtractPair.c:515-1276,
+// and feeds lexicalTaskMaxEF without a host round trip).
+// Per rule array (already in canonical order): hash the target side (words, [X,1], [X,2]) ->
+// stable sort by (converted id, hash) -> each run is one lexicon line whose first rule is the
+// smallest rule index (first occurrence) and whose length is paircount -> lines re-sorted by
+// first rule index = the reference's first-occurrence order inside each id group.  Equal keys
+// are verified tuple-by-tuple; a genuine 64-bit collision is reported so that the caller can
+// take the exact host path instead.
+// ------------------------------------------------------------------------------------
+struct lexsrc {              // everything needed to name a group's source side on the device
+    const cgx_block *blocks; const cgx_gapsearch *s1; const cgx_twogapsearch *s2; const cgx_gappat *p1; const int32_t *c2;
+    const int32_t *str; const int32_t *tstr; const cgx_hit1 *hits1; const uint32_t *pidx; const int32_t *miss;
+    uint32_t G, D1, D2, sep1, sep2a, sep2b;
+};
+struct rulerec { int32_t id; uint32_t tstart; uint8_t end, g1, g1e, g2, g2e; };
+__device__ __forceinline__ rulerec load_rule(int kind, const cgx_rule0 *r0, const cgx_rule1 *r1, const cgx_rule2 *r2, uint32_t i) {
+    rulerec r; r.g1 = r.g1e = r.g2 = r.g2e = 0;
+    if (kind == 0) { cgx_rule0 x = r0[i]; r.id = x.block; r.tstart = (uint32_t)x.tar_start; r.end = x.tar_end; }
+    else if (kind == 1) { cgx_rule1 x = r1[i]; r.id = x.id; r.tstart = x.tstart; r.end = x.end; r.g1 = x.gap1; r.g1e = x.gap1_1; }
+    else { cgx_rule2 x = r2[i]; r.id = x.id; r.tstart = x.tstart; r.end = x.end; r.g1 = x.gap1; r.g1e = x.gap1_1; r.g2 = x.gap2; r.g2e = x.gap2_1; }
+    return r;
+}
+__device__ __forceinline__ uint32_t conv_id(const lexsrc &L, int kind, uint32_t i, int32_t id) {      // ExtractPair.c:724-728, 1000-1006
+    if (kind == 0) return (uint32_t)id;
+    if (kind == 1) return i < L.sep1 ? (uint32_t)id : 2 * L.G + (uint32_t)id;
+    return i < L.sep2a ? (uint32_t)id : i < L.sep2b ? L.G + (uint32_t)id : L.G + L.D2 + (uint32_t)id;
+}
+// target side as symbols: words, -1 for [X,1], -2 for [X,2] (ExtractPair.c:813-837, 1141-1163)
+__device__ __forceinline__ int target_syms(const int32_t *tstr, const rulerec &r, int kind, int32_t *out) {
+    int n = 0; uint32_t t0 = r.tstart, t1 = t0 + r.end, a = t0 + r.g1, b = t0 + r.g1e, c = t0 + r.g2, d = t0 + r.g2e;
+    for (uint32_t jj = t0; jj <= t1 && n < 32; jj++) {
+        if (kind >= 1 && jj >= a && jj <= b) { out[n++] = -1; jj = b; }
+        else if (kind >= 2 && jj >= c && jj <= d) { out[n++] = -2; jj = d; }
+        else out[n++] = tstr[jj];
+    }
+    return n;
+}
+__global__ void k_rule_hash(lexsrc L, int kind, const cgx_rule0 *r0, const cgx_rule1 *r1, const cgx_rule2 *r2, uint32_t n, uint64_t *hi, uint64_t *lo) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    rulerec r = load_rule(kind, r0, r1, r2, i);
+    int32_t sym[32]; int m = target_syms(L.tstr, r, kind, sym);
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)m;
+    for (int k = 0; k < m; k++) { h ^= (uint64_t)(uint32_t)sym[k]; h *= 0xff51afd7ed558ccdull; h ^= h >> 32; h *= 0xc4ceb9fe1a85ec53ull; h ^= h >> 29; }
+    hi[i] = conv_id(L, kind, i, r.id); lo[i] = h;
+}
+__global__ void k_lex_heads(lexsrc L, int kind, const cgx_rule0 *r0, const cgx_rule1 *r1, const cgx_rule2 *r2, const uint64_t *hi, const uint64_t *lo, const uint32_t *perm,
+                            uint32_t n, uint32_t *flags, unsigned int *collisions) {
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    bool head = j == 0 || hi[j] != hi[j - 1] || lo[j] != lo[j - 1];
+    if (!head) {                                            // same key as the previous rule: the tuples must really be equal
+        rulerec a = load_rule(kind, r0, r1, r2, perm[j]), b = load_rule(kind, r0, r1, r2, perm[j - 1]);
+        int32_t sa[32], sb[32]; int na = target_syms(L.tstr, a, kind, sa), nb = target_syms(L.tstr, b, kind, sb);
+        bool same = na == nb; for (int k = 0; same && k < na; k++) same = sa[k] == sb[k];
+        if (!same) atomicAdd(collisions, 1u);
+    }
+    flags[j] = head ? 1u : 0u;
+}
+// one record per lexicon line, keyed by its first rule index
+__global__ void k_lex_entries(const uint32_t *flags, const uint32_t *incl, const uint32_t *perm, uint32_t n, uint32_t *first_rule, uint32_t *runstart) {
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n && flags[j]) { uint32_t e = incl[j] - 1; first_rule[e] = perm[j]; runstart[e] = j; }
+}
+__device__ __forceinline__ int dev_marker_fsample(const lexsrc &L, uint32_t one) {         // ExtractPair.c:895-908
+    cgx_gapsearch s = L.s1[one]; int fs = 1 + s.sa_end - s.sa_start;
+    if (s.marker) { uint32_t pre = L.hits1[s.sa_start].str_position; fs = (int)(1 - L.pidx[2 * pre] + L.pidx[2 * pre + 1] + (uint32_t)L.miss[pre]); }
+    return fs;
+}
+__device__ __forceinline__ int dev_group_fsample(const lexsrc &L, int kind, uint32_t cid) {
+    const uint32_t G = L.G, D1 = L.D1, D2 = L.D2; int fs;
+    if (kind == 0) fs = 1 + L.blocks[cid].end - L.blocks[cid].start;
+    else if (kind == 1) { if (cid < 2 * G) { uint32_t r = cid >= G ? cid - G : cid; fs = 1 + L.blocks[r].end - L.blocks[r].start; } else fs = dev_marker_fsample(L, cid - 2 * G); }
+    else if (cid < G) fs = 1 + L.blocks[cid].end - L.blocks[cid].start;
+    else if (cid < G + D2) fs = 1 + L.s2[cid - G].sa_end - L.s2[cid - G].sa_start;
+    else fs = dev_marker_fsample(L, cid < G + D2 + D1 ? cid - G - D2 : cid - G - D2 - D1);
+    return fs > CGX_SAMPLER ? CGX_SAMPLER : fs;
+}
+__device__ __forceinline__ int dev_pattern_src(const cgx_gappat *p, int32_t *src) { int n = 0; cgx_gappat x = *p; for (int j = 0; j < x.number; j++) if (x.pat[j] >= 0) src[n++] = x.pat[j]; return n; }
+__device__ __forceinline__ int dev_block_src(const lexsrc &L, uint32_t bn, int32_t *src) { cgx_block k = L.blocks[bn]; for (int s = 0; s < k.matchlen; s++) src[s] = L.str[k.string_start + s]; return k.matchlen; }
+__device__ __forceinline__ int dev_group_src(const lexsrc &L, int kind, uint32_t cid, int32_t *src) {
+    const uint32_t G = L.G, D1 = L.D1, D2 = L.D2;
+    if (kind == 0) return dev_block_src(L, cid, src);
+    if (kind == 1) return cid < 2 * G ? dev_block_src(L, cid < G ? cid : cid - G, src) : dev_pattern_src(&L.p1[L.s1[cid - 2 * G].position], src);
+    if (cid < G) return dev_block_src(L, cid, src);
+    if (cid < G + D2) { cgx_twogapsearch t = L.s2[cid - G]; int n = dev_pattern_src(&L.p1[L.s1[t.blockid].position], src); src[n++] = L.c2[t.position]; return n; }
+    return dev_pattern_src(&L.p1[L.s1[cid < G + D2 + D1 ? cid - G - D2 : cid - G - D2 - D1].position], src);
+}
+// group size f of every rule: rules of one converted id are contiguous
+__global__ void k_cid_flags(lexsrc L, int kind, const cgx_rule0 *r0, const cgx_rule1 *r1, const cgx_rule2 *r2, uint32_t n, uint32_t *flags) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t c = conv_id(L, kind, i, load_rule(kind, r0, r1, r2, i).id);
+    flags[i] = (i == 0 || c != conv_id(L, kind, i - 1, load_rule(kind, r0, r1, r2, i - 1).id)) ? 1u : 0u;
+}
+__global__ void k_group_starts(const uint32_t *flags, const uint32_t *incl, uint32_t n, uint32_t *gstart) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && flags[i]) gstart[incl[i] - 1] = i;
+}
+// final pass: one lane per lexicon line (in first-occurrence order): fill the wire record and run MaxLex
+__global__ void k_lex_finish(lexsrc L, cgx_lexview T, int kind, const cgx_rule0 *r0, const cgx_rule1 *r1, const cgx_rule2 *r2, uint32_t nrules,
+                             const uint32_t *first_rule_sorted, const uint32_t *entry_of_sorted, const uint32_t *runstart, uint32_t nent, uint32_t nruns_total,
+                             const uint32_t *gidx_incl, const uint32_t *gstart, uint32_t ngroups, cgx_lexent *out) {
+    uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nent) return;
+    uint32_t rule = first_rule_sorted[e], orig = entry_of_sorted[e];
+    uint32_t rs = runstart[orig], re = orig + 1 < nruns_total ? runstart[orig + 1] : nrules;      // run [rs,re) in (id,hash) order
+    rulerec r = load_rule(kind, r0, r1, r2, rule);
+    uint32_t cid = conv_id(L, kind, rule, r.id);
+    uint32_t g = gidx_incl[rule] - 1; uint32_t gs = gstart[g], ge = g + 1 < ngroups ? gstart[g + 1] : nrules;
+    cgx_lexent o;
+    o.id = (int32_t)cid; o.tstart = r.tstart; o.end = r.end; o.gap1 = r.g1; o.gap1_1 = r.g1e; o.gap2 = r.g2; o.gap2_1 = r.g2e; o.kind = (uint8_t)kind;
+    o.f = (uint16_t)(ge - gs); o.fsample = (uint16_t)dev_group_fsample(L, kind, cid); o.paircount = (uint16_t)(re - rs);
+    int32_t src[8]; int nsrc = dev_group_src(L, kind, cid, src);
+    float fe, ef;
+    cgx_maxlex(T, L.tstr, src, nsrc, r.tstart, r.end, r.g1, r.g1e, r.g2, r.g2e, kind == 1 ? 0 : kind == 2 ? 1 : 2, &fe, &ef);
+    o.fe = fe; o.ef = ef;
+    out[e] = o;
+}
+
+static int lexicon_kind(cgx_ctx *ctx, const lexsrc &L, const cgx_lexview &T, int kind, uint32_t n, uint32_t nid, cgx_lexent **out, uint32_t *nout) {
+    hipStream_t st = ctx->stream;
+    *out = nullptr; *nout = 0;
+    TRY(dalloc(ctx, out, 1));
+    if (n == 0) return CGX_OK;
+    uint64_t *hi = nullptr, *lo = nullptr; uint32_t *perm = nullptr, *flags = nullptr, *incl = nullptr; unsigned int *coll = nullptr;
+    TRY(dalloc(ctx, &hi, n)); TRY(dalloc(ctx, &lo, n)); TRY(dalloc(ctx, &flags, n)); TRY(dalloc(ctx, &incl, n)); TRY(dalloc(ctx, &coll, 1));
+    HIPCHK(hipMemsetAsync(coll, 0, 4, st));
+    k_rule_hash<<<nblocks(n, 256), 256, 0, st>>>(L, kind, ctx->d_r0, ctx->d_r1, ctx->d_r2, n, hi, lo);
+    TRY(sort128(ctx, hi, lo, n, 64, (unsigned)bits_for(nid), &perm));
+    k_lex_heads<<<nblocks(n, 256), 256, 0, st>>>(L, kind, ctx->d_r0, ctx->d_r1, ctx->d_r2, hi, lo, perm, n, flags, coll);
+    TRY(incl_scan(ctx, flags, incl, n));
+    uint32_t nent = 0; TRY(d2h(ctx, &nent, incl + (n - 1), 1));
+    unsigned int nc = 0; TRY(d2h(ctx, &nc, coll, 1));
+    if (nc) { snprintf(ctx->err, sizeof ctx->err, "target-side hash collision in the device lexicon (%u)", nc); return CGX_ERR_STATE; }
+    uint32_t *first = nullptr, *runstart = nullptr, *sfirst = nullptr, *eid = nullptr, *seid = nullptr;
+    TRY(dalloc(ctx, &first, nent)); TRY(dalloc(ctx, &runstart, nent)); TRY(dalloc(ctx, &sfirst, nent)); TRY(dalloc(ctx, &eid, nent)); TRY(dalloc(ctx, &seid, nent));
+    k_lex_entries<<<nblocks(n, 256), 256, 0, st>>>(flags, incl, perm, n, first, runstart);
+    k_iota<<<nblocks(nent, 256), 256, 0, st>>>(eid, nent);
+    TRY(sort_pairs(ctx, first, sfirst, eid, seid, nent, 0, (unsigned)bits_for(n)));             // lines in first-occurrence order
+    // group sizes
+    uint32_t *gflags = flags, *gincl = incl;                                                   // reuse
+    k_cid_flags<<<nblocks(n, 256), 256, 0, st>>>(L, kind, ctx->d_r0, ctx->d_r1, ctx->d_r2, n, gflags);
+    TRY(incl_scan(ctx, gflags, gincl, n));
+    uint32_t ng = 0; TRY(d2h(ctx, &ng, gincl + (n - 1), 1));
+    uint32_t *gstart = nullptr; TRY(dalloc(ctx, &gstart, ng));
+    k_group_starts<<<nblocks(n, 256), 256, 0, st>>>(gflags, gincl, n, gstart);
+    dfree(*out); TRY(dalloc(ctx, out, nent));
+    k_lex_finish<<<nblocks(nent, 128), 128, 0, st>>>(L, T, kind, ctx->d_r0, ctx->d_r1, ctx->d_r2, n, sfirst, seid, runstart, nent, nent, gincl, gstart, ng, *out);
+    HIPCHK(hipStreamSynchronize(st)); HIPCHK(hipGetLastError());
+    *nout = nent;
+    dfree(hi); dfree(lo); dfree(perm); dfree(flags); dfree(incl); dfree(coll); dfree(first); dfree(runstart); dfree(sfirst); dfree(eid); dfree(seid); dfree(gstart);
+    return CGX_OK;
+}
+extern "C" int cgx_lexicon(cgx_ctx *ctx) {
+    if (!ctx || !ctx->d_blocks || !ctx->d_r0 || !ctx->d_lexkey) return CGX_ERR_STATE;
+    HIPCHK(hipSetDevice(ctx->device));
+    if (ctx->force_host_lexicon) { snprintf(ctx->err, sizeof ctx->err, "target-side hash collision in the device lexicon (forced by option)"); return CGX_ERR_STATE; }
+    Timer tm(ctx->stream);
+    dfree(ctx->d_lex0); dfree(ctx->d_lex1); dfree(ctx->d_lex2); ctx->nl0 = ctx->nl1 = ctx->nl2 = 0;
+    lexsrc L{ctx->d_blocks, ctx->d_s1, ctx->d_s2, ctx->d_p1, ctx->d_c2, ctx->d_str, ctx->d_tstr, ctx->d_hits1, ctx->d_pidx, ctx->d_miss,
+             ctx->g, ctx->d1, ctx->d2, ctx->sep1, ctx->sep2a, ctx->sep2b};
+    cgx_lexview T{ctx->d_lexkey, ctx->d_lexv1, ctx->d_lexv2, ctx->d_lexn1, ctx->d_lexn2, ctx->nlex};
+    TRY(lexicon_kind(ctx, L, T, 1, ctx->n1, 2 * ctx->g + ctx->d1, &ctx->d_lex1, &ctx->nl1));
+    TRY(lexicon_kind(ctx, L, T, 2, ctx->n2, ctx->g + 2 * ctx->d1 + ctx->d2, &ctx->d_lex2, &ctx->nl2));
+    TRY(lexicon_kind(ctx, L, T, 0, ctx->n0, ctx->g, &ctx->d_lex0, &ctx->nl0));
+    ctx->ms["lexicon"] = tm.stop();
+    return CGX_OK;
+}
+
+// ------------------------------------------------------------------------------------
 // result fetch
 // ------------------------------------------------------------------------------------
 extern "C" int64_t cgx_fetch(cgx_ctx *ctx, const char *name, void *dst, int64_t cap) {
@@ -1374,6 +1559,8 @@ extern "C" int64_t cgx_fetch(cgx_ctx *ctx, const char *name, void *dst, int64_t 
     ENT("s1", ctx->d_s1, ctx->d1, cgx_gapsearch) ENT("hits1", ctx->d_hits1, ctx->h1, cgx_hit1)
     ENT("g2", ctx->d_g2, ctx->e2, cgx_twogappy) ENT("c2", ctx->d_c2, ctx->e2, int32_t) ENT("pid2", ctx->d_pid2, ctx->e2, uint32_t)
     ENT("s2", ctx->d_s2, ctx->d2, cgx_twogapsearch) ENT("hits2", ctx->d_hits2, ctx->h2, cgx_hit2)
+    ENT("p1d", ctx->d_p1d, ctx->d1, cgx_gappat) ENT("c2d", ctx->d_c2d, ctx->d2, int32_t) ENT("one2", ctx->d_one2, ctx->d2, uint32_t)
+    ENT("lex0", ctx->d_lex0, ctx->nl0, cgx_lexent) ENT("lex1", ctx->d_lex1, ctx->nl1, cgx_lexent) ENT("lex2", ctx->d_lex2, ctx->nl2, cgx_lexent)
     ENT("r0", ctx->d_r0, ctx->n0, cgx_rule0) ENT("r1", ctx->d_r1, ctx->n1, cgx_rule1) ENT("r2", ctx->d_r2, ctx->n2, cgx_rule2)
 #undef ENT
     if (s == "counts") { bytes = sizeof counts; if (!dst) return bytes; if (cap < bytes) return CGX_ERR_ARG; memcpy(dst, counts, sizeof counts); return bytes; }

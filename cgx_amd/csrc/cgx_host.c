@@ -283,7 +283,9 @@ typedef struct {
     uint32_t n0, n1, n2, sep1, sep2a, sep2b;
     cgx_rule0 *r0; cgx_rule1 *r1; cgx_rule2 *r2;
     uint32_t *pidx; int32_t *miss;
-    lexent *lex0, *lex1, *lex2; uint32_t nl0, nl1, nl2;
+    lexent *lex0, *lex1, *lex2; uint32_t nl0, nl1, nl2;       /* exact host path only (hash-collision fallback) */
+    cgx_lexent *L0, *L1, *L2;                                 /* lexicon lines as produced on the device */
+    cgx_gappat *p1d; int32_t *c2d; uint32_t *one2;            /* per distinct pattern: symbols of aXb, token c and one-gap id of aXbXc */
     range *rng0, *rng1, *rng2;
     cgx_lextask *tasks; uint32_t ntask;
 } batch;
@@ -293,7 +295,7 @@ static void batch_free(batch *b) {
     for (int32_t q = 0; q < b->nq; q++) { if (b->qblocks) free(b->qblocks[q].v); if (b->qone) free(b->qone[q].v); if (b->qtwo) free(b->qtwo[q].v); }
     free(b->qblocks); free(b->qone); free(b->qtwo); free(b->p1); free(b->s1); free(b->s2); free(b->c2); free(b->hits1);
     free(b->r0); free(b->r1); free(b->r2); free(b->pidx); free(b->miss); free(b->lex0); free(b->lex1); free(b->lex2);
-    free(b->rng0); free(b->rng1); free(b->rng2); free(b->tasks);
+    free(b->rng0); free(b->rng1); free(b->rng2); free(b->tasks); free(b->L0); free(b->L1); free(b->L2); free(b->p1d); free(b->c2d); free(b->one2);
 }
 
 static int fetch_alloc(cgx_ctx *ctx, const char *name, void **out, size_t elem, uint32_t *count) {
@@ -405,9 +407,19 @@ static void scores(lexent *l, uint32_t n) {
         l[i].fscore = (float)log10((double)(1 + l[i].fsample));
     }
 }
+static const cgx_gappat *pat_of(const batch *b, uint32_t one) { return b->p1d ? &b->p1d[one] : &b->p1[b->s1[one].position]; }
+static int32_t c_of(const batch *b, uint32_t two) { return b->c2d ? b->c2d[two] : b->c2[b->s2[two].position]; }
+static uint32_t one_of(const batch *b, uint32_t two) { return b->one2 ? b->one2[two] : b->s2[two].blockid; }
 static int pattern_src(const cgx_gappat *p, int32_t *src) { int n = 0; for (int j = 0; j < p->number; j++) if (p->pat[j] >= 0) src[n++] = p->pat[j]; return n; }
 static int block_src(const batch *b, uint32_t bn, int32_t *src) { const cgx_block *k = &b->blocks[bn]; for (int s = 0; s < k->matchlen; s++) src[s] = b->c->str[k->string_start + s]; return k->matchlen; }
 
+static range *make_ranges_dev(const cgx_lexent *l, uint32_t nl, uint32_t nid) {
+    range *r = malloc(((size_t)nid + 1) * sizeof *r);
+    if (!r) return NULL;
+    for (uint32_t i = 0; i < nid; i++) r[i].down = r[i].up = -1;
+    for (uint32_t i = 0; i < nl; i++) { if (i == 0 || l[i].id != l[i - 1].id) r[l[i].id].down = (int32_t)i; r[l[i].id].up = (int32_t)i; }
+    return r;
+}
 static range *make_ranges(const lexent *l, uint32_t nl, uint32_t nid) {
     range *r = malloc(((size_t)nid + 1) * sizeof *r);
     if (!r) return NULL;
@@ -427,10 +439,10 @@ static uint32_t rule_cid(const batch *b, int kind, uint32_t i) {
 static int group_src(const batch *b, int kind, uint32_t cid, int32_t *src) {
     const uint32_t G = b->g, D1 = b->d1, D2 = b->d2;
     if (kind == 0) return block_src(b, cid, src);
-    if (kind == 1) return cid < 2 * G ? block_src(b, cid < G ? cid : cid - G, src) : pattern_src(&b->p1[b->s1[cid - 2 * G].position], src);
+    if (kind == 1) return cid < 2 * G ? block_src(b, cid < G ? cid : cid - G, src) : pattern_src(pat_of(b, cid - 2 * G), src);
     if (cid < G) return block_src(b, cid, src);
-    if (cid < G + D2) { const cgx_twogapsearch *t = &b->s2[cid - G]; int n = pattern_src(&b->p1[b->s1[t->blockid].position], src); src[n++] = b->c2[t->position]; return n; }
-    return pattern_src(&b->p1[b->s1[cid < G + D2 + D1 ? cid - G - D2 : cid - G - D2 - D1].position], src);
+    if (cid < G + D2) { int n = pattern_src(pat_of(b, one_of(b, cid - G)), src); src[n++] = c_of(b, cid - G); return n; }
+    return pattern_src(pat_of(b, cid < G + D2 + D1 ? cid - G - D2 : cid - G - D2 - D1), src);
 }
 static int group_fsample(const batch *b, int kind, uint32_t cid) {
     const uint32_t G = b->g, D1 = b->d1, D2 = b->d2; int fs;
@@ -544,7 +556,7 @@ static int sb_block(sbuf *s, const batch *b, uint32_t bn) {
     return 0;
 }
 static int sb_pattern(sbuf *s, const batch *b, uint32_t one, const char *gap, int lead_space) {
-    const cgx_gappat *p = &b->p1[b->s1[one].position];
+    const cgx_gappat *p = pat_of(b, one);
     for (int j = 0; j < p->number; j++) {
         if ((j || lead_space) && sb_puts(s, " ")) return -1;
         if (p->pat[j] >= 0) { if (sb_word(s, b->c, 0, p->pat[j])) return -1; } else if (sb_puts(s, gap)) return -1;
@@ -562,20 +574,27 @@ static int sb_source(sbuf *s, const batch *b, int kind, uint32_t cid) {
     }
     if (cid < G) return sb_puts(s, "[X,1] ") || sb_block(s, b, cid) || sb_puts(s, " [X,2]");
     if (cid < G + D2) {
-        const cgx_twogapsearch *t = &b->s2[cid - G];
-        return sb_pattern(s, b, t->blockid, "[X,1]", 0) || sb_puts(s, " [X,2] ") || sb_word(s, b->c, 0, b->c2[t->position]);
+        return sb_pattern(s, b, one_of(b, cid - G), "[X,1]", 0) || sb_puts(s, " [X,2] ") || sb_word(s, b->c, 0, c_of(b, cid - G));
     }
     if (cid < G + D2 + D1) return sb_puts(s, "[X,1]") || sb_pattern(s, b, cid - G - D2, "[X,2]", 1);
     return sb_pattern(s, b, cid - G - D2 - D1, "[X,1]", 0) || sb_puts(s, " [X,2]");
 }
-static int sb_target(sbuf *s, const batch *b, int kind, uint32_t rule) {
-    int32_t sym[48]; int n = rule_symbols(b, kind, rule, sym);
+static int sb_target(sbuf *s, const batch *b, const cgx_lexent *e) {
+    int32_t sym[48]; int n = target_symbols(b->c, e->tstart, e->end, e->gap1, e->gap1_1, e->gap2, e->gap2_1, e->kind, sym);
     for (int i = 0; i < n; i++) {
         if (i && sb_puts(s, " ")) return -1;
         if (sym[i] == -1) { if (sb_puts(s, "[X,1]")) return -1; } else if (sym[i] == -2) { if (sb_puts(s, "[X,2]")) return -1; }
         else if (sb_word(s, b->c, 1, sym[i])) return -1;
     }
     return 0;
+}
+/* feature values depend only on (paircount, fsample) <= 300 each (ExtractPair.c:652-656): tabulated once with the host libm */
+#define TABN 302
+static float g_aa[TABN][TABN], g_bb[TABN], g_fs[TABN]; static int g_tab_ready;
+static void score_tables(void) {
+    if (g_tab_ready) return;
+    for (int p = 0; p < TABN; p++) { g_bb[p] = (float)log10((double)(1 + p)); g_fs[p] = (float)log10((double)(1 + p)); for (int f = 1; f < TABN; f++) g_aa[p][f] = -log10f((float)p / (float)f); }
+    g_tab_ready = 1;
 }
 /* "%f" of a float: the value times 10^6 is exact in double (24 + 14 significant bits), so
  * rounding it to nearest-even is exactly what printf does; odd cases fall back to snprintf. */
@@ -593,12 +612,15 @@ static int sb_f6(sbuf *s, float x) {
     p += 6; s->n = (size_t)(p - s->p);
     return 0;
 }
-static int emit_range(sbuf *s, const batch *b, int kind, const lexent *lex, const range *rng, uint32_t id, uint64_t *lines) {
+static int emit_range(sbuf *s, const batch *b, int kind, const cgx_lexent *lex, const range *rng, uint32_t id, uint64_t *lines) {
     if (rng[id].down == -1 || rng[id].up == -1) return 0;
     for (int32_t i = rng[id].down; i <= rng[id].up; i++) {
-        const lexent *e = &lex[i];
-        if (sb_puts(s, "[X] ||| ") || sb_source(s, b, kind, (uint32_t)e->id) || sb_puts(s, " ||| ") || sb_target(s, b, kind, e->rule)) return -1;
-        if (sb_puts(s, " ||| EgivenFCoherent=") || sb_f6(s, e->aa) || sb_puts(s, " SampleCountF=") || sb_f6(s, e->fscore) || sb_puts(s, " CountEF=") || sb_f6(s, e->bb) ||
+        const cgx_lexent *e = &lex[i];
+        int p = e->paircount < TABN ? e->paircount : TABN - 1, f = e->fsample < TABN ? e->fsample : TABN - 1;
+        float aa = (e->paircount < TABN && e->fsample < TABN && e->fsample > 0) ? g_aa[p][f] : -log10f((float)e->paircount / (float)e->fsample);
+        float bb = e->paircount < TABN ? g_bb[p] : (float)log10((double)(1 + e->paircount)), fsc = e->fsample < TABN ? g_fs[f] : (float)log10((double)(1 + e->fsample));
+        if (sb_puts(s, "[X] ||| ") || sb_source(s, b, kind, (uint32_t)e->id) || sb_puts(s, " ||| ") || sb_target(s, b, e)) return -1;
+        if (sb_puts(s, " ||| EgivenFCoherent=") || sb_f6(s, aa) || sb_puts(s, " SampleCountF=") || sb_f6(s, fsc) || sb_puts(s, " CountEF=") || sb_f6(s, bb) ||
             sb_puts(s, " MaxLexFgivenE=") || sb_f6(s, e->fe) || sb_puts(s, " MaxLexEgivenF=") || sb_f6(s, e->ef) ||
             sb_puts(s, e->f == 1 ? " IsSingletonF=1" : " IsSingletonF=0") || sb_puts(s, e->paircount == 1 ? " IsSingletonFE=1\n" : " IsSingletonFE=0\n")) return -1;
         (*lines)++;
@@ -617,15 +639,15 @@ static void *write_worker(void *arg) {
         s.n = 0; int bad = 0;
         for (uint32_t k = 0; !bad && k < b->qblocks[q].n; k++) {
             uint32_t p = b->qblocks[q].v[k];
-            bad = emit_range(&s, b, 1, b->lex1, b->rng1, p + G, lines) || emit_range(&s, b, 1, b->lex1, b->rng1, p, lines) ||
-                  emit_range(&s, b, 2, b->lex2, b->rng2, p, lines) || emit_range(&s, b, 0, b->lex0, b->rng0, p, lines);
+            bad = emit_range(&s, b, 1, b->L1, b->rng1, p + G, lines) || emit_range(&s, b, 1, b->L1, b->rng1, p, lines) ||
+                  emit_range(&s, b, 2, b->L2, b->rng2, p, lines) || emit_range(&s, b, 0, b->L0, b->rng0, p, lines);
         }
         for (uint32_t k = 0; !bad && b->qone && k < b->qone[q].n; k++) {
             uint32_t id = b->qone[q].v[k];
-            bad = emit_range(&s, b, 1, b->lex1, b->rng1, 2 * G + id, lines) || emit_range(&s, b, 2, b->lex2, b->rng2, G + D2 + id, lines) ||
-                  emit_range(&s, b, 2, b->lex2, b->rng2, G + D2 + D1 + id, lines);
+            bad = emit_range(&s, b, 1, b->L1, b->rng1, 2 * G + id, lines) || emit_range(&s, b, 2, b->L2, b->rng2, G + D2 + id, lines) ||
+                  emit_range(&s, b, 2, b->L2, b->rng2, G + D2 + D1 + id, lines);
         }
-        for (uint32_t k = 0; !bad && b->qtwo && k < b->qtwo[q].n; k++) bad = emit_range(&s, b, 2, b->lex2, b->rng2, G + b->qtwo[q].v[k], lines);
+        for (uint32_t k = 0; !bad && b->qtwo && k < b->qtwo[q].n; k++) bad = emit_range(&s, b, 2, b->L2, b->rng2, G + b->qtwo[q].v[k], lines);
         if (bad) { w->rc = CGX_ERR_NOMEM; break; }
         snprintf(fn, sizeof fn, "%s/grammar.%d.s", w->outdir, w->first + q);
         FILE *fp = fopen(fn, "w");
@@ -663,18 +685,18 @@ static int run_batch(cgx_ctx *ctx, const cgx_corpus *c, batch *b, const char *ou
     if ((rc = cgx_set_blocks(ctx, b->blocks, b->g)) != CGX_OK) return rc;   /* also fills string_start = sa[start] (ExtractPair.cu:2798) */
     if ((rc = cgx_gappy_search(ctx)) != CGX_OK) return rc;
     if ((rc = cgx_extract(ctx)) != CGX_OK) return rc;
+    /* lexicon + MaxLex features on the device (host path only if a target-side hash collides) */
+    int exact_host = 0;
+    rc = cgx_lexicon(ctx);
+    if (rc == CGX_ERR_STATE && strstr(cgx_last_error(ctx), "hash collision")) exact_host = 1; else if (rc != CGX_OK) return rc;
     /* device results needed by the host stages */
     uint32_t *pid1 = NULL, *pid2 = NULL; cgx_gappy *g1 = NULL; cgx_twogappy *g2 = NULL; uint32_t counts[16];
     if (cgx_fetch(ctx, "counts", counts, sizeof counts) < 0) return CGX_ERR_HIP;
-    b->sep1 = counts[10]; b->sep2a = counts[11]; b->sep2b = counts[12];
+    b->d1 = counts[1]; b->d2 = counts[4]; b->sep1 = counts[10]; b->sep2a = counts[11]; b->sep2b = counts[12];
     if ((rc = fetch_alloc(ctx, "pid1", (void **)&pid1, 4, &b->e1)) || (rc = fetch_alloc(ctx, "g1", (void **)&g1, sizeof *g1, NULL)) ||
-        (rc = fetch_alloc(ctx, "p1", (void **)&b->p1, sizeof *b->p1, NULL)) || (rc = fetch_alloc(ctx, "s1", (void **)&b->s1, sizeof *b->s1, &b->d1)) ||
-        (rc = fetch_alloc(ctx, "hits1", (void **)&b->hits1, sizeof *b->hits1, &b->h1)) ||
         (rc = fetch_alloc(ctx, "pid2", (void **)&pid2, 4, &b->e2)) || (rc = fetch_alloc(ctx, "g2", (void **)&g2, sizeof *g2, NULL)) ||
-        (rc = fetch_alloc(ctx, "c2", (void **)&b->c2, 4, NULL)) || (rc = fetch_alloc(ctx, "s2", (void **)&b->s2, sizeof *b->s2, &b->d2)) ||
-        (rc = fetch_alloc(ctx, "r0", (void **)&b->r0, sizeof *b->r0, &b->n0)) || (rc = fetch_alloc(ctx, "r1", (void **)&b->r1, sizeof *b->r1, &b->n1)) ||
-        (rc = fetch_alloc(ctx, "r2", (void **)&b->r2, sizeof *b->r2, &b->n2)) ||
-        (rc = fetch_alloc(ctx, "pidx", (void **)&b->pidx, 4, NULL)) || (rc = fetch_alloc(ctx, "miss", (void **)&b->miss, 4, NULL))) return rc;
+        (rc = fetch_alloc(ctx, "p1d", (void **)&b->p1d, sizeof *b->p1d, NULL)) || (rc = fetch_alloc(ctx, "c2d", (void **)&b->c2d, 4, NULL)) ||
+        (rc = fetch_alloc(ctx, "one2", (void **)&b->one2, 4, NULL))) return rc;
     t = now_ms();
     {   /* per-query pattern lists */
         int32_t *tok2q = malloc(((size_t)b->ntok + 1) * 4), *pos1 = malloc(((size_t)b->e1 + 1) * 4), *pos2 = malloc(((size_t)b->e2 + 1) * 4);
@@ -688,18 +710,40 @@ static int run_batch(cgx_ctx *ctx, const cgx_corpus *c, batch *b, const char *ou
     free(pid1); free(pid2); free(g1); free(g2);
     cgx__set_host_ms(ctx, "lists", now_ms() - t);
     t = now_ms();
-    if ((rc = build_lexicons(b)) != CGX_OK) return rc;
-    cgx__set_host_ms(ctx, "lexicon", now_ms() - t);
-    {   /* MaxLex features on the device, scattered back (ExtractPair.cu:3965-3982) */
+    score_tables();
+    uint32_t nl0 = 0, nl1 = 0, nl2 = 0;
+    if (!exact_host) {
+        if ((rc = fetch_alloc(ctx, "lex1", (void **)&b->L1, sizeof *b->L1, &nl1)) || (rc = fetch_alloc(ctx, "lex2", (void **)&b->L2, sizeof *b->L2, &nl2)) ||
+            (rc = fetch_alloc(ctx, "lex0", (void **)&b->L0, sizeof *b->L0, &nl0))) return rc;
+    } else {
+        /* exact host lexicon (ExtractPair.c:515-1276 restated on integer tuples) + MaxLex through the task ABI */
+        if ((rc = fetch_alloc(ctx, "p1", (void **)&b->p1, sizeof *b->p1, NULL)) || (rc = fetch_alloc(ctx, "s1", (void **)&b->s1, sizeof *b->s1, NULL)) ||
+            (rc = fetch_alloc(ctx, "hits1", (void **)&b->hits1, sizeof *b->hits1, &b->h1)) || (rc = fetch_alloc(ctx, "c2", (void **)&b->c2, 4, NULL)) ||
+            (rc = fetch_alloc(ctx, "s2", (void **)&b->s2, sizeof *b->s2, NULL)) ||
+            (rc = fetch_alloc(ctx, "r0", (void **)&b->r0, sizeof *b->r0, &b->n0)) || (rc = fetch_alloc(ctx, "r1", (void **)&b->r1, sizeof *b->r1, &b->n1)) ||
+            (rc = fetch_alloc(ctx, "r2", (void **)&b->r2, sizeof *b->r2, &b->n2)) ||
+            (rc = fetch_alloc(ctx, "pidx", (void **)&b->pidx, 4, NULL)) || (rc = fetch_alloc(ctx, "miss", (void **)&b->miss, 4, NULL))) return rc;
+        if ((rc = build_lexicons(b)) != CGX_OK) return rc;
         float *fe = malloc(((size_t)b->ntask + 1) * 4), *ef = malloc(((size_t)b->ntask + 1) * 4);
         if (!fe || !ef) return CGX_ERR_NOMEM;
         if ((rc = cgx_lex_features(ctx, b->tasks, b->ntask, b->nl1, b->nl2, fe, ef)) != CGX_OK) return rc;
+        nl0 = b->nl0; nl1 = b->nl1; nl2 = b->nl2;
+        b->L0 = calloc((size_t)nl0 + 1, sizeof *b->L0); b->L1 = calloc((size_t)nl1 + 1, sizeof *b->L1); b->L2 = calloc((size_t)nl2 + 1, sizeof *b->L2);
+        if (!b->L0 || !b->L1 || !b->L2) return CGX_ERR_NOMEM;
         for (uint32_t i = 0; i < b->ntask; i++) {
-            lexent *e = i < b->nl1 ? &b->lex1[b->tasks[i].lexid] : i < b->nl1 + b->nl2 ? &b->lex2[b->tasks[i].lexid] : &b->lex0[b->tasks[i].lexid];
-            e->fe = fe[i]; e->ef = ef[i];
+            int kind = i < nl1 ? 1 : i < nl1 + nl2 ? 2 : 0; uint32_t k = b->tasks[i].lexid;
+            const lexent *e = kind == 1 ? &b->lex1[k] : kind == 2 ? &b->lex2[k] : &b->lex0[k];
+            cgx_lexent *o = kind == 1 ? &b->L1[k] : kind == 2 ? &b->L2[k] : &b->L0[k];
+            o->id = e->id; o->kind = (uint8_t)kind; o->f = (uint16_t)e->f; o->fsample = (uint16_t)e->fsample; o->paircount = (uint16_t)e->paircount; o->fe = fe[i]; o->ef = ef[i];
+            o->tstart = b->tasks[i].tstart; o->end = b->tasks[i].end; o->gap1 = b->tasks[i].gap1; o->gap1_1 = b->tasks[i].gap1_1; o->gap2 = b->tasks[i].gap2; o->gap2_1 = b->tasks[i].gap2_1;
         }
         free(fe); free(ef);
     }
+    b->nl0 = nl0; b->nl1 = nl1; b->nl2 = nl2;
+    free(b->rng0); free(b->rng1); free(b->rng2);
+    b->rng1 = make_ranges_dev(b->L1, nl1, 2 * b->g + b->d1); b->rng2 = make_ranges_dev(b->L2, nl2, b->g + 2 * b->d1 + b->d2); b->rng0 = make_ranges_dev(b->L0, nl0, b->g);
+    if (!b->rng0 || !b->rng1 || !b->rng2) return CGX_ERR_NOMEM;
+    cgx__set_host_ms(ctx, "lexicon", now_ms() - t);
     uint64_t lines = 0;
     t = now_ms();
     if (outdir) {

@@ -46,6 +46,9 @@ typedef struct { int32_t tar_start; int32_t block; uint8_t tar_end; } cgx_rule0;
 typedef struct { uint32_t lexid; int32_t src[5]; uint8_t nsrc; uint32_t tstart;
                  uint8_t end, gap1, gap1_1, gap2, gap2_1; } cgx_lextask;              /* MaxLex work item            (:376)           */
 #pragma pack(pop)
+/* one lexicon line (red_dup_t, ComTypes.h:244) as produced on the device: converted id, the first rule's target span and gaps,
+ * group size f, sample base, pair count and the two MaxLex features; kind 0 contiguous, 1 one gap, 2 two gaps */
+typedef struct { int32_t id; uint32_t tstart; uint8_t end, gap1, gap1_1, gap2, gap2_1, kind; uint16_t f, fsample, paircount; uint16_t pad; float fe, ef; } cgx_lexent;
 typedef struct { int32_t qrystart; int32_t a_len, b_len, gap; uint32_t position; int32_t sa_start, sa_end; int32_t marker; } cgx_gapsearch; /* distinct aXb   (:168) */
 typedef struct { uint32_t blockid, gap2; int32_t c_len; uint32_t position; int32_t sa_start, sa_end; } cgx_twogapsearch;                  /* distinct aXbXc (:158) */
 typedef struct { int32_t start, end, matchlen, string_start; } cgx_block;            /* distinct contiguous phrase (saind_t, :342)    */
@@ -70,7 +73,7 @@ typedef struct {
 cgx_ctx *cgx_create(int device);                       /* replaces suffixArraySearchInit (SuffixArray.cu:769) */
 void cgx_destroy(cgx_ctx *ctx);                        /* replaces suffixArraySearchFinalize*, extractPairFinalize */
 const char *cgx_last_error(cgx_ctx *ctx);
-int cgx_set_option(cgx_ctx *ctx, const char *name, int64_t value); /* "k1_limit" (default 128), "chunk_items" */
+int cgx_set_option(cgx_ctx *ctx, const char *name, int64_t value); /* "k1_limit" (default 128), "chunk_items", "force_host_lexicon" */
 
 /* ---- index: upload, device suffix-array construction, frequent-pair precomputation ---- */
 int cgx_upload_index(cgx_ctx *ctx, const cgx_index_host *ix);   /* H2D of the index (SuffixArray.cu:1396-1412, ExtractPair.cu:3279-3282) */
@@ -92,13 +95,14 @@ int cgx_sa_lookup(cgx_ctx *ctx);        /* K1 + K2: SuffixArray.cu:402-767, 109-
 int cgx_gappy_search(cgx_ctx *ctx);     /* enumeration, sorts, lookups: SuffixArray.cu:1530-2256, GappyLook.cu:128-737 */
 int cgx_set_blocks(cgx_ctx *ctx, cgx_block *blocks, uint32_t g);   /* distinct contiguous phrases (GenerateBlocks, ExtractPair.cu:2742-2903); fills blocks[i].string_start = sa[start] */
 int cgx_extract(cgx_ctx *ctx);          /* three extraction launches + sorts: ExtractPair.cu:3336-3670 */
+int cgx_lexicon(cgx_ctx *ctx);          /* device lexicon + MaxLex: createLexicon*Fast (ExtractPair.c:515-1276) + lexicalTaskMaxEF; results "lex1" "lex2" "lex0" */
 int cgx_lex_features(cgx_ctx *ctx, const cgx_lextask *tasks, uint32_t ntask, uint32_t n_onegap, uint32_t n_twogap,
                      float *max_fe, float *max_ef);             /* lexicalTaskMaxEF: ExtractPair.cu:2144-2432 */
 
 /* ---- results: copy a named device/host result into caller memory.
  * dst == NULL returns the size in bytes; otherwise returns bytes written, or < 0. Names:
  *   "sa" "tokstart" "freq" "pidx" "miss" "phit_start" "phit_len"
- *   "lm" "up" "down" "g1" "p1" "pid1" "s1" "hits1" "g2" "c2" "pid2" "s2" "hits2" "r0" "r1" "r2" "counts" */
+ *   "lm" "up" "down" "g1" "p1" "pid1" "s1" "hits1" "g2" "c2" "pid2" "s2" "hits2" "r0" "r1" "r2" "p1d" "c2d" "one2" "lex0" "lex1" "lex2" "counts" */
 int64_t cgx_fetch(cgx_ctx *ctx, const char *name, void *dst, int64_t cap);
 /* last-stage timings in milliseconds (hipEvent): "sa_lookup" "gappy" "extract" "lex" "build_sa" "precompute";
  * "sa_lookup_kernel" is the batched interval-search kernel alone */

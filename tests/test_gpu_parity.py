@@ -96,7 +96,29 @@ def test_every_stage_matches_the_oracle(name, cgx, oracle_bin, fixtures_dir, tmp
     fe, ef = ex.lex_features(d["tasks"], nl1, nl2)
     assert np.array_equal(fe.view(np.uint32), d["task_fe"].view(np.uint32))      # bit patterns
     assert np.array_equal(ef.view(np.uint32), d["task_ef"].view(np.uint32))
+    # device lexicon: same lines, same order, same counts and MaxLex bits as the oracle's createLexicon* restatement
+    ex.lexicon()
+    off = 0
+    for k, n in (("lex1", nl1), ("lex2", nl2), ("lex0", len(d["lex0_int"]) // 4)):
+        got = ex.fetch(k); want = d[k + "_int"].reshape(-1, 4)
+        assert len(got) == n == len(want), k
+        assert np.array_equal(got["id"], want[:, 0]) and np.array_equal(got["f"], want[:, 1]), k
+        assert np.array_equal(got["fsample"], want[:, 2]) and np.array_equal(got["paircount"], want[:, 3]), k
+        assert np.array_equal(got["fe"].view(np.uint32), d["task_fe"][off:off + n].view(np.uint32)), k
+        assert np.array_equal(got["ef"].view(np.uint32), d["task_ef"][off:off + n].view(np.uint32)), k
+        tk = d["tasks"][off:off + n]
+        for f, g in (("tstart", "tstart"), ("end", "end"), ("gap1", "gap1"), ("gap1_1", "gap1_1")):
+            assert np.array_equal(got[f], tk[g]), (k, f)
+        off += n
     ex.close()
+
+
+def test_exact_host_lexicon_path(cgx, fixtures_dir, tmp_path):
+    """The host lexicon (taken only on a target-hash collision) must give the same files as the device lexicon."""
+    fx = make_fixture("mid", fixtures_dir)
+    ex, corpus, n = run_product(cgx, fx, str(tmp_path / "h"), force_host_lexicon=1)
+    assert op.sha_dir(str(tmp_path / "h"), META["mid"]["spec"][2]) == META["mid"]["grammar"]
+    ex.close(); corpus.close()
 
 
 def test_edge_case_queries(cgx, oracle_bin, tmp_path):
