@@ -69,6 +69,7 @@ struct cgx_corpus {
     uint8_t *P;
     uint32_t *rlp; uint8_t *ltar, *rtar;
     char **svocab, **tvocab; int32_t nsvocab, ntvocab;   /* id -> spelling, NULL entries when built from ids */
+    uint32_t *svlen, *tvlen; uint32_t maxword;            /* spelling lengths (writer) */
     wordmap smap, tmap;
     cgx_lexkey *lexk; cgx_lexval *lexv; uint32_t nlex;
 };
@@ -209,7 +210,7 @@ void cgx_corpus_free(cgx_corpus *c) {
     if (!c) return;
     for (int32_t i = 0; c->svocab && i < c->nsvocab; i++) free(c->svocab[i]);
     for (int32_t i = 0; c->tvocab && i < c->ntvocab; i++) free(c->tvocab[i]);
-    free(c->svocab); free(c->tvocab); wordmap_free(&c->smap); wordmap_free(&c->tmap);
+    free(c->svocab); free(c->tvocab); free(c->svlen); free(c->tvlen); wordmap_free(&c->smap); wordmap_free(&c->tmap);
     free(c->str); free(c->tstr); free(c->sentind); free(c->tsentind); free(c->P); free(c->rlp); free(c->ltar); free(c->rtar);
     free(c->lexk); free(c->lexv); free(c);
 }
@@ -225,6 +226,10 @@ cgx_corpus *cgx_corpus_load(const char *src, const char *tgt, const char *align,
     if (tn != c->nsent) { snprintf(err, errcap, "source has %d lines, target %d", c->nsent, tn); goto bad; }
     if (load_lex(c, lex, err, errcap) != CGX_OK) goto bad;
     if (load_alignment(c, align, err, errcap) != CGX_OK) goto bad;
+    c->svlen = calloc((size_t)c->nsvocab + 1, 4); c->tvlen = calloc((size_t)c->ntvocab + 1, 4); c->maxword = 16;
+    if (!c->svlen || !c->tvlen) goto bad;
+    for (int32_t i = 2; i < c->nsvocab; i++) { c->svlen[i] = (uint32_t)strlen(c->svocab[i]); if (c->svlen[i] > c->maxword) c->maxword = c->svlen[i]; }
+    for (int32_t i = 2; i < c->ntvocab; i++) { c->tvlen[i] = (uint32_t)strlen(c->tvocab[i]); if (c->tvlen[i] > c->maxword) c->maxword = c->tvlen[i]; }
     return c;
 bad:
     cgx_corpus_free(c);
@@ -246,6 +251,7 @@ cgx_corpus *cgx_corpus_from_ids(const int32_t *str, uint32_t n, const int32_t *s
     memcpy(c->ltar, ltar, nt); memcpy(c->rtar, rtar, nt); memcpy(c->lexk, lexk, (size_t)nlex * sizeof *lexk); memcpy(c->lexv, lexv, (size_t)nlex * sizeof *lexv);
     for (int32_t q = 0; q < nsent; q++) for (int32_t i = sentind[q]; i < sentind[q + 1] - 1; i++) c->P[i] = (uint8_t)(i - sentind[q]);
     if (pack_alignment(c, lsrc, rsrc)) { cgx_corpus_free(c); return NULL; }
+    c->maxword = 16;
     return c;
 }
 
@@ -543,50 +549,55 @@ static int build_lexicons(batch *b) {
 /* ------------------------------------------------------------------ */
 typedef struct { char *p; size_t n, cap; } sbuf;
 static int sb_need(sbuf *s, size_t extra) { if (s->n + extra + 1 > s->cap) { size_t nc = s->cap ? s->cap : 1 << 16; while (nc < s->n + extra + 1) nc *= 2; s->p = realloc(s->p, nc); if (!s->p) return -1; s->cap = nc; } return 0; }
-static int sb_puts(sbuf *s, const char *x) { size_t L = strlen(x); if (sb_need(s, L)) return -1; memcpy(s->p + s->n, x, L); s->n += L; return 0; }
-static int sb_word(sbuf *s, const cgx_corpus *c, int target, int32_t id) {
+/* The formatter below appends through a raw cursor; the caller reserves line_max() bytes per line first. */
+static size_t line_max(const cgx_corpus *c) { return 512 + 32 * ((size_t)c->maxword + 8); }
+#define PUT_LIT(p, lit) do { memcpy((p), (lit), sizeof(lit) - 1); (p) += sizeof(lit) - 1; } while (0)
+static inline char *put_uint(char *p, uint32_t v) { char t[12]; int k = 0; do { t[k++] = (char)('0' + v % 10); v /= 10; } while (v); while (k) *p++ = t[--k]; return p; }
+static inline char *put_word(char *p, const cgx_corpus *c, int target, int32_t id) {
     char **voc = target ? c->tvocab : c->svocab; int32_t nv = target ? c->ntvocab : c->nsvocab;
-    if (voc && id >= 0 && id < nv && voc[id]) return sb_puts(s, voc[id]);
-    char tmp[24]; snprintf(tmp, sizeof tmp, "%c%d", target ? 't' : 's', id);
-    return sb_puts(s, tmp);
+    if (voc && id >= 0 && id < nv && voc[id]) { uint32_t L = (target ? c->tvlen : c->svlen)[id]; memcpy(p, voc[id], L); return p + L; }
+    *p++ = target ? 't' : 's';                            /* corpora built from ids have no spellings: s<id> / t<id> */
+    if (id < 0) { *p++ = '-'; id = -id; }
+    return put_uint(p, (uint32_t)id);
 }
-static int sb_block(sbuf *s, const batch *b, uint32_t bn) {
+static char *put_block(char *p, const batch *b, uint32_t bn) {
     const cgx_block *k = &b->blocks[bn];
-    for (int i = 0; i < k->matchlen; i++) { if (i && sb_puts(s, " ")) return -1; if (sb_word(s, b->c, 0, b->c->str[k->string_start + i])) return -1; }
-    return 0;
+    for (int i = 0; i < k->matchlen; i++) { if (i) *p++ = ' '; p = put_word(p, b->c, 0, b->c->str[k->string_start + i]); }
+    return p;
 }
-static int sb_pattern(sbuf *s, const batch *b, uint32_t one, const char *gap, int lead_space) {
-    const cgx_gappat *p = pat_of(b, one);
-    for (int j = 0; j < p->number; j++) {
-        if ((j || lead_space) && sb_puts(s, " ")) return -1;
-        if (p->pat[j] >= 0) { if (sb_word(s, b->c, 0, p->pat[j])) return -1; } else if (sb_puts(s, gap)) return -1;
+static char *put_pattern(char *p, const batch *b, uint32_t one, char gapdigit, int lead_space) {
+    const cgx_gappat *pt = pat_of(b, one);
+    for (int j = 0; j < pt->number; j++) {
+        if (j || lead_space) *p++ = ' ';
+        if (pt->pat[j] >= 0) p = put_word(p, b->c, 0, pt->pat[j]); else { PUT_LIT(p, "[X,"); *p++ = gapdigit; *p++ = ']'; }
     }
-    return 0;
+    return p;
 }
 /* source side of a rule group from its converted id (ExtractPair.c:743-796, 1021-1123) */
-static int sb_source(sbuf *s, const batch *b, int kind, uint32_t cid) {
+static char *put_source(char *p, const batch *b, int kind, uint32_t cid) {
     const uint32_t G = b->g, D1 = b->d1, D2 = b->d2;
-    if (kind == 0) return sb_block(s, b, cid);
+    if (kind == 0) return put_block(p, b, cid);
     if (kind == 1) {
-        if (cid < G) return sb_puts(s, "[X,1] ") || sb_block(s, b, cid);
-        if (cid < 2 * G) return sb_block(s, b, cid - G) || sb_puts(s, " [X,1]");
-        return sb_pattern(s, b, cid - 2 * G, "[X,1]", 0);
+        if (cid < G) { PUT_LIT(p, "[X,1] "); return put_block(p, b, cid); }
+        if (cid < 2 * G) { p = put_block(p, b, cid - G); PUT_LIT(p, " [X,1]"); return p; }
+        return put_pattern(p, b, cid - 2 * G, '1', 0);
     }
-    if (cid < G) return sb_puts(s, "[X,1] ") || sb_block(s, b, cid) || sb_puts(s, " [X,2]");
-    if (cid < G + D2) {
-        return sb_pattern(s, b, one_of(b, cid - G), "[X,1]", 0) || sb_puts(s, " [X,2] ") || sb_word(s, b->c, 0, c_of(b, cid - G));
-    }
-    if (cid < G + D2 + D1) return sb_puts(s, "[X,1]") || sb_pattern(s, b, cid - G - D2, "[X,2]", 1);
-    return sb_pattern(s, b, cid - G - D2 - D1, "[X,1]", 0) || sb_puts(s, " [X,2]");
+    if (cid < G) { PUT_LIT(p, "[X,1] "); p = put_block(p, b, cid); PUT_LIT(p, " [X,2]"); return p; }
+    if (cid < G + D2) { p = put_pattern(p, b, one_of(b, cid - G), '1', 0); PUT_LIT(p, " [X,2] "); return put_word(p, b->c, 0, c_of(b, cid - G)); }
+    if (cid < G + D2 + D1) { PUT_LIT(p, "[X,1]"); return put_pattern(p, b, cid - G - D2, '2', 1); }
+    p = put_pattern(p, b, cid - G - D2 - D1, '1', 0); PUT_LIT(p, " [X,2]"); return p;
 }
-static int sb_target(sbuf *s, const batch *b, const cgx_lexent *e) {
-    int32_t sym[48]; int n = target_symbols(b->c, e->tstart, e->end, e->gap1, e->gap1_1, e->gap2, e->gap2_1, e->kind, sym);
-    for (int i = 0; i < n; i++) {
-        if (i && sb_puts(s, " ")) return -1;
-        if (sym[i] == -1) { if (sb_puts(s, "[X,1]")) return -1; } else if (sym[i] == -2) { if (sb_puts(s, "[X,2]")) return -1; }
-        else if (sb_word(s, b->c, 1, sym[i])) return -1;
+static char *put_target(char *p, const batch *b, const cgx_lexent *e) {
+    const cgx_corpus *c = b->c; int first = 1;
+    uint32_t t0 = e->tstart, t1 = t0 + e->end, ga = t0 + e->gap1, gb = t0 + e->gap1_1, gc = t0 + e->gap2, gd = t0 + e->gap2_1;
+    for (uint32_t jj = t0; jj <= t1; jj++) {             /* ExtractPair.c:813-837, 1141-1163 */
+        if (!first) *p++ = ' ';
+        first = 0;
+        if (e->kind >= 1 && jj >= ga && jj <= gb) { PUT_LIT(p, "[X,1]"); jj = gb; }
+        else if (e->kind >= 2 && jj >= gc && jj <= gd) { PUT_LIT(p, "[X,2]"); jj = gd; }
+        else p = put_word(p, c, 1, c->tstr[jj]);
     }
-    return 0;
+    return p;
 }
 /* feature values depend only on (paircount, fsample) <= 300 each (ExtractPair.c:652-656): tabulated once with the host libm */
 #define TABN 302
@@ -598,31 +609,37 @@ static void score_tables(void) {
 }
 /* "%f" of a float: the value times 10^6 is exact in double (24 + 14 significant bits), so
  * rounding it to nearest-even is exactly what printf does; odd cases fall back to snprintf. */
-static int sb_f6(sbuf *s, float x) {
-    if (sb_need(s, 64)) return -1;
+static inline char *put_f6(char *p, float x) {
     double v = (double)x;
-    if (!(fabs(v) < 1e12)) { s->n += (size_t)snprintf(s->p + s->n, 64, "%f", v); return 0; }
-    char *p = s->p + s->n;
+    if (!(fabs(v) < 1e12)) return p + snprintf(p, 64, "%f", v);
     if (signbit(v)) { *p++ = '-'; v = -v; }
     uint64_t m = (uint64_t)rint(v * 1e6), ip = m / 1000000u, fp = m % 1000000u;
     char tmp[24]; int k = 0; do { tmp[k++] = (char)('0' + ip % 10); ip /= 10; } while (ip);
     while (k) *p++ = tmp[--k];
     *p++ = '.';
     for (int d = 5; d >= 0; d--) { p[d] = (char)('0' + fp % 10); fp /= 10; }
-    p += 6; s->n = (size_t)(p - s->p);
-    return 0;
+    return p + 6;
 }
+static int sb_f6(sbuf *s, float x) { if (sb_need(s, 64)) return -1; s->n = (size_t)(put_f6(s->p + s->n, x) - s->p); return 0; }
 static int emit_range(sbuf *s, const batch *b, int kind, const cgx_lexent *lex, const range *rng, uint32_t id, uint64_t *lines) {
     if (rng[id].down == -1 || rng[id].up == -1) return 0;
+    const size_t lmax = line_max(b->c);
+    char srcbuf[4096]; size_t srclen = 0;                 /* every line of the range shares the source side */
+    if (lmax < sizeof srcbuf) srclen = (size_t)(put_source(srcbuf, b, kind, (uint32_t)lex[rng[id].down].id) - srcbuf);
     for (int32_t i = rng[id].down; i <= rng[id].up; i++) {
         const cgx_lexent *e = &lex[i];
-        int p = e->paircount < TABN ? e->paircount : TABN - 1, f = e->fsample < TABN ? e->fsample : TABN - 1;
-        float aa = (e->paircount < TABN && e->fsample < TABN && e->fsample > 0) ? g_aa[p][f] : -log10f((float)e->paircount / (float)e->fsample);
-        float bb = e->paircount < TABN ? g_bb[p] : (float)log10((double)(1 + e->paircount)), fsc = e->fsample < TABN ? g_fs[f] : (float)log10((double)(1 + e->fsample));
-        if (sb_puts(s, "[X] ||| ") || sb_source(s, b, kind, (uint32_t)e->id) || sb_puts(s, " ||| ") || sb_target(s, b, e)) return -1;
-        if (sb_puts(s, " ||| EgivenFCoherent=") || sb_f6(s, aa) || sb_puts(s, " SampleCountF=") || sb_f6(s, fsc) || sb_puts(s, " CountEF=") || sb_f6(s, bb) ||
-            sb_puts(s, " MaxLexFgivenE=") || sb_f6(s, e->fe) || sb_puts(s, " MaxLexEgivenF=") || sb_f6(s, e->ef) ||
-            sb_puts(s, e->f == 1 ? " IsSingletonF=1" : " IsSingletonF=0") || sb_puts(s, e->paircount == 1 ? " IsSingletonFE=1\n" : " IsSingletonFE=0\n")) return -1;
+        if (sb_need(s, lmax)) return -1;
+        char *p = s->p + s->n;
+        int pc = e->paircount < TABN ? e->paircount : TABN - 1, f = e->fsample < TABN ? e->fsample : TABN - 1;
+        float aa = (e->paircount < TABN && e->fsample < TABN && e->fsample > 0) ? g_aa[pc][f] : -log10f((float)e->paircount / (float)e->fsample);
+        float bb = e->paircount < TABN ? g_bb[pc] : (float)log10((double)(1 + e->paircount)), fsc = e->fsample < TABN ? g_fs[f] : (float)log10((double)(1 + e->fsample));
+        PUT_LIT(p, "[X] ||| ");
+        if (srclen) { memcpy(p, srcbuf, srclen); p += srclen; } else p = put_source(p, b, kind, (uint32_t)e->id);
+        PUT_LIT(p, " ||| "); p = put_target(p, b, e);
+        PUT_LIT(p, " ||| EgivenFCoherent="); p = put_f6(p, aa); PUT_LIT(p, " SampleCountF="); p = put_f6(p, fsc); PUT_LIT(p, " CountEF="); p = put_f6(p, bb);
+        PUT_LIT(p, " MaxLexFgivenE="); p = put_f6(p, e->fe); PUT_LIT(p, " MaxLexEgivenF="); p = put_f6(p, e->ef);
+        PUT_LIT(p, " IsSingletonF="); *p++ = e->f == 1 ? '1' : '0'; PUT_LIT(p, " IsSingletonFE="); *p++ = e->paircount == 1 ? '1' : '0'; *p++ = '\n';
+        s->n = (size_t)(p - s->p);
         (*lines)++;
     }
     return 0;
