@@ -173,6 +173,14 @@ def main():
         lm = ex.fetch("lm"); c = ex.counts()
         abytes, lookups = algorithmic_bytes(len(corpus["str"]), lm)
         kms = float(np.mean(kernel_ms))
+        traffic = None                      # HBM bytes per launch from the committed PMC passes (same config only)
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_k_sa_lookup.json")))
+            pc = pmc["config"]
+            if (pc["pairs"], pc["queries"], pc["seed"], pc["vocab"]) == (args.pairs, args.queries, args.seed, args.vocab):
+                traffic = int(pmc["traffic_bytes_raw"])
+        except Exception:
+            traffic = None
         ach = abytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
         line = {
             "metric": "query sentences/sec", "value": round(total_q / dt, 3), "unit": "query sentences/s",
@@ -185,7 +193,7 @@ def main():
                        "queries_per_gpu": int(len(qoff)), "query_tokens_per_gpu": int(len(qtok)), "parallelism": "query-shard x%d, index replicated" % world,
                        "grammar_files_written": not args.no_write, "outdir": os.path.dirname(outdir) if outdir else None},
             "roofline": {"bound": "hbm", "kernel": "k_sa_lookup (batched SA interval search)", "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s",
-                         "frac": round(ach / 8000.0, 4), "traffic": None, "algorithmic_bytes_per_launch": int(abytes), "lookups_per_launch": int(lookups),
+                         "frac": round(ach / 8000.0, 4), "traffic": traffic, "algorithmic_bytes_per_launch": int(abytes), "lookups_per_launch": int(lookups),
                          "kernel_ms": round(kms, 4)},
             "stages_ms_per_step": {k: round(v / args.steps, 3) for k, v in {**stage, **{"host_" + k: v for k, v in hoststage.items()}}.items()},
             "index": {"build_sa_ms": round(ex.stage_ms("build_sa"), 1), "precompute_ms": round(ex.stage_ms("precompute"), 1),
