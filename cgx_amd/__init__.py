@@ -47,10 +47,10 @@ COUNT_NAMES = ["e1", "d1", "h1", "e2", "d2", "h2", "g", "n0", "n1", "n2", "sep1"
 # every entry point declared in include/cgx.h
 ABI = [
     "cgx_create", "cgx_destroy", "cgx_last_error", "cgx_set_option", "cgx_upload_index", "cgx_build_sa", "cgx_precompute",
-    "cgx_index_alloc", "cgx_index_nbuffers", "cgx_index_buffer", "cgx_index_d2d", "cgx_index_finalize", "cgx_broadcast_index",
+    "cgx_index_shape", "cgx_index_alloc", "cgx_index_nbuffers", "cgx_index_buffer", "cgx_index_d2d", "cgx_index_finalize", "cgx_broadcast_index",
     "cgx_upload_queries", "cgx_sa_lookup", "cgx_gappy_search", "cgx_set_blocks", "cgx_extract", "cgx_lexicon", "cgx_lex_features", "cgx_fetch",
     "cgx_stage_ms", "cgx_corpus_load", "cgx_corpus_free", "cgx_corpus_upload", "cgx_extract_grammars", "cgx_extract_grammars_ids",
-    "cgx_corpus_from_ids", "cgx_host_ms",
+    "cgx_corpus_from_ids", "cgx_host_ms", "cgx_flush",
 ]
 
 
@@ -80,9 +80,10 @@ def load_library():
     lib.cgx_last_error.restype = C.c_char_p; lib.cgx_last_error.argtypes = [C.c_void_p]
     lib.cgx_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
     lib.cgx_upload_index.argtypes = [C.c_void_p, C.POINTER(IndexHost)]
-    for f in ("cgx_build_sa", "cgx_precompute", "cgx_sa_lookup", "cgx_gappy_search", "cgx_extract", "cgx_lexicon", "cgx_index_finalize", "cgx_index_nbuffers"):
+    for f in ("cgx_flush", "cgx_build_sa", "cgx_precompute", "cgx_sa_lookup", "cgx_gappy_search", "cgx_extract", "cgx_lexicon", "cgx_index_finalize", "cgx_index_nbuffers"):
         getattr(lib, f).argtypes = [C.c_void_p]
-    lib.cgx_index_alloc.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32]
+    lib.cgx_index_alloc.argtypes = [C.c_void_p, C.c_void_p]
+    lib.cgx_index_shape.argtypes = [C.c_void_p, C.c_void_p]
     lib.cgx_index_buffer.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64)]
     lib.cgx_index_d2d.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
     lib.cgx_broadcast_index.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
@@ -202,8 +203,14 @@ class Extractor:
             out.append((name.value.decode(), int(nb.value)))
         return out
 
-    def index_alloc(self, n, nt, nlex, nphits, last):
-        self._chk(self.lib.cgx_index_alloc(self.h, n, nt, nlex, nphits, last), "cgx_index_alloc")
+    def index_shape(self):
+        d = np.zeros(7, np.int32)
+        self._chk(self.lib.cgx_index_shape(self.h, _ptr(d)), "cgx_index_shape")
+        return [int(x) for x in d]
+
+    def index_alloc(self, dims):
+        d = np.asarray(dims, np.int32)
+        self._chk(self.lib.cgx_index_alloc(self.h, _ptr(d)), "cgx_index_alloc")
 
     def index_d2d(self, i, dptr, direction):
         self._chk(self.lib.cgx_index_d2d(self.h, i, C.c_void_p(dptr), direction), "cgx_index_d2d")
@@ -258,6 +265,9 @@ class Extractor:
 
     def host_ms(self, name):
         return float(self.lib.cgx_host_ms(self.h, name.encode()))
+
+    def flush(self):
+        self._chk(self.lib.cgx_flush(self.h), "cgx_flush")
 
     # ---- whole path ----
     def extract_grammars(self, corpus, qryfile, outdir, q_begin=0, q_end=-1):

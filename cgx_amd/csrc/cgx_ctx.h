@@ -13,6 +13,8 @@ struct cgx_ctx {
     hipStream_t stream = nullptr;
     char err[512] = {0};
     int k1_limit = 128;                 // K1 launches 128 threads per query sentence (SuffixArray.cu:1374-1378)
+    bool async_write = false;           // grammar files of batch k are written by host threads while the GPU runs batch k+1 (cgx_flush joins)
+    void *host_state = nullptr;         // owned by the host TU
     bool force_host_lexicon = false;    // test hook: take the exact host lexicon path
     uint64_t chunk_items = 1ull << 26;  // work items per count/fill chunk
     std::map<std::string, double> ms;   // stage timings
@@ -24,6 +26,7 @@ struct cgx_ctx {
     uint32_t *d_rlp = nullptr;
     uint8_t *d_ltar = nullptr, *d_rtar = nullptr;
     uint64_t *d_lexkey = nullptr; float *d_lexv1 = nullptr, *d_lexv2 = nullptr, *d_lexn1 = nullptr, *d_lexn2 = nullptr;
+    uint32_t *d_lexrow = nullptr; int32_t *d_lexnullt = nullptr; uint32_t lex_nrow = 0, lex_ntgt = 0;
     int32_t *d_tokstart = nullptr; int8_t *d_tokrank = nullptr; int32_t *d_freq = nullptr;
     uint32_t *d_pidx = nullptr; int32_t *d_miss = nullptr; uint32_t *d_phit_start = nullptr; uint8_t *d_phit_len = nullptr;
     int32_t freq[100] = {0};

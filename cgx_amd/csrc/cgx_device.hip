@@ -33,12 +33,41 @@ static int fail(cgx_ctx *c, int code, const char *what, hipError_t e) {
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(ctx, CGX_ERR_HIP, #x, e_); } while (0)
 #define TRY(x) do { int r_ = (x); if (r_ != CGX_OK) return r_; } while (0)
 
+// Caching device allocator: hipMalloc/hipFree of multi-GB scratch cost 100s of ms per batch and
+// hipFree synchronises the device.  Freed blocks are kept (grow-only pool, best fit within 2x)
+// and reused by later stages/batches on the same stream; cgx_destroy returns them to the driver.
+#include <unordered_map>
+#include <map>
+struct DevPool {
+    std::unordered_map<void *, size_t> live;
+    std::multimap<size_t, void *> cached;
+    size_t cached_bytes = 0;
+    void *get(size_t bytes) {
+        auto it = cached.lower_bound(bytes);
+        if (it != cached.end() && it->first <= bytes * 2 + (1u << 20)) { void *p = it->second; live[p] = it->first; cached_bytes -= it->first; cached.erase(it); return p; }
+        void *p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) { trim(); (void)hipGetLastError(); if (hipMalloc(&p, bytes) != hipSuccess) return nullptr; }
+        live[p] = bytes;
+        return p;
+    }
+    void put(void *p) {
+        auto it = live.find(p);
+        if (it == live.end()) { (void)hipFree(p); return; }
+        cached.insert({it->second, p}); cached_bytes += it->second; live.erase(it);
+    }
+    void trim() { for (auto &kv : cached) (void)hipFree(kv.second); cached.clear(); cached_bytes = 0; }
+};
+static DevPool g_pool;
 template <class T> static int dalloc(cgx_ctx *ctx, T **p, size_t count) {
-    *p = nullptr;
-    HIPCHK(hipMalloc((void **)p, (count ? count : 1) * sizeof(T)));
+    size_t bytes = (count ? count : 1) * sizeof(T);
+    bytes = (bytes + 255) & ~(size_t)255;
+    *p = (T *)g_pool.get(bytes);
+    if (!*p) return fail(ctx, CGX_ERR_NOMEM, "device allocation", hipErrorOutOfMemory);
     return CGX_OK;
 }
-template <class T> static void dfree(T *&p) { if (p) { (void)hipFree((void *)p); p = nullptr; } }
+template <class T> static void dfree(T *&p) { if (p) { g_pool.put((void *)p); p = nullptr; } }
+static int dalloc_bytes(cgx_ctx *ctx, void **p, size_t bytes) { return dalloc(ctx, (char **)p, bytes); }
+static void dfree_bytes(void *p) { if (p) g_pool.put(p); }
 static inline unsigned nblocks(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
 static int bits_for(uint64_t maxval) { int b = 1; while (b < 64 && (maxval >> b)) b++; return b; }
 
@@ -53,9 +82,9 @@ template <class K, class V>
 static int sort_pairs(cgx_ctx *ctx, const K *kin, K *kout, const V *vin, V *vout, size_t n, unsigned b0, unsigned b1) {
     size_t tb = 0; void *tmp = nullptr;
     HIPCHK(rocprim::radix_sort_pairs(nullptr, tb, kin, kout, vin, vout, n, b0, b1, ctx->stream));
-    HIPCHK(hipMalloc(&tmp, tb ? tb : 1));
+    TRY(dalloc_bytes(ctx, &tmp, tb ? tb : 1));
     hipError_t e = rocprim::radix_sort_pairs(tmp, tb, kin, kout, vin, vout, n, b0, b1, ctx->stream);
-    (void)hipStreamSynchronize(ctx->stream); (void)hipFree(tmp);
+    dfree_bytes(tmp);
     HIPCHK(e);
     return CGX_OK;
 }
@@ -63,9 +92,9 @@ template <class K>
 static int sort_keys(cgx_ctx *ctx, const K *kin, K *kout, size_t n, unsigned b0, unsigned b1) {
     size_t tb = 0; void *tmp = nullptr;
     HIPCHK(rocprim::radix_sort_keys(nullptr, tb, kin, kout, n, b0, b1, ctx->stream));
-    HIPCHK(hipMalloc(&tmp, tb ? tb : 1));
+    TRY(dalloc_bytes(ctx, &tmp, tb ? tb : 1));
     hipError_t e = rocprim::radix_sort_keys(tmp, tb, kin, kout, n, b0, b1, ctx->stream);
-    (void)hipStreamSynchronize(ctx->stream); (void)hipFree(tmp);
+    dfree_bytes(tmp);
     HIPCHK(e);
     return CGX_OK;
 }
@@ -73,9 +102,9 @@ template <class In, class Out>
 static int excl_scan(cgx_ctx *ctx, const In *in, Out *out, size_t n) {
     size_t tb = 0; void *tmp = nullptr;
     HIPCHK(rocprim::exclusive_scan(nullptr, tb, in, out, (Out)0, n, rocprim::plus<Out>(), ctx->stream));
-    HIPCHK(hipMalloc(&tmp, tb ? tb : 1));
+    TRY(dalloc_bytes(ctx, &tmp, tb ? tb : 1));
     hipError_t e = rocprim::exclusive_scan(tmp, tb, in, out, (Out)0, n, rocprim::plus<Out>(), ctx->stream);
-    (void)hipStreamSynchronize(ctx->stream); (void)hipFree(tmp);
+    dfree_bytes(tmp);
     HIPCHK(e);
     return CGX_OK;
 }
@@ -83,9 +112,9 @@ template <class In, class Out>
 static int incl_scan(cgx_ctx *ctx, const In *in, Out *out, size_t n) {
     size_t tb = 0; void *tmp = nullptr;
     HIPCHK(rocprim::inclusive_scan(nullptr, tb, in, out, n, rocprim::plus<Out>(), ctx->stream));
-    HIPCHK(hipMalloc(&tmp, tb ? tb : 1));
+    TRY(dalloc_bytes(ctx, &tmp, tb ? tb : 1));
     hipError_t e = rocprim::inclusive_scan(tmp, tb, in, out, n, rocprim::plus<Out>(), ctx->stream);
-    (void)hipStreamSynchronize(ctx->stream); (void)hipFree(tmp);
+    dfree_bytes(tmp);
     HIPCHK(e);
     return CGX_OK;
 }
@@ -172,15 +201,18 @@ static void free_batch(cgx_ctx *c) {
 }
 static void free_index(cgx_ctx *c) {
     dfree(c->d_str); dfree(c->d_sa); dfree(c->d_rlp); dfree(c->d_tstr); dfree(c->d_ltar); dfree(c->d_rtar);
-    dfree(c->d_lexkey); dfree(c->d_lexv1); dfree(c->d_lexv2); dfree(c->d_lexn1); dfree(c->d_lexn2);
+    dfree(c->d_lexkey); dfree(c->d_lexv1); dfree(c->d_lexv2); dfree(c->d_lexn1); dfree(c->d_lexn2); dfree(c->d_lexrow); dfree(c->d_lexnullt);
     dfree(c->d_tokstart); dfree(c->d_tokrank); dfree(c->d_freq); dfree(c->d_pidx); dfree(c->d_miss);
     dfree(c->d_phit_start); dfree(c->d_phit_len);
     c->n = c->nt = c->nlex = c->nphits = 0; c->have_sa = c->have_pre = false;
 }
 extern "C" void cgx_destroy(cgx_ctx *c) {
     if (!c) return;
+    cgx__host_release(c);
     (void)hipSetDevice(c->device);
     free_batch(c); free_index(c);
+    (void)hipStreamSynchronize(c->stream);
+    g_pool.trim();
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -188,11 +220,15 @@ extern "C" const char *cgx_last_error(cgx_ctx *c) { return c ? c->err : "null co
 extern "C" int cgx_set_option(cgx_ctx *c, const char *name, int64_t value) {
     if (!c || !name) return CGX_ERR_ARG;
     if (!strcmp(name, "k1_limit")) { c->k1_limit = (int)value; return CGX_OK; }
+    if (!strcmp(name, "async_write")) { c->async_write = value != 0; return CGX_OK; }
     if (!strcmp(name, "force_host_lexicon")) { c->force_host_lexicon = value != 0; return CGX_OK; }
     if (!strcmp(name, "chunk_items")) { if (value < 1024) return CGX_ERR_ARG; c->chunk_items = (uint64_t)value; return CGX_OK; }
     snprintf(c->err, sizeof c->err, "unknown option %s", name);
     return CGX_ERR_ARG;
 }
+extern "C" int64_t cgx__option(cgx_ctx *c, const char *name) { return (c && name && !strcmp(name, "async_write")) ? (int64_t)c->async_write : 0; }
+extern "C" void cgx__set_host_state(cgx_ctx *c, void *p) { if (c) c->host_state = p; }
+extern "C" void *cgx__get_host_state(cgx_ctx *c) { return c ? c->host_state : nullptr; }
 extern "C" void cgx__set_host_ms(cgx_ctx *c, const char *name, double ms) { if (c && name) c->host_ms[name] = ms; }
 extern "C" double cgx_host_ms(cgx_ctx *c, const char *name) {
     if (!c || !name) return -1;
@@ -239,6 +275,16 @@ static int upload_lex(cgx_ctx *ctx, const cgx_lexkey *k, const cgx_lexval *v, ui
     TRY(dalloc(ctx, &ctx->d_lexn1, nlex)); TRY(dalloc(ctx, &ctx->d_lexn2, nlex));
     TRY(h2d(ctx, ctx->d_lexkey, key.data(), nlex)); TRY(h2d(ctx, ctx->d_lexv1, v1.data(), nlex)); TRY(h2d(ctx, ctx->d_lexv2, v2.data(), nlex));
     TRY(h2d(ctx, ctx->d_lexn1, n1.data(), nlex)); TRY(h2d(ctx, ctx->d_lexn2, n2.data(), nlex));
+    // row pointers per source word and the direct (NULL, tgt) table
+    uint32_t maxs = 0, maxt = 0;
+    for (uint32_t i = 0; i < nlex; i++) { uint32_t s_ = (uint32_t)(key[i] >> 32), t_ = (uint32_t)key[i]; if (s_ > maxs) maxs = s_; if (t_ > maxt) maxt = t_; }
+    ctx->lex_nrow = maxs + 1; ctx->lex_ntgt = maxt;                   // target ids 0..maxt-1 (key stores tgt+1)
+    std::vector<uint32_t> row((size_t)ctx->lex_nrow + 2, nlex); std::vector<int32_t> nullt((size_t)ctx->lex_ntgt + 1, -1);
+    for (uint32_t i = nlex; i-- > 0;) row[(size_t)(key[i] >> 32)] = i;
+    for (size_t s_ = ctx->lex_nrow; s_-- > 0;) if (row[s_] == nlex || row[s_] > row[s_ + 1]) row[s_] = row[s_ + 1];      // empty rows point at the next row
+    for (uint32_t i = 0; i < nlex && (key[i] >> 32) == 0; i++) { uint32_t t_ = (uint32_t)key[i]; if (t_ >= 1) nullt[t_ - 1] = (int32_t)i; }
+    TRY(dalloc(ctx, &ctx->d_lexrow, row.size())); TRY(h2d(ctx, ctx->d_lexrow, row.data(), row.size()));
+    TRY(dalloc(ctx, &ctx->d_lexnullt, nullt.size())); TRY(h2d(ctx, ctx->d_lexnullt, nullt.data(), nullt.size()));
     ctx->nlex = nlex;
     return CGX_OK;
 }
@@ -412,6 +458,8 @@ static std::vector<bufdesc> index_buffers(cgx_ctx *c) {
     b.push_back({"lexv2", (void **)&c->d_lexv2, (uint64_t)c->nlex * 4});
     b.push_back({"lexn1", (void **)&c->d_lexn1, (uint64_t)c->nlex * 4});
     b.push_back({"lexn2", (void **)&c->d_lexn2, (uint64_t)c->nlex * 4});
+    b.push_back({"lexrow", (void **)&c->d_lexrow, ((uint64_t)c->lex_nrow + 2) * 4});
+    b.push_back({"lexnullt", (void **)&c->d_lexnullt, ((uint64_t)c->lex_ntgt + 1) * 4});
     b.push_back({"tokstart", (void **)&c->d_tokstart, ((uint64_t)c->last + 3) * 4});
     b.push_back({"tokrank", (void **)&c->d_tokrank, (uint64_t)c->last + 2});
     b.push_back({"freq", (void **)&c->d_freq, CGX_TOP * 4});
@@ -421,12 +469,17 @@ static std::vector<bufdesc> index_buffers(cgx_ctx *c) {
     b.push_back({"phit_len", (void **)&c->d_phit_len, (uint64_t)c->nphits});
     return b;
 }
-extern "C" int cgx_index_alloc(cgx_ctx *ctx, uint32_t n, uint32_t nt, uint32_t nlex, uint32_t nphits, int32_t last) {
-    if (!ctx) return CGX_ERR_ARG;
+extern "C" int cgx_index_shape(cgx_ctx *ctx, cgx_index_dims *d) {
+    if (!ctx || !d) return CGX_ERR_ARG;
+    d->n = ctx->n; d->nt = ctx->nt; d->nlex = ctx->nlex; d->nphits = ctx->nphits; d->last = ctx->last; d->lex_nrow = ctx->lex_nrow; d->lex_ntgt = ctx->lex_ntgt;
+    return CGX_OK;
+}
+extern "C" int cgx_index_alloc(cgx_ctx *ctx, const cgx_index_dims *d) {
+    if (!ctx || !d) return CGX_ERR_ARG;
     HIPCHK(hipSetDevice(ctx->device));
     free_batch(ctx); free_index(ctx);
-    ctx->n = n; ctx->nt = nt; ctx->nlex = nlex; ctx->nphits = nphits; ctx->last = last;
-    for (auto &b : index_buffers(ctx)) HIPCHK(hipMalloc(b.ptr, b.bytes ? b.bytes : 1));
+    ctx->n = d->n; ctx->nt = d->nt; ctx->nlex = d->nlex; ctx->nphits = d->nphits; ctx->last = d->last; ctx->lex_nrow = d->lex_nrow; ctx->lex_ntgt = d->lex_ntgt;
+    for (auto &b : index_buffers(ctx)) TRY(dalloc_bytes(ctx, b.ptr, b.bytes ? b.bytes : 1));
     return CGX_OK;
 }
 extern "C" int cgx_index_nbuffers(cgx_ctx *ctx) { return ctx ? (int)index_buffers(ctx).size() : CGX_ERR_ARG; }
@@ -1359,7 +1412,7 @@ extern "C" int cgx_lex_features(cgx_ctx *ctx, const cgx_lextask *tasks, uint32_t
         cgx_lextask *d = nullptr; float *fe = nullptr, *ef = nullptr;
         TRY(dalloc(ctx, &d, ntask)); TRY(dalloc(ctx, &fe, ntask)); TRY(dalloc(ctx, &ef, ntask));
         TRY(h2d(ctx, d, tasks, ntask));
-        cgx_lexview t{ctx->d_lexkey, ctx->d_lexv1, ctx->d_lexv2, ctx->d_lexn1, ctx->d_lexn2, ctx->nlex};
+        cgx_lexview t{ctx->d_lexkey, ctx->d_lexv1, ctx->d_lexv2, ctx->d_lexn1, ctx->d_lexn2, ctx->nlex, ctx->d_lexrow, ctx->d_lexnullt, ctx->lex_nrow, ctx->lex_ntgt};
         k_lextask<<<nblocks(ntask, 128), 128, 0, ctx->stream>>>(t, ctx->d_tstr, d, ntask, n_onegap, n_onegap + n_twogap, fe, ef);
         HIPCHK(hipGetLastError());
         TRY(d2h(ctx, max_fe, fe, ntask)); TRY(d2h(ctx, max_ef, ef, ntask));
@@ -1532,7 +1585,7 @@ extern "C" int cgx_lexicon(cgx_ctx *ctx) {
     dfree(ctx->d_lex0); dfree(ctx->d_lex1); dfree(ctx->d_lex2); ctx->nl0 = ctx->nl1 = ctx->nl2 = 0;
     lexsrc L{ctx->d_blocks, ctx->d_s1, ctx->d_s2, ctx->d_p1, ctx->d_c2, ctx->d_str, ctx->d_tstr, ctx->d_hits1, ctx->d_pidx, ctx->d_miss,
              ctx->g, ctx->d1, ctx->d2, ctx->sep1, ctx->sep2a, ctx->sep2b};
-    cgx_lexview T{ctx->d_lexkey, ctx->d_lexv1, ctx->d_lexv2, ctx->d_lexn1, ctx->d_lexn2, ctx->nlex};
+    cgx_lexview T{ctx->d_lexkey, ctx->d_lexv1, ctx->d_lexv2, ctx->d_lexn1, ctx->d_lexn2, ctx->nlex, ctx->d_lexrow, ctx->d_lexnullt, ctx->lex_nrow, ctx->lex_ntgt};
     TRY(lexicon_kind(ctx, L, T, 1, ctx->n1, 2 * ctx->g + ctx->d1, &ctx->d_lex1, &ctx->nl1));
     TRY(lexicon_kind(ctx, L, T, 2, ctx->n2, ctx->g + 2 * ctx->d1 + ctx->d2, &ctx->d_lex2, &ctx->nl2));
     TRY(lexicon_kind(ctx, L, T, 0, ctx->n0, ctx->g, &ctx->d_lex0, &ctx->nl0));

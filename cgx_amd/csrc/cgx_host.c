@@ -690,7 +690,26 @@ static int write_grammars(const batch *b, const char *outdir, int32_t first, uin
 /* ------------------------------------------------------------------ */
 /* the whole path for one batch of queries                             */
 /* ------------------------------------------------------------------ */
-static int run_batch(cgx_ctx *ctx, const cgx_corpus *c, batch *b, const char *outdir, int32_t first, uint64_t *nrules) {
+/* number of grammar lines the writer will produce (PrintResults.c:451-570 walked without formatting) */
+static uint64_t range_len(const range *r, uint32_t id) { return (r[id].down == -1 || r[id].up == -1) ? 0 : (uint64_t)(r[id].up - r[id].down + 1); }
+static uint64_t count_lines(const batch *b) {
+    const uint32_t G = b->g, D1 = b->d1, D2 = b->d2; uint64_t n = 0;
+    for (int32_t q = 0; q < b->nq; q++) {
+        for (uint32_t k = 0; k < b->qblocks[q].n; k++) { uint32_t p = b->qblocks[q].v[k]; n += range_len(b->rng1, p + G) + range_len(b->rng1, p) + range_len(b->rng2, p) + range_len(b->rng0, p); }
+        for (uint32_t k = 0; b->qone && k < b->qone[q].n; k++) { uint32_t id = b->qone[q].v[k]; n += range_len(b->rng1, 2 * G + id) + range_len(b->rng2, G + D2 + id) + range_len(b->rng2, G + D2 + D1 + id); }
+        for (uint32_t k = 0; b->qtwo && k < b->qtwo[q].n; k++) n += range_len(b->rng2, G + b->qtwo[q].v[k]);
+    }
+    return n;
+}
+typedef struct { batch *b; char *outdir; int32_t first; pthread_t th; int active, rc; uint64_t lines; double ms; } pending;
+static void *pending_main(void *arg) {
+    pending *pw = arg; double t = now_ms();
+    pw->rc = write_grammars(pw->b, pw->outdir, pw->first, &pw->lines);
+    pw->ms = now_ms() - t;
+    return NULL;
+}
+
+static int run_batch(cgx_ctx *ctx, const cgx_corpus *c, batch *b, const char *outdir, int32_t first, uint64_t *nrules, int *handed_off) {
     int rc; double t0 = now_ms(), t;
     b->c = c;
     if ((rc = cgx_upload_queries(ctx, b->qoff, b->nq, b->qtok, b->ntok)) != CGX_OK) return rc;
@@ -761,28 +780,58 @@ static int run_batch(cgx_ctx *ctx, const cgx_corpus *c, batch *b, const char *ou
     b->rng1 = make_ranges_dev(b->L1, nl1, 2 * b->g + b->d1); b->rng2 = make_ranges_dev(b->L2, nl2, b->g + 2 * b->d1 + b->d2); b->rng0 = make_ranges_dev(b->L0, nl0, b->g);
     if (!b->rng0 || !b->rng1 || !b->rng2) return CGX_ERR_NOMEM;
     cgx__set_host_ms(ctx, "lexicon", now_ms() - t);
-    uint64_t lines = 0;
+    uint64_t lines = count_lines(b);
+    if (nrules) *nrules = lines;
+    if (outdir && cgx__option(ctx, "async_write")) {
+        /* hand the finished batch to a background writer; the GPU is free for the next batch */
+        if ((rc = cgx_flush(ctx)) != CGX_OK) return rc;
+        pending *pw = calloc(1, sizeof *pw);
+        if (!pw) return CGX_ERR_NOMEM;
+        pw->b = b; pw->outdir = strdup(outdir); pw->first = first; pw->active = 1;
+        fprintf(stderr, "Start Printing Gappy Phrases...\n");
+        if (pthread_create(&pw->th, NULL, pending_main, pw)) { free(pw->outdir); free(pw); return CGX_ERR_NOMEM; }
+        cgx__set_host_state(ctx, pw);
+        *handed_off = 1;
+        cgx__set_host_ms(ctx, "total", now_ms() - t0);
+        return CGX_OK;
+    }
     t = now_ms();
     if (outdir) {
+        uint64_t wrote = 0;
         fprintf(stderr, "Start Printing Gappy Phrases...\n");
-        if ((rc = write_grammars(b, outdir, first, &lines)) != CGX_OK) return rc;
-    } else lines = (uint64_t)b->nl0 + b->nl1 + b->nl2;
+        if ((rc = write_grammars(b, outdir, first, &wrote)) != CGX_OK) return rc;
+    }
     cgx__set_host_ms(ctx, "write", now_ms() - t);
     cgx__set_host_ms(ctx, "total", now_ms() - t0);
-    if (nrules) *nrules = lines;
     return CGX_OK;
 }
+
+/* waits for the background writer of the previous batch (async_write); its error, if any, is returned here */
+int cgx_flush(cgx_ctx *ctx) {
+    if (!ctx) return CGX_ERR_ARG;
+    pending *pw = cgx__get_host_state(ctx);
+    if (!pw) return CGX_OK;
+    pthread_join(pw->th, NULL);
+    int rc = pw->rc;
+    cgx__set_host_ms(ctx, "write", pw->ms);
+    cgx__set_host_state(ctx, NULL);
+    batch_free(pw->b); free(pw->b); free(pw->outdir); free(pw);
+    return rc;
+}
+void cgx__host_release(cgx_ctx *ctx) { (void)cgx_flush(ctx); }
 
 int cgx_extract_grammars_ids(cgx_ctx *ctx, const cgx_corpus *c, const int32_t *qoff, int32_t nq, const int32_t *qtok, int32_t ntok,
                              const char *outdir, int32_t first, uint64_t *nrules) {
     if (!ctx || !c || nq < 0 || ntok < 0) return CGX_ERR_ARG;
-    batch b; memset(&b, 0, sizeof b);
-    b.nq = nq; b.ntok = ntok;
-    b.qoff = malloc(((size_t)nq + 1) * 4); b.qtok = malloc(((size_t)ntok + 1) * 4);
-    if (!b.qoff || !b.qtok) return CGX_ERR_NOMEM;
-    memcpy(b.qoff, qoff, (size_t)nq * 4); b.qoff[nq] = ntok; memcpy(b.qtok, qtok, (size_t)ntok * 4);
-    int rc = run_batch(ctx, c, &b, outdir, first, nrules);
-    batch_free(&b);
+    batch *b = calloc(1, sizeof *b);
+    if (!b) return CGX_ERR_NOMEM;
+    b->nq = nq; b->ntok = ntok;
+    b->qoff = malloc(((size_t)nq + 1) * 4); b->qtok = malloc(((size_t)ntok + 1) * 4);
+    if (!b->qoff || !b->qtok) return CGX_ERR_NOMEM;
+    memcpy(b->qoff, qoff, (size_t)nq * 4); b->qoff[nq] = ntok; memcpy(b->qtok, qtok, (size_t)ntok * 4);
+    int handed_off = 0;
+    int rc = run_batch(ctx, c, b, outdir, first, nrules, &handed_off);
+    if (!handed_off) { batch_free(b); free(b); }
     return rc;
 }
 

@@ -348,12 +348,24 @@ CGX_HD bool cgx_extract_onegap(const cgx_view &v, int32_t id, int32_t D1, int a_
 }
 
 // ---- lexical table: keys packed (src+1)<<32 | (tgt+1), sorted ascending ----
-struct cgx_lexview { const uint64_t *key; const float *v1, *v2, *n1, *n2; uint32_t n; };  // n1/n2 = -log10f(v1/v2), precomputed on the host
+struct cgx_lexview {
+    const uint64_t *key; const float *v1, *v2, *n1, *n2; uint32_t n;    // n1/n2 = -log10f(v1/v2), precomputed on the host
+    const uint32_t *row;     // row[s] = first entry whose (src+1) >= s, s = 0..nrow; the table is sorted by (src+1, tgt+1)
+    const int32_t *nullt;    // entry index of (NULL, tgt) per target id, -1 if absent
+    uint32_t nrow, ntgt;     // valid src+1 values are < nrow; target ids are < ntgt
+};
 CGX_HD uint64_t cgx_lexkey_pack(int32_t src, int32_t tgt) { return ((uint64_t)(uint32_t)(src + 1) << 32) | (uint32_t)(tgt + 1); }
+// index of the (src,tgt) row or -1.  Replaces searchLexFile's binary search over the whole table
+// (ExtractPair.cu:2108-2142): a per-source row pointer narrows the search to that word's few
+// translations, and (NULL,tgt) is a direct table.
 CGX_HD int64_t cgx_lex_find(const cgx_lexview &t, int32_t src, int32_t tgt) {
-    uint64_t k = cgx_lexkey_pack(src, tgt);
-    int64_t lo = 0, hi = (int64_t)t.n - 1;
-    while (lo <= hi) { int64_t m = lo + ((hi - lo) >> 1); uint64_t x = t.key[m]; if (k < x) hi = m - 1; else if (k > x) lo = m + 1; else return m; }
+    if (src < -1 || tgt < -1) return -1;
+    if (src == -1 && tgt >= 0) return (uint32_t)tgt < t.ntgt ? (int64_t)t.nullt[tgt] : -1;
+    uint32_t s = (uint32_t)(src + 1);
+    if (s >= t.nrow) return -1;
+    int64_t lo = t.row[s], hi = (int64_t)t.row[s + 1] - 1;
+    const uint32_t want = (uint32_t)(tgt + 1);
+    while (lo <= hi) { int64_t m = lo + ((hi - lo) >> 1); uint32_t x = (uint32_t)t.key[m]; if (want < x) hi = m - 1; else if (want > x) lo = m + 1; else return m; }
     return -1;
 }
 

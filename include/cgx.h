@@ -73,7 +73,7 @@ typedef struct {
 cgx_ctx *cgx_create(int device);                       /* replaces suffixArraySearchInit (SuffixArray.cu:769) */
 void cgx_destroy(cgx_ctx *ctx);                        /* replaces suffixArraySearchFinalize*, extractPairFinalize */
 const char *cgx_last_error(cgx_ctx *ctx);
-int cgx_set_option(cgx_ctx *ctx, const char *name, int64_t value); /* "k1_limit" (default 128), "chunk_items", "force_host_lexicon" */
+int cgx_set_option(cgx_ctx *ctx, const char *name, int64_t value); /* "k1_limit" (default 128), "chunk_items", "force_host_lexicon", "async_write" */
 
 /* ---- index: upload, device suffix-array construction, frequent-pair precomputation ---- */
 int cgx_upload_index(cgx_ctx *ctx, const cgx_index_host *ix);   /* H2D of the index (SuffixArray.cu:1396-1412, ExtractPair.cu:3279-3282) */
@@ -81,7 +81,9 @@ int cgx_build_sa(cgx_ctx *ctx);                                 /* replaces suff
 int cgx_precompute(cgx_ctx *ctx);                               /* replaces preComputation + precomp kernel (SuffixArray.cu:1132-1340) */
 /* multi-GPU: allocate an empty replica of given sizes, then move buffers device-to-device
  * (dir 0: index buffer -> dptr, dir 1: dptr -> index buffer) around a collective broadcast. */
-int cgx_index_alloc(cgx_ctx *ctx, uint32_t n, uint32_t nt, uint32_t nlex, uint32_t nphits, int32_t last);
+typedef struct { uint32_t n, nt, nlex, nphits; int32_t last; uint32_t lex_nrow, lex_ntgt; } cgx_index_dims;
+int cgx_index_shape(cgx_ctx *ctx, cgx_index_dims *dims);        /* sizes of a built index (root rank) */
+int cgx_index_alloc(cgx_ctx *ctx, const cgx_index_dims *dims);  /* empty replica of the same sizes (other ranks) */
 int cgx_index_nbuffers(cgx_ctx *ctx);
 int cgx_index_buffer(cgx_ctx *ctx, int i, const char **name, uint64_t *nbytes);
 int cgx_index_d2d(cgx_ctx *ctx, int i, void *dptr, int dir);
@@ -120,6 +122,9 @@ int cgx_extract_grammars(cgx_ctx *ctx, const cgx_corpus *c, const char *qryfile,
 /* same on an id-level batch (bench / tests): corpus may have no spellings, words print as s<id>/t<id> */
 int cgx_extract_grammars_ids(cgx_ctx *ctx, const cgx_corpus *c, const int32_t *qoff, int32_t nq, const int32_t *qtok,
                              int32_t ntok, const char *outdir, int32_t first_query_index, uint64_t *nrules);
+/* with option "async_write" the files of a batch are written in the background while the next batch runs on the GPU;
+ * cgx_flush waits for them (also done by the next cgx_extract_grammars* call and by cgx_destroy) */
+int cgx_flush(cgx_ctx *ctx);
 cgx_corpus *cgx_corpus_from_ids(const int32_t *str, uint32_t n, const int32_t *sentind, int32_t nsent,
                                 const int32_t *tstr, uint32_t nt, const int32_t *tsentind,
                                 const uint8_t *lsrc, const uint8_t *rsrc, const uint8_t *ltar, const uint8_t *rtar,

@@ -116,7 +116,14 @@ int main(int argc, char **argv) {
         uint32_t nlex = hdr[5]; const orc_lexkey *lk = arr<orc_lexkey>(d, "lexk"); const orc_lexval *lv = arr<orc_lexval>(d, "lexv");
         std::vector<uint64_t> key(nlex); std::vector<float> v1(nlex), v2(nlex), n1v(nlex), n2v(nlex);
         for (uint32_t i = 0; i < nlex; i++) { key[i] = cgx_lexkey_pack(lk[i].src, lk[i].tgt); v1[i] = lv[i].v1; v2[i] = lv[i].v2; n1v[i] = -log10f(lv[i].v1); n2v[i] = -log10f(lv[i].v2); }
-        cgx_lexview t{key.data(), v1.data(), v2.data(), n1v.data(), n2v.data(), nlex};
+        uint32_t maxs = 0, maxt = 0;
+        for (uint32_t i = 0; i < nlex; i++) { uint32_t a = (uint32_t)(key[i] >> 32), b = (uint32_t)key[i]; if (a > maxs) maxs = a; if (b > maxt) maxt = b; }
+        uint32_t nrow = maxs + 1, ntgt = maxt;
+        std::vector<uint32_t> row((size_t)nrow + 2, nlex); std::vector<int32_t> nullt((size_t)ntgt + 1, -1);
+        for (uint32_t i = nlex; i-- > 0;) row[(size_t)(key[i] >> 32)] = i;
+        for (size_t a = nrow; a-- > 0;) if (row[a] == nlex || row[a] > row[a + 1]) row[a] = row[a + 1];
+        for (uint32_t i = 0; i < nlex && (key[i] >> 32) == 0; i++) { uint32_t b = (uint32_t)key[i]; if (b >= 1) nullt[b - 1] = (int32_t)i; }
+        cgx_lexview t{key.data(), v1.data(), v2.data(), n1v.data(), n2v.data(), nlex, row.data(), nullt.data(), nrow, ntgt};
         const orc_lextask *tk = arr<orc_lextask>(d, "tasks"); size_t nt = cnt<orc_lextask>(d, "tasks");
         const float *fe = arr<float>(d, "task_fe"), *ef = arr<float>(d, "task_ef");
         size_t nl1 = cnt<int32_t>(d, "lex1_int") / 4, nl2 = cnt<int32_t>(d, "lex2_int") / 4;

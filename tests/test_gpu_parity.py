@@ -151,6 +151,20 @@ def test_chunking_and_sharding_do_not_change_results(cgx, fixtures_dir, tmp_path
     ex.close(); corpus.close(); corpus2.close()
 
 
+def test_async_writer_gives_the_same_files(cgx, fixtures_dir, tmp_path):
+    """async_write: batch k is written by host threads while batch k+1 runs; after cgx_flush the files are identical."""
+    fx = make_fixture("mid", fixtures_dir); files = op.fixture_args(fx)
+    ex = cgx.Extractor(0); ex.set_option("async_write", 1)
+    corpus = cgx.Corpus.load(files[0], files[2], files[3], files[4]); ex.upload_corpus(corpus)
+    out = tmp_path / "a"; out.mkdir()
+    n1 = ex.extract_grammars(corpus, files[1], str(out), 0, 17)
+    n2 = ex.extract_grammars(corpus, files[1], str(out), 17, 40)
+    ex.flush()
+    assert op.sha_dir(str(out), 40) == META["mid"]["grammar"]
+    assert n1 + n2 == sum(sum(1 for _ in open(out / ("grammar.%d.s" % q), "rb")) for q in range(40))
+    ex.close(); corpus.close()
+
+
 def test_id_level_batch_on_synthetic_corpus(cgx, tmp_path):
     """bench.py's path: corpus from id arrays; suffix array property check + oracle parity through liboracle."""
     import ctypes as C
