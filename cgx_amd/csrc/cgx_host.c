@@ -29,6 +29,8 @@
 #include <time.h>
 #include <pthread.h>
 #include <unistd.h>
+#include <fcntl.h>
+#include <sys/types.h>
 
 #define SAMPLER 300
 #define LONGEST_SRC 5
@@ -252,6 +254,17 @@ cgx_corpus *cgx_corpus_from_ids(const int32_t *str, uint32_t n, const int32_t *s
     for (int32_t q = 0; q < nsent; q++) for (int32_t i = sentind[q]; i < sentind[q + 1] - 1; i++) c->P[i] = (uint8_t)(i - sentind[q]);
     if (pack_alignment(c, lsrc, rsrc)) { cgx_corpus_free(c); return NULL; }
     c->maxword = 16;
+    /* no spellings were given: words print as s<id> / t<id>; build them once */
+    int32_t maxs = 0, maxt = 0;
+    for (uint32_t i = 0; i < n; i++) if (str[i] > maxs) maxs = str[i];
+    for (uint32_t i = 0; i < nt; i++) if (tstr[i] > maxt) maxt = tstr[i];
+    c->nsvocab = maxs + 1; c->ntvocab = maxt + 1;
+    c->svocab = calloc((size_t)c->nsvocab + 1, sizeof(char *)); c->tvocab = calloc((size_t)c->ntvocab + 1, sizeof(char *));
+    c->svlen = calloc((size_t)c->nsvocab + 1, 4); c->tvlen = calloc((size_t)c->ntvocab + 1, 4);
+    if (!c->svocab || !c->tvocab || !c->svlen || !c->tvlen) { cgx_corpus_free(c); return NULL; }
+    char tmp[24];
+    for (int32_t i = 2; i < c->nsvocab; i++) { c->svlen[i] = (uint32_t)snprintf(tmp, sizeof tmp, "s%d", i); c->svocab[i] = strdup(tmp); }
+    for (int32_t i = 2; i < c->ntvocab; i++) { c->tvlen[i] = (uint32_t)snprintf(tmp, sizeof tmp, "t%d", i); c->tvocab[i] = strdup(tmp); }
     return c;
 }
 
@@ -552,7 +565,14 @@ static int sb_need(sbuf *s, size_t extra) { if (s->n + extra + 1 > s->cap) { siz
 /* The formatter below appends through a raw cursor; the caller reserves line_max() bytes per line first. */
 static size_t line_max(const cgx_corpus *c) { return 512 + 32 * ((size_t)c->maxword + 8); }
 #define PUT_LIT(p, lit) do { memcpy((p), (lit), sizeof(lit) - 1); (p) += sizeof(lit) - 1; } while (0)
-static inline char *put_uint(char *p, uint32_t v) { char t[12]; int k = 0; do { t[k++] = (char)('0' + v % 10); v /= 10; } while (v); while (k) *p++ = t[--k]; return p; }
+static const char DIG2[201] = "00010203040506070809101112131415161718192021222324252627282930313233343536373839404142434445464748495051525354555657585960616263646566676869707172737475767778798081828384858687888990919293949596979899";
+static inline char *put_uint(char *p, uint32_t v) {
+    char t[12]; int k = 12;
+    while (v >= 100) { uint32_t r = v % 100; v /= 100; k -= 2; memcpy(t + k, DIG2 + 2 * r, 2); }
+    if (v >= 10) { k -= 2; memcpy(t + k, DIG2 + 2 * v, 2); } else t[--k] = (char)('0' + v);
+    memcpy(p, t + k, (size_t)(12 - k));
+    return p + (12 - k);
+}
 static inline char *put_word(char *p, const cgx_corpus *c, int target, int32_t id) {
     char **voc = target ? c->tvocab : c->svocab; int32_t nv = target ? c->ntvocab : c->nsvocab;
     if (voc && id >= 0 && id < nv && voc[id]) { uint32_t L = (target ? c->tvlen : c->svlen)[id]; memcpy(p, voc[id], L); return p + L; }
@@ -602,9 +622,16 @@ static char *put_target(char *p, const batch *b, const cgx_lexent *e) {
 /* feature values depend only on (paircount, fsample) <= 300 each (ExtractPair.c:652-656): tabulated once with the host libm */
 #define TABN 302
 static float g_aa[TABN][TABN], g_bb[TABN], g_fs[TABN]; static int g_tab_ready;
+static char g_aa_s[TABN][TABN][12], g_bb_s[TABN][12], g_fs_s[TABN][12];      /* the same values already formatted with %f */
+static uint8_t g_aa_l[TABN][TABN], g_bb_l[TABN], g_fs_l[TABN];
+static inline char *put_f6(char *p, float x);
 static void score_tables(void) {
     if (g_tab_ready) return;
-    for (int p = 0; p < TABN; p++) { g_bb[p] = (float)log10((double)(1 + p)); g_fs[p] = (float)log10((double)(1 + p)); for (int f = 1; f < TABN; f++) g_aa[p][f] = -log10f((float)p / (float)f); }
+    for (int p = 0; p < TABN; p++) {
+        g_bb[p] = (float)log10((double)(1 + p)); g_fs[p] = (float)log10((double)(1 + p));
+        g_bb_l[p] = (uint8_t)(put_f6(g_bb_s[p], g_bb[p]) - g_bb_s[p]); g_fs_l[p] = (uint8_t)(put_f6(g_fs_s[p], g_fs[p]) - g_fs_s[p]);
+        for (int f = 1; f < TABN; f++) { g_aa[p][f] = -log10f((float)p / (float)f); g_aa_l[p][f] = (uint8_t)(put_f6(g_aa_s[p][f], g_aa[p][f]) - g_aa_s[p][f]); }
+    }
     g_tab_ready = 1;
 }
 /* "%f" of a float: the value times 10^6 is exact in double (24 + 14 significant bits), so
@@ -613,11 +640,12 @@ static inline char *put_f6(char *p, float x) {
     double v = (double)x;
     if (!(fabs(v) < 1e12)) return p + snprintf(p, 64, "%f", v);
     if (signbit(v)) { *p++ = '-'; v = -v; }
-    uint64_t m = (uint64_t)rint(v * 1e6), ip = m / 1000000u, fp = m % 1000000u;
-    char tmp[24]; int k = 0; do { tmp[k++] = (char)('0' + ip % 10); ip /= 10; } while (ip);
-    while (k) *p++ = tmp[--k];
+    uint64_t m = (uint64_t)llrint(v * 1e6);                 /* current rounding mode = to nearest even, like printf */
+    uint32_t fp = (uint32_t)(m % 1000000u); uint64_t ip = m / 1000000u;
+    if (ip < 0xFFFFFFFFull) p = put_uint(p, (uint32_t)ip);
+    else { char tmp[24]; int k = 0; do { tmp[k++] = (char)('0' + ip % 10); ip /= 10; } while (ip); while (k) *p++ = tmp[--k]; }
     *p++ = '.';
-    for (int d = 5; d >= 0; d--) { p[d] = (char)('0' + fp % 10); fp /= 10; }
+    memcpy(p, DIG2 + 2 * (fp / 10000u), 2); memcpy(p + 2, DIG2 + 2 * (fp / 100u % 100u), 2); memcpy(p + 4, DIG2 + 2 * (fp % 100u), 2);
     return p + 6;
 }
 static int sb_f6(sbuf *s, float x) { if (sb_need(s, 64)) return -1; s->n = (size_t)(put_f6(s->p + s->n, x) - s->p); return 0; }
@@ -630,13 +658,17 @@ static int emit_range(sbuf *s, const batch *b, int kind, const cgx_lexent *lex, 
         const cgx_lexent *e = &lex[i];
         if (sb_need(s, lmax)) return -1;
         char *p = s->p + s->n;
-        int pc = e->paircount < TABN ? e->paircount : TABN - 1, f = e->fsample < TABN ? e->fsample : TABN - 1;
-        float aa = (e->paircount < TABN && e->fsample < TABN && e->fsample > 0) ? g_aa[pc][f] : -log10f((float)e->paircount / (float)e->fsample);
-        float bb = e->paircount < TABN ? g_bb[pc] : (float)log10((double)(1 + e->paircount)), fsc = e->fsample < TABN ? g_fs[f] : (float)log10((double)(1 + e->fsample));
+        const int tab = e->paircount < TABN && e->fsample < TABN && e->fsample > 0 && e->paircount > 0;
+        const int pc = e->paircount, f = e->fsample;
         PUT_LIT(p, "[X] ||| ");
         if (srclen) { memcpy(p, srcbuf, srclen); p += srclen; } else p = put_source(p, b, kind, (uint32_t)e->id);
         PUT_LIT(p, " ||| "); p = put_target(p, b, e);
-        PUT_LIT(p, " ||| EgivenFCoherent="); p = put_f6(p, aa); PUT_LIT(p, " SampleCountF="); p = put_f6(p, fsc); PUT_LIT(p, " CountEF="); p = put_f6(p, bb);
+        PUT_LIT(p, " ||| EgivenFCoherent=");
+        if (tab) { memcpy(p, g_aa_s[pc][f], 12); p += g_aa_l[pc][f]; PUT_LIT(p, " SampleCountF="); memcpy(p, g_fs_s[f], 12); p += g_fs_l[f]; PUT_LIT(p, " CountEF="); memcpy(p, g_bb_s[pc], 12); p += g_bb_l[pc]; }
+        else {
+            p = put_f6(p, -log10f((float)e->paircount / (float)e->fsample)); PUT_LIT(p, " SampleCountF="); p = put_f6(p, (float)log10((double)(1 + e->fsample)));
+            PUT_LIT(p, " CountEF="); p = put_f6(p, (float)log10((double)(1 + e->paircount)));
+        }
         PUT_LIT(p, " MaxLexFgivenE="); p = put_f6(p, e->fe); PUT_LIT(p, " MaxLexEgivenF="); p = put_f6(p, e->ef);
         PUT_LIT(p, " IsSingletonF="); *p++ = e->f == 1 ? '1' : '0'; PUT_LIT(p, " IsSingletonFE="); *p++ = e->paircount == 1 ? '1' : '0'; *p++ = '\n';
         s->n = (size_t)(p - s->p);
@@ -667,10 +699,14 @@ static void *write_worker(void *arg) {
         for (uint32_t k = 0; !bad && b->qtwo && k < b->qtwo[q].n; k++) bad = emit_range(&s, b, 2, b->L2, b->rng2, G + b->qtwo[q].v[k], lines);
         if (bad) { w->rc = CGX_ERR_NOMEM; break; }
         snprintf(fn, sizeof fn, "%s/grammar.%d.s", w->outdir, w->first + q);
-        FILE *fp = fopen(fn, "w");
-        if (!fp) { w->rc = CGX_ERR_IO; break; }
-        if (s.n && fwrite(s.p, 1, s.n, fp) != s.n) { fclose(fp); w->rc = CGX_ERR_IO; break; }
-        fclose(fp);
+        /* overwrite in place and cut to length: same bytes as fopen(fn,"w"), but an existing file keeps its pages */
+        int fd = open(fn, O_WRONLY | O_CREAT, 0644);
+        if (fd < 0) { w->rc = CGX_ERR_IO; break; }
+        size_t off = 0; int bad_io = 0;
+        while (off < s.n) { ssize_t k = write(fd, s.p + off, s.n - off); if (k <= 0) { bad_io = 1; break; } off += (size_t)k; }
+        if (!bad_io && ftruncate(fd, (off_t)s.n)) bad_io = 1;
+        close(fd);
+        if (bad_io) { w->rc = CGX_ERR_IO; break; }
     }
     free(s.p);
     return NULL;
