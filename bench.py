@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--cpu-pairs", type=int, default=100000)
     ap.add_argument("--cpu-queries", type=int, default=48)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend; nccl (= RCCL over xGMI) for real runs, gloo only to rehearse N>1 on a one-GPU box")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--sync-write", action="store_true", help="write each step's files before starting the next step")
     ap.add_argument("--no-write", action="store_true", help="format nothing, write no files (kernel-side study only; not the headline)")
     args = ap.parse_args()
@@ -100,12 +102,13 @@ def main():
     import cgx_amd
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl")
+    if args.single_device:
+        local = 0
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the extractor has no CPU fallback")
     torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group(args.backend)
     ex = cgx_amd.Extractor(local)
     if not args.sync_write:
         ex.set_option("async_write", 1)       # files of step k are written by host threads while the GPU runs step k+1; flushed inside the timed region
