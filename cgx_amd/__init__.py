@@ -204,7 +204,7 @@ class Extractor:
         return out
 
     def index_shape(self):
-        d = np.zeros(7, np.int32)
+        d = np.zeros(8, np.int32)
         self._chk(self.lib.cgx_index_shape(self.h, _ptr(d)), "cgx_index_shape")
         return [int(x) for x in d]
 

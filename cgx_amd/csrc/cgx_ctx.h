@@ -29,6 +29,8 @@ struct cgx_ctx {
     uint32_t *d_lexrow = nullptr; int32_t *d_lexnullt = nullptr; uint32_t lex_nrow = 0, lex_ntgt = 0;
     int32_t *d_tokstart = nullptr; int8_t *d_tokrank = nullptr; int32_t *d_freq = nullptr;
     uint32_t *d_pidx = nullptr; int32_t *d_miss = nullptr; uint32_t *d_phit_start = nullptr; uint8_t *d_phit_len = nullptr;
+    uint64_t *d_bg_key = nullptr; uint32_t *d_bg_lo = nullptr, *d_bg_hi = nullptr; uint32_t bg_cap = 0; unsigned bg_shift = 0;   // bigram -> SA interval
+    bool use_bigrams = true;
     int32_t freq[100] = {0};
 
     // ---- batch ----

@@ -203,7 +203,7 @@ static void free_index(cgx_ctx *c) {
     dfree(c->d_str); dfree(c->d_sa); dfree(c->d_rlp); dfree(c->d_tstr); dfree(c->d_ltar); dfree(c->d_rtar);
     dfree(c->d_lexkey); dfree(c->d_lexv1); dfree(c->d_lexv2); dfree(c->d_lexn1); dfree(c->d_lexn2); dfree(c->d_lexrow); dfree(c->d_lexnullt);
     dfree(c->d_tokstart); dfree(c->d_tokrank); dfree(c->d_freq); dfree(c->d_pidx); dfree(c->d_miss);
-    dfree(c->d_phit_start); dfree(c->d_phit_len);
+    dfree(c->d_phit_start); dfree(c->d_phit_len); dfree(c->d_bg_key); dfree(c->d_bg_lo); dfree(c->d_bg_hi); c->bg_cap = 0;
     c->n = c->nt = c->nlex = c->nphits = 0; c->have_sa = c->have_pre = false;
 }
 extern "C" void cgx_destroy(cgx_ctx *c) {
@@ -220,6 +220,7 @@ extern "C" const char *cgx_last_error(cgx_ctx *c) { return c ? c->err : "null co
 extern "C" int cgx_set_option(cgx_ctx *c, const char *name, int64_t value) {
     if (!c || !name) return CGX_ERR_ARG;
     if (!strcmp(name, "k1_limit")) { c->k1_limit = (int)value; return CGX_OK; }
+    if (!strcmp(name, "use_bigrams")) { c->use_bigrams = value != 0; return CGX_OK; }
     if (!strcmp(name, "async_write")) { c->async_write = value != 0; return CGX_OK; }
     if (!strcmp(name, "force_host_lexicon")) { c->force_host_lexicon = value != 0; return CGX_OK; }
     if (!strcmp(name, "chunk_items")) { if (value < 1024) return CGX_ERR_ARG; c->chunk_items = (uint64_t)value; return CGX_OK; }
@@ -401,6 +402,7 @@ static int install_freq(cgx_ctx *ctx, const int32_t *freq) {
     memcpy(ctx->freq, freq, sizeof ctx->freq);
     return CGX_OK;
 }
+static int build_bigrams(cgx_ctx *ctx);
 extern "C" int cgx_precompute(cgx_ctx *ctx) {
     if (!ctx || !ctx->d_str || !ctx->d_tokstart) return CGX_ERR_STATE;
     HIPCHK(hipSetDevice(ctx->device));
@@ -438,6 +440,61 @@ extern "C" int cgx_precompute(cgx_ctx *ctx) {
     dfree(keys); dfree(skeys); dfree(counter);
     ctx->nphits = cnt; ctx->have_pre = true;
     ctx->ms["precompute"] = tm.stop();
+    Timer tb(ctx->stream);
+    TRY(build_bigrams(ctx));
+    ctx->ms["bigrams"] = tb.stop();
+    return CGX_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// bigram table: SA interval of every 2-token phrase of the corpus in an open-addressing hash
+// table (key = tok0<<32|tok1, linear probing).  The interval search for l = 2 - the longest
+// binary search of the reference's K2, up to log2(count of a frequent token) dependent probe
+// pairs - becomes one or two probes; longer phrases are refined inside the bigram interval.
+// Built once per index from the suffix array (runs of equal first-two-tokens are contiguous).
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t bigram_key_at(const int32_t *str, const int32_t *sa, uint32_t i) {
+    int32_t p = sa[i]; int32_t a = str[p], b = str[p + 1];
+    return (a >= 2 && b >= 2) ? (((uint64_t)(uint32_t)a << 32) | (uint32_t)b) : 0ull;     // 0 = not a bigram (delimiter inside)
+}
+__device__ __forceinline__ uint32_t bigram_slot(uint64_t key, unsigned shift) { return (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> shift); }
+__global__ void k_bigram_count(const int32_t *str, const int32_t *sa, uint32_t n, unsigned int *count) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    bool head = false;
+    if (i < n) { uint64_t k = bigram_key_at(str, sa, (uint32_t)i); head = k != 0 && (i == 0 || bigram_key_at(str, sa, (uint32_t)i - 1) != k); }
+    unsigned long long m = __ballot(head);
+    if (m && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)m) - 1)) atomicAdd(count, (unsigned int)__popcll(m));
+}
+__global__ void k_bigram_fill(const int32_t *str, const int32_t *sa, uint32_t n, unsigned long long *keys, uint32_t *lo, uint32_t *hi, uint32_t mask, unsigned shift) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t k = bigram_key_at(str, sa, (uint32_t)i);
+    if (k == 0) return;
+    bool head = i == 0 || bigram_key_at(str, sa, (uint32_t)i - 1) != k;
+    bool tail = i + 1 == n || bigram_key_at(str, sa, (uint32_t)i + 1) != k;
+    if (!head && !tail) return;
+    uint32_t s = bigram_slot(k, shift) & mask;
+    for (;;) {                                             // claim or find the slot of this key
+        unsigned long long prev = atomicCAS(&keys[s], 0ull, (unsigned long long)k);
+        if (prev == 0ull || prev == k) break;
+        s = (s + 1) & mask;
+    }
+    if (head) lo[s] = (uint32_t)i;
+    if (tail) hi[s] = (uint32_t)i;
+}
+static int build_bigrams(cgx_ctx *ctx) {
+    dfree(ctx->d_bg_key); dfree(ctx->d_bg_lo); dfree(ctx->d_bg_hi); ctx->bg_cap = 0;
+    unsigned int *cnt = nullptr; TRY(dalloc(ctx, &cnt, 1)); HIPCHK(hipMemsetAsync(cnt, 0, 4, ctx->stream));
+    k_bigram_count<<<nblocks(ctx->n, 256), 256, 0, ctx->stream>>>(ctx->d_str, ctx->d_sa, ctx->n, cnt);
+    unsigned int distinct = 0; TRY(d2h(ctx, &distinct, cnt, 1)); dfree(cnt);
+    uint64_t cap = 1024; while (cap < (uint64_t)distinct * 2) cap <<= 1;
+    if (cap > (1ull << 31)) { snprintf(ctx->err, sizeof ctx->err, "bigram table too large"); return CGX_ERR_NOMEM; }
+    ctx->bg_cap = (uint32_t)cap; ctx->bg_shift = 64 - (unsigned)bits_for(cap - 1);
+    TRY(dalloc(ctx, &ctx->d_bg_key, cap)); TRY(dalloc(ctx, &ctx->d_bg_lo, cap)); TRY(dalloc(ctx, &ctx->d_bg_hi, cap));
+    HIPCHK(hipMemsetAsync(ctx->d_bg_key, 0, cap * 8, ctx->stream));
+    k_bigram_fill<<<nblocks(ctx->n, 256), 256, 0, ctx->stream>>>(ctx->d_str, ctx->d_sa, ctx->n, (unsigned long long *)ctx->d_bg_key, ctx->d_bg_lo, ctx->d_bg_hi, (uint32_t)(cap - 1), ctx->bg_shift);
+    HIPCHK(hipStreamSynchronize(ctx->stream)); HIPCHK(hipGetLastError());
+    ctx->ms["bigrams_distinct"] = distinct;
     return CGX_OK;
 }
 
@@ -467,18 +524,21 @@ static std::vector<bufdesc> index_buffers(cgx_ctx *c) {
     b.push_back({"miss", (void **)&c->d_miss, CGX_TOP * CGX_TOP * 4});
     b.push_back({"phit_start", (void **)&c->d_phit_start, (uint64_t)c->nphits * 4});
     b.push_back({"phit_len", (void **)&c->d_phit_len, (uint64_t)c->nphits});
+    b.push_back({"bg_key", (void **)&c->d_bg_key, (uint64_t)c->bg_cap * 8});
+    b.push_back({"bg_lo", (void **)&c->d_bg_lo, (uint64_t)c->bg_cap * 4});
+    b.push_back({"bg_hi", (void **)&c->d_bg_hi, (uint64_t)c->bg_cap * 4});
     return b;
 }
 extern "C" int cgx_index_shape(cgx_ctx *ctx, cgx_index_dims *d) {
     if (!ctx || !d) return CGX_ERR_ARG;
-    d->n = ctx->n; d->nt = ctx->nt; d->nlex = ctx->nlex; d->nphits = ctx->nphits; d->last = ctx->last; d->lex_nrow = ctx->lex_nrow; d->lex_ntgt = ctx->lex_ntgt;
+    d->n = ctx->n; d->nt = ctx->nt; d->nlex = ctx->nlex; d->nphits = ctx->nphits; d->last = ctx->last; d->lex_nrow = ctx->lex_nrow; d->lex_ntgt = ctx->lex_ntgt; d->bigram_cap = ctx->bg_cap;
     return CGX_OK;
 }
 extern "C" int cgx_index_alloc(cgx_ctx *ctx, const cgx_index_dims *d) {
     if (!ctx || !d) return CGX_ERR_ARG;
     HIPCHK(hipSetDevice(ctx->device));
     free_batch(ctx); free_index(ctx);
-    ctx->n = d->n; ctx->nt = d->nt; ctx->nlex = d->nlex; ctx->nphits = d->nphits; ctx->last = d->last; ctx->lex_nrow = d->lex_nrow; ctx->lex_ntgt = d->lex_ntgt;
+    ctx->n = d->n; ctx->nt = d->nt; ctx->nlex = d->nlex; ctx->nphits = d->nphits; ctx->last = d->last; ctx->lex_nrow = d->lex_nrow; ctx->lex_ntgt = d->lex_ntgt; ctx->bg_cap = d->bigram_cap; ctx->bg_shift = d->bigram_cap ? 64 - (unsigned)bits_for((uint64_t)d->bigram_cap - 1) : 0;
     for (auto &b : index_buffers(ctx)) TRY(dalloc_bytes(ctx, b.ptr, b.bytes ? b.bytes : 1));
     return CGX_OK;
 }
@@ -570,7 +630,8 @@ extern "C" int cgx_upload_queries(cgx_ctx *ctx, const int32_t *qoff, int32_t nq,
 // ------------------------------------------------------------------------------------
 #define LOOK_BS 256
 __global__ __launch_bounds__(LOOK_BS) void k_sa_lookup(const int32_t *__restrict__ str, const int32_t *__restrict__ sa,
-        const int32_t *__restrict__ tokstart, const int32_t *__restrict__ qtok, const int32_t *__restrict__ qoff,
+        const int32_t *__restrict__ tokstart, const uint64_t *__restrict__ bg_key, const uint32_t *__restrict__ bg_lo, const uint32_t *__restrict__ bg_hi,
+        uint32_t bg_mask, unsigned bg_shift, const int32_t *__restrict__ qtok, const int32_t *__restrict__ qoff,
         const int32_t *__restrict__ tok2q, int32_t ntok, int k1_limit,
         int32_t *__restrict__ lm, int32_t *__restrict__ up, int32_t *__restrict__ down) {
     __shared__ int32_t s_tok[LOOK_BS + 8];
@@ -589,11 +650,20 @@ __global__ __launch_bounds__(LOOK_BS) void k_sa_lookup(const int32_t *__restrict
         int32_t lo = tokstart[c0], hi = tokstart[c0 + 1] - 1;
         if (lo <= hi) {
             r_up[0] = lo; r_dn[0] = hi; len = 1;
-            for (int l = 1; l < 5; l++) {
+            int l = 1;
+            if (bg_key && t + 1 < qe && s_tok[threadIdx.x + 1] >= 2) {      // l = 2 from the bigram table
+                const uint64_t key = ((uint64_t)(uint32_t)c0 << 32) | (uint32_t)s_tok[threadIdx.x + 1];
+                uint32_t s = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> bg_shift) & bg_mask;
+                uint64_t k = bg_key[s];
+                while (k != 0 && k != key) { s = (s + 1) & bg_mask; k = bg_key[s]; }
+                if (k == key) { lo = (int32_t)bg_lo[s]; hi = (int32_t)bg_hi[s]; r_up[1] = lo; r_dn[1] = hi; len = 2; l = 2; }
+                else l = 5;                                                  // the bigram does not occur: longestmatch = 1
+            }
+            for (; l < 5; l++) {
                 if (t + l >= qe) break;
                 const int32_t c = s_tok[threadIdx.x + l];
                 if (c < 2) break;
-                // first m in [lo,hi+1) with tok(m) >= c, and first with tok(m) > c
+                // first m in [lo,hi+1) with tok(m) >= c, and first with tok(m) > c; both searches advance together
                 int32_t a0 = lo, z0 = hi + 1, a1 = lo, z1 = hi + 1;
                 while (a0 < z0 || a1 < z1) {
                     int32_t m0 = (a0 + z0) >> 1, m1 = (a1 + z1) >> 1;
@@ -622,7 +692,8 @@ extern "C" int cgx_sa_lookup(cgx_ctx *ctx) {
     if (T > 0) {
         hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
         HIPCHK(hipEventRecord(a, ctx->stream));
-        k_sa_lookup<<<nblocks(T, LOOK_BS), LOOK_BS, 0, ctx->stream>>>(ctx->d_str, ctx->d_sa, ctx->d_tokstart, ctx->d_qtok, ctx->d_qoff,
+        k_sa_lookup<<<nblocks(T, LOOK_BS), LOOK_BS, 0, ctx->stream>>>(ctx->d_str, ctx->d_sa, ctx->d_tokstart, ctx->use_bigrams ? ctx->d_bg_key : nullptr, ctx->d_bg_lo, ctx->d_bg_hi,
+                                                                     ctx->bg_cap ? ctx->bg_cap - 1 : 0, ctx->bg_shift, ctx->d_qtok, ctx->d_qoff,
                                                                      ctx->d_tok2q, T, ctx->k1_limit, ctx->d_lm, ctx->d_up, ctx->d_down);
         HIPCHK(hipEventRecord(b, ctx->stream)); HIPCHK(hipEventSynchronize(b));
         float ms = 0; HIPCHK(hipEventElapsedTime(&ms, a, b)); ctx->ms["sa_lookup_kernel"] = ms;

@@ -73,7 +73,7 @@ typedef struct {
 cgx_ctx *cgx_create(int device);                       /* replaces suffixArraySearchInit (SuffixArray.cu:769) */
 void cgx_destroy(cgx_ctx *ctx);                        /* replaces suffixArraySearchFinalize*, extractPairFinalize */
 const char *cgx_last_error(cgx_ctx *ctx);
-int cgx_set_option(cgx_ctx *ctx, const char *name, int64_t value); /* "k1_limit" (default 128), "chunk_items", "force_host_lexicon", "async_write" */
+int cgx_set_option(cgx_ctx *ctx, const char *name, int64_t value); /* "k1_limit" (default 128), "chunk_items", "force_host_lexicon", "async_write", "use_bigrams" (default 1) */
 
 /* ---- index: upload, device suffix-array construction, frequent-pair precomputation ---- */
 int cgx_upload_index(cgx_ctx *ctx, const cgx_index_host *ix);   /* H2D of the index (SuffixArray.cu:1396-1412, ExtractPair.cu:3279-3282) */
@@ -81,7 +81,7 @@ int cgx_build_sa(cgx_ctx *ctx);                                 /* replaces suff
 int cgx_precompute(cgx_ctx *ctx);                               /* replaces preComputation + precomp kernel (SuffixArray.cu:1132-1340) */
 /* multi-GPU: allocate an empty replica of given sizes, then move buffers device-to-device
  * (dir 0: index buffer -> dptr, dir 1: dptr -> index buffer) around a collective broadcast. */
-typedef struct { uint32_t n, nt, nlex, nphits; int32_t last; uint32_t lex_nrow, lex_ntgt; } cgx_index_dims;
+typedef struct { uint32_t n, nt, nlex, nphits; int32_t last; uint32_t lex_nrow, lex_ntgt, bigram_cap; } cgx_index_dims;
 int cgx_index_shape(cgx_ctx *ctx, cgx_index_dims *dims);        /* sizes of a built index (root rank) */
 int cgx_index_alloc(cgx_ctx *ctx, const cgx_index_dims *dims);  /* empty replica of the same sizes (other ranks) */
 int cgx_index_nbuffers(cgx_ctx *ctx);

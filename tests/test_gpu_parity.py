@@ -151,6 +151,24 @@ def test_chunking_and_sharding_do_not_change_results(cgx, fixtures_dir, tmp_path
     ex.close(); corpus.close(); corpus2.close()
 
 
+def test_bigram_table_does_not_change_intervals(cgx, oracle_bin, fixtures_dir, tmp_path):
+    """l = 2 from the bigram hash table vs. by binary search: same lm / up / down (and both equal the oracle)."""
+    fx = make_fixture("toy", fixtures_dir); dump = str(tmp_path / "d.bin")
+    op.run_oracle(oracle_bin, fx, str(tmp_path / "o"), dump)
+    d = op.read_dump(dump); h = d["hdr"]
+    ex = cgx.Extractor(0)
+    ex.upload_index(d["str"][:h["n"]], d["rlp"], d["tstr"][:h["nt"]], d["ltar"], d["rtar"], d["lexk"], d["lexv"])
+    ex.build_sa(); ex.precompute(); ex.upload_queries(d["qoff"][:-1], d["qtok"])
+    res = []
+    for flag in (1, 0):
+        ex.set_option("use_bigrams", flag); ex.sa_lookup()
+        res.append((ex.fetch("lm"), ex.fetch("up"), ex.fetch("down")))
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(res[0][0], np.minimum(d["lm"], 5)) and np.array_equal(res[0][1], d["up"]) and np.array_equal(res[0][2], d["down"])
+    ex.close()
+
+
 def test_async_writer_gives_the_same_files(cgx, fixtures_dir, tmp_path):
     """async_write: batch k is written by host threads while batch k+1 runs; after cgx_flush the files are identical."""
     fx = make_fixture("mid", fixtures_dir); files = op.fixture_args(fx)
