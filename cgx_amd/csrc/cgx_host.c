@@ -72,6 +72,7 @@ struct cgx_corpus {
     uint32_t *rlp; uint8_t *ltar, *rtar;
     char **svocab, **tvocab; int32_t nsvocab, ntvocab;   /* id -> spelling, NULL entries when built from ids */
     uint32_t *svlen, *tvlen; uint32_t maxword;            /* spelling lengths (writer) */
+    struct wslot { uint8_t len; char s[15]; } *svslot, *tvslot;   /* words of <= 15 bytes packed in 16-byte slots: one cache line serves four words */
     wordmap smap, tmap;
     cgx_lexkey *lexk; cgx_lexval *lexv; uint32_t nlex;
 };
@@ -208,11 +209,18 @@ static int load_lex(cgx_corpus *c, const char *path, char *err, size_t errcap) {
     return CGX_OK;
 }
 
+static int build_word_slots(cgx_corpus *c) {
+    c->svslot = calloc((size_t)c->nsvocab + 1, sizeof *c->svslot); c->tvslot = calloc((size_t)c->ntvocab + 1, sizeof *c->tvslot);
+    if (!c->svslot || !c->tvslot) return -1;
+    for (int32_t i = 0; i < c->nsvocab; i++) { uint32_t L = c->svocab[i] ? c->svlen[i] : 0; if (c->svocab[i] && L <= 15) { c->svslot[i].len = (uint8_t)L; memcpy(c->svslot[i].s, c->svocab[i], L); } else c->svslot[i].len = 255; }
+    for (int32_t i = 0; i < c->ntvocab; i++) { uint32_t L = c->tvocab[i] ? c->tvlen[i] : 0; if (c->tvocab[i] && L <= 15) { c->tvslot[i].len = (uint8_t)L; memcpy(c->tvslot[i].s, c->tvocab[i], L); } else c->tvslot[i].len = 255; }
+    return 0;
+}
 void cgx_corpus_free(cgx_corpus *c) {
     if (!c) return;
     for (int32_t i = 0; c->svocab && i < c->nsvocab; i++) free(c->svocab[i]);
     for (int32_t i = 0; c->tvocab && i < c->ntvocab; i++) free(c->tvocab[i]);
-    free(c->svocab); free(c->tvocab); free(c->svlen); free(c->tvlen); wordmap_free(&c->smap); wordmap_free(&c->tmap);
+    free(c->svocab); free(c->tvocab); free(c->svlen); free(c->tvlen); free(c->svslot); free(c->tvslot); wordmap_free(&c->smap); wordmap_free(&c->tmap);
     free(c->str); free(c->tstr); free(c->sentind); free(c->tsentind); free(c->P); free(c->rlp); free(c->ltar); free(c->rtar);
     free(c->lexk); free(c->lexv); free(c);
 }
@@ -232,6 +240,7 @@ cgx_corpus *cgx_corpus_load(const char *src, const char *tgt, const char *align,
     if (!c->svlen || !c->tvlen) goto bad;
     for (int32_t i = 2; i < c->nsvocab; i++) { c->svlen[i] = (uint32_t)strlen(c->svocab[i]); if (c->svlen[i] > c->maxword) c->maxword = c->svlen[i]; }
     for (int32_t i = 2; i < c->ntvocab; i++) { c->tvlen[i] = (uint32_t)strlen(c->tvocab[i]); if (c->tvlen[i] > c->maxword) c->maxword = c->tvlen[i]; }
+    if (build_word_slots(c)) goto bad;
     return c;
 bad:
     cgx_corpus_free(c);
@@ -265,6 +274,7 @@ cgx_corpus *cgx_corpus_from_ids(const int32_t *str, uint32_t n, const int32_t *s
     char tmp[24];
     for (int32_t i = 2; i < c->nsvocab; i++) { c->svlen[i] = (uint32_t)snprintf(tmp, sizeof tmp, "s%d", i); c->svocab[i] = strdup(tmp); }
     for (int32_t i = 2; i < c->ntvocab; i++) { c->tvlen[i] = (uint32_t)snprintf(tmp, sizeof tmp, "t%d", i); c->tvocab[i] = strdup(tmp); }
+    if (build_word_slots(c)) { cgx_corpus_free(c); return NULL; }
     return c;
 }
 
@@ -574,9 +584,14 @@ static inline char *put_uint(char *p, uint32_t v) {
     return p + (12 - k);
 }
 static inline char *put_word(char *p, const cgx_corpus *c, int target, int32_t id) {
-    char **voc = target ? c->tvocab : c->svocab; int32_t nv = target ? c->ntvocab : c->nsvocab;
-    if (voc && id >= 0 && id < nv && voc[id]) { uint32_t L = (target ? c->tvlen : c->svlen)[id]; memcpy(p, voc[id], L); return p + L; }
-    *p++ = target ? 't' : 's';                            /* corpora built from ids have no spellings: s<id> / t<id> */
+    int32_t nv = target ? c->ntvocab : c->nsvocab;
+    if (id >= 0 && id < nv) {
+        const struct wslot *w = &(target ? c->tvslot : c->svslot)[id];
+        if (w->len != 255) { memcpy(p, w->s, 15); return p + w->len; }          /* 15 bytes copied, len kept: the line buffer has headroom */
+        char **voc = target ? c->tvocab : c->svocab;
+        if (voc[id]) { uint32_t L = (target ? c->tvlen : c->svlen)[id]; memcpy(p, voc[id], L); return p + L; }
+    }
+    *p++ = target ? 't' : 's';                            /* no spelling known */
     if (id < 0) { *p++ = '-'; id = -id; }
     return put_uint(p, (uint32_t)id);
 }
@@ -656,6 +671,8 @@ static int emit_range(sbuf *s, const batch *b, int kind, const cgx_lexent *lex, 
     if (lmax < sizeof srcbuf) srclen = (size_t)(put_source(srcbuf, b, kind, (uint32_t)lex[rng[id].down].id) - srcbuf);
     for (int32_t i = rng[id].down; i <= rng[id].up; i++) {
         const cgx_lexent *e = &lex[i];
+        if (i + 8 <= rng[id].up) __builtin_prefetch(&b->c->tstr[lex[i + 8].tstart]);   /* the target words sit at random places of a GB-sized array */
+        if (i + 3 <= rng[id].up) { const cgx_lexent *n = &lex[i + 3]; const int32_t *tw = &b->c->tstr[n->tstart]; __builtin_prefetch(&b->c->tvslot[tw[0]]); __builtin_prefetch(&b->c->tvslot[tw[n->end]]); }
         if (sb_need(s, lmax)) return -1;
         char *p = s->p + s->n;
         const int tab = e->paircount < TABN && e->fsample < TABN && e->fsample > 0 && e->paircount > 0;
@@ -676,6 +693,7 @@ static int emit_range(sbuf *s, const batch *b, int kind, const cgx_lexent *lex, 
     }
     return 0;
 }
+static int g_diag_format_only;
 typedef struct { const batch *b; const char *outdir; int32_t first; int32_t *next; uint64_t lines; int rc; } writejob;
 static void *write_worker(void *arg) {
     writejob *w = arg; const batch *b = w->b;
@@ -700,6 +718,7 @@ static void *write_worker(void *arg) {
         if (bad) { w->rc = CGX_ERR_NOMEM; break; }
         snprintf(fn, sizeof fn, "%s/grammar.%d.s", w->outdir, w->first + q);
         /* overwrite in place and cut to length: same bytes as fopen(fn,"w"), but an existing file keeps its pages */
+        if (g_diag_format_only) continue;                   /* diagnostic (CGX_DIAG_FORMAT_ONLY=1): measure formatting without the file system */
         int fd = open(fn, O_WRONLY | O_CREAT, 0644);
         if (fd < 0) { w->rc = CGX_ERR_IO; break; }
         size_t off = 0; int bad_io = 0;
@@ -714,6 +733,7 @@ static void *write_worker(void *arg) {
 /* one file per query (PrintResults.c:434-446); queries are independent, so a pool of host threads formats them */
 static int write_grammars(const batch *b, const char *outdir, int32_t first, uint64_t *lines) {
     int nt = nthreads_host(); if (nt > b->nq) nt = b->nq > 0 ? b->nq : 1;
+    { const char *e = getenv("CGX_DIAG_FORMAT_ONLY"); g_diag_format_only = e && *e == '1'; }
     writejob jobs[64]; pthread_t th[64]; int32_t next = 0;
     for (int t = 0; t < nt; t++) { jobs[t].b = b; jobs[t].outdir = outdir; jobs[t].first = first; jobs[t].next = &next; jobs[t].lines = 0; jobs[t].rc = CGX_OK; }
     for (int t = 1; t < nt; t++) if (pthread_create(&th[t], NULL, write_worker, &jobs[t])) return CGX_ERR_NOMEM;
