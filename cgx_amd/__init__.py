@@ -40,7 +40,7 @@ FETCH_DTYPES = {
     "phit_len": np.uint8, "lm": np.int32, "up": np.int32, "down": np.int32, "g1": GAPPY, "p1": GAPPAT, "pid1": np.uint32,
     "s1": GAPSEARCH, "hits1": HIT1, "g2": TWOGAPPY, "c2": np.int32, "pid2": np.uint32, "s2": TWOGAPSEARCH, "hits2": HIT2,
     "r0": RULE0, "r1": RULE1, "r2": RULE2, "counts": np.uint32, "p1d": GAPPAT, "c2d": np.int32, "one2": np.uint32,
-    "lex0": LEXENT, "lex1": LEXENT, "lex2": LEXENT,
+    "lex0": LEXENT, "lex1": LEXENT, "lex2": LEXENT, "rng0": np.int32, "rng1": np.int32, "rng2": np.int32,
 }
 COUNT_NAMES = ["e1", "d1", "h1", "e2", "d2", "h2", "g", "n0", "n1", "n2", "sep1", "sep2a", "sep2b", "nphits", "guard_exits", "last"]
 
@@ -50,7 +50,7 @@ ABI = [
     "cgx_index_shape", "cgx_index_alloc", "cgx_index_nbuffers", "cgx_index_buffer", "cgx_index_d2d", "cgx_index_finalize", "cgx_broadcast_index",
     "cgx_upload_queries", "cgx_sa_lookup", "cgx_gappy_search", "cgx_set_blocks", "cgx_extract", "cgx_lexicon", "cgx_lex_features", "cgx_fetch",
     "cgx_stage_ms", "cgx_corpus_load", "cgx_corpus_free", "cgx_corpus_upload", "cgx_extract_grammars", "cgx_extract_grammars_ids",
-    "cgx_corpus_from_ids", "cgx_host_ms", "cgx_flush",
+    "cgx_corpus_from_ids", "cgx_host_ms", "cgx_flush", "cgx_fetch_pinned", "cgx_pinned_next_batch",
 ]
 
 

@@ -45,7 +45,10 @@ struct cgx_ctx {
     uint32_t g = 0; cgx_block *d_blocks = nullptr;
     uint32_t n0 = 0, n1 = 0, n2 = 0, sep1 = 0, sep2a = 0, sep2b = 0, guard_exits = 0;
     cgx_rule0 *d_r0 = nullptr; cgx_rule1 *d_r1 = nullptr; cgx_rule2 *d_r2 = nullptr;
+    int32_t *d_rng0 = nullptr, *d_rng1 = nullptr, *d_rng2 = nullptr;   // id -> [first,last] lexicon line
     cgx_lexent *d_lex0 = nullptr, *d_lex1 = nullptr, *d_lex2 = nullptr; uint32_t nl0 = 0, nl1 = 0, nl2 = 0;
+
+    void *arena[2] = {nullptr, nullptr}; size_t arena_cap[2] = {0, 0}, arena_used[2] = {0, 0}; int arena_sel = 0;   // pinned result arenas
 
     // ---- host-side stage timings of the whole-path driver ----
     std::map<std::string, double> host_ms;

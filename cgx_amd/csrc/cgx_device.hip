@@ -195,7 +195,7 @@ static void free_batch(cgx_ctx *c) {
     dfree(c->d_qoff); dfree(c->d_qtok); dfree(c->d_tok2q); dfree(c->d_lm); dfree(c->d_up); dfree(c->d_down);
     dfree(c->d_g1); dfree(c->d_p1); dfree(c->d_pid1); dfree(c->d_s1); dfree(c->d_hits1);
     dfree(c->d_g2); dfree(c->d_c2); dfree(c->d_pid2); dfree(c->d_s2); dfree(c->d_hits2); dfree(c->d_p1d); dfree(c->d_c2d); dfree(c->d_one2);
-    dfree(c->d_blocks); dfree(c->d_r0); dfree(c->d_r1); dfree(c->d_r2); dfree(c->d_lex0); dfree(c->d_lex1); dfree(c->d_lex2); c->nl0 = c->nl1 = c->nl2 = 0;
+    dfree(c->d_blocks); dfree(c->d_r0); dfree(c->d_r1); dfree(c->d_r2); dfree(c->d_lex0); dfree(c->d_lex1); dfree(c->d_lex2); dfree(c->d_rng0); dfree(c->d_rng1); dfree(c->d_rng2); c->nl0 = c->nl1 = c->nl2 = 0;
     c->e1 = c->d1 = c->h1 = c->e2 = c->d2 = c->h2 = c->g = c->n0 = c->n1 = c->n2 = c->sep1 = c->sep2a = c->sep2b = 0;
     c->guard_exits = 0;
 }
@@ -211,6 +211,7 @@ extern "C" void cgx_destroy(cgx_ctx *c) {
     cgx__host_release(c);
     (void)hipSetDevice(c->device);
     free_batch(c); free_index(c);
+    for (int a = 0; a < 2; a++) if (c->arena[a]) { (void)hipHostFree(c->arena[a]); c->arena[a] = nullptr; }
     (void)hipStreamSynchronize(c->stream);
     g_pool.trim();
     (void)hipStreamDestroy(c->stream);
@@ -1614,10 +1615,20 @@ __global__ void k_lex_finish(lexsrc L, cgx_lexview T, int kind, const cgx_rule0 
     out[e] = o;
 }
 
-static int lexicon_kind(cgx_ctx *ctx, const lexsrc &L, const cgx_lexview &T, int kind, uint32_t n, uint32_t nid, cgx_lexent **out, uint32_t *nout) {
+// id -> [first,last] lexicon line (the host loops of ExtractPair.cu:3745-3756, 3805-3816 and extractGlobalPairsUpDown)
+__global__ void k_lex_ranges(const cgx_lexent *lex, uint32_t nl, int32_t *rng) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nl) return;
+    int32_t id = lex[i].id;
+    if (i == 0 || lex[i - 1].id != id) rng[2 * (size_t)id] = (int32_t)i;
+    if (i + 1 == nl || lex[i + 1].id != id) rng[2 * (size_t)id + 1] = (int32_t)i;
+}
+static int lexicon_kind(cgx_ctx *ctx, const lexsrc &L, const cgx_lexview &T, int kind, uint32_t n, uint32_t nid, cgx_lexent **out, uint32_t *nout, int32_t **rng) {
     hipStream_t st = ctx->stream;
     *out = nullptr; *nout = 0;
     TRY(dalloc(ctx, out, 1));
+    TRY(dalloc(ctx, rng, (size_t)2 * nid + 2));
+    HIPCHK(hipMemsetAsync(*rng, 0xFF, ((size_t)2 * nid + 2) * 4, st));
     if (n == 0) return CGX_OK;
     uint64_t *hi = nullptr, *lo = nullptr; uint32_t *perm = nullptr, *flags = nullptr, *incl = nullptr; unsigned int *coll = nullptr;
     TRY(dalloc(ctx, &hi, n)); TRY(dalloc(ctx, &lo, n)); TRY(dalloc(ctx, &flags, n)); TRY(dalloc(ctx, &incl, n)); TRY(dalloc(ctx, &coll, 1));
@@ -1643,6 +1654,7 @@ static int lexicon_kind(cgx_ctx *ctx, const lexsrc &L, const cgx_lexview &T, int
     k_group_starts<<<nblocks(n, 256), 256, 0, st>>>(gflags, gincl, n, gstart);
     dfree(*out); TRY(dalloc(ctx, out, nent));
     k_lex_finish<<<nblocks(nent, 128), 128, 0, st>>>(L, T, kind, ctx->d_r0, ctx->d_r1, ctx->d_r2, n, sfirst, seid, runstart, nent, nent, gincl, gstart, ng, *out);
+    k_lex_ranges<<<nblocks(nent, 256), 256, 0, st>>>(*out, nent, *rng);
     HIPCHK(hipStreamSynchronize(st)); HIPCHK(hipGetLastError());
     *nout = nent;
     dfree(hi); dfree(lo); dfree(perm); dfree(flags); dfree(incl); dfree(coll); dfree(first); dfree(runstart); dfree(sfirst); dfree(eid); dfree(seid); dfree(gstart);
@@ -1657,10 +1669,46 @@ extern "C" int cgx_lexicon(cgx_ctx *ctx) {
     lexsrc L{ctx->d_blocks, ctx->d_s1, ctx->d_s2, ctx->d_p1, ctx->d_c2, ctx->d_str, ctx->d_tstr, ctx->d_hits1, ctx->d_pidx, ctx->d_miss,
              ctx->g, ctx->d1, ctx->d2, ctx->sep1, ctx->sep2a, ctx->sep2b};
     cgx_lexview T{ctx->d_lexkey, ctx->d_lexv1, ctx->d_lexv2, ctx->d_lexn1, ctx->d_lexn2, ctx->nlex, ctx->d_lexrow, ctx->d_lexnullt, ctx->lex_nrow, ctx->lex_ntgt};
-    TRY(lexicon_kind(ctx, L, T, 1, ctx->n1, 2 * ctx->g + ctx->d1, &ctx->d_lex1, &ctx->nl1));
-    TRY(lexicon_kind(ctx, L, T, 2, ctx->n2, ctx->g + 2 * ctx->d1 + ctx->d2, &ctx->d_lex2, &ctx->nl2));
-    TRY(lexicon_kind(ctx, L, T, 0, ctx->n0, ctx->g, &ctx->d_lex0, &ctx->nl0));
+    dfree(ctx->d_rng0); dfree(ctx->d_rng1); dfree(ctx->d_rng2);
+    TRY(lexicon_kind(ctx, L, T, 1, ctx->n1, 2 * ctx->g + ctx->d1, &ctx->d_lex1, &ctx->nl1, &ctx->d_rng1));
+    TRY(lexicon_kind(ctx, L, T, 2, ctx->n2, ctx->g + 2 * ctx->d1 + ctx->d2, &ctx->d_lex2, &ctx->nl2, &ctx->d_rng2));
+    TRY(lexicon_kind(ctx, L, T, 0, ctx->n0, ctx->g, &ctx->d_lex0, &ctx->nl0, &ctx->d_rng0));
     ctx->ms["lexicon"] = tm.stop();
+    return CGX_OK;
+}
+
+
+// ------------------------------------------------------------------------------------
+// pinned result arenas: the big per-batch results (lexicon lines) are copied device->host by
+// DMA into page-locked memory owned by the context.  Two arenas alternate between batches so
+// that the background writer of batch k can still read its arena while batch k+1 is fetched.
+// ------------------------------------------------------------------------------------
+extern "C" int cgx_pinned_next_batch(cgx_ctx *ctx) {
+    if (!ctx) return CGX_ERR_ARG;
+    ctx->arena_sel ^= 1; ctx->arena_used[ctx->arena_sel] = 0;
+    return CGX_OK;
+}
+extern "C" int cgx_fetch_pinned(cgx_ctx *ctx, const char *name, void **out, int64_t *nbytes) {
+    if (!ctx || !name || !out || !nbytes) return CGX_ERR_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    int64_t bytes = cgx_fetch(ctx, name, nullptr, 0);
+    if (bytes < 0) return (int)bytes;
+    int a = ctx->arena_sel;
+    size_t need = ((size_t)bytes + 255) & ~(size_t)255;
+    if (ctx->arena_used[a] + need > ctx->arena_cap[a]) {
+        if (ctx->arena_used[a] != 0) {                       // arena already holds results of this batch: fall back to a plain fetch into malloc memory
+            *out = nullptr; *nbytes = bytes; return CGX_ERR_NOMEM;
+        }
+        if (ctx->arena[a]) (void)hipHostFree(ctx->arena[a]);
+        ctx->arena[a] = nullptr; ctx->arena_cap[a] = 0;
+        size_t cap = need * 3 + (64u << 20);                 // room for the three lexicons of a batch of this size
+        if (hipHostMalloc(&ctx->arena[a], cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); *out = nullptr; *nbytes = bytes; return CGX_ERR_NOMEM; }
+        ctx->arena_cap[a] = cap;
+    }
+    char *dst = (char *)ctx->arena[a] + ctx->arena_used[a];
+    if (bytes) { int64_t got = cgx_fetch(ctx, name, dst, bytes); if (got < 0) return (int)got; }
+    ctx->arena_used[a] += need;
+    *out = dst; *nbytes = bytes;
     return CGX_OK;
 }
 
@@ -1684,6 +1732,8 @@ extern "C" int64_t cgx_fetch(cgx_ctx *ctx, const char *name, void *dst, int64_t 
     ENT("g2", ctx->d_g2, ctx->e2, cgx_twogappy) ENT("c2", ctx->d_c2, ctx->e2, int32_t) ENT("pid2", ctx->d_pid2, ctx->e2, uint32_t)
     ENT("s2", ctx->d_s2, ctx->d2, cgx_twogapsearch) ENT("hits2", ctx->d_hits2, ctx->h2, cgx_hit2)
     ENT("p1d", ctx->d_p1d, ctx->d1, cgx_gappat) ENT("c2d", ctx->d_c2d, ctx->d2, int32_t) ENT("one2", ctx->d_one2, ctx->d2, uint32_t)
+    ENT("rng0", ctx->d_rng0, ctx->d_rng0 ? 2 * (size_t)ctx->g : 0, int32_t) ENT("rng1", ctx->d_rng1, ctx->d_rng1 ? 2 * ((size_t)2 * ctx->g + ctx->d1) : 0, int32_t)
+    ENT("rng2", ctx->d_rng2, ctx->d_rng2 ? 2 * ((size_t)ctx->g + 2 * (size_t)ctx->d1 + ctx->d2) : 0, int32_t)
     ENT("lex0", ctx->d_lex0, ctx->nl0, cgx_lexent) ENT("lex1", ctx->d_lex1, ctx->nl1, cgx_lexent) ENT("lex2", ctx->d_lex2, ctx->nl2, cgx_lexent)
     ENT("r0", ctx->d_r0, ctx->n0, cgx_rule0) ENT("r1", ctx->d_r1, ctx->n1, cgx_rule1) ENT("r2", ctx->d_r2, ctx->n2, cgx_rule2)
 #undef ENT

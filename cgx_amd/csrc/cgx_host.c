@@ -314,6 +314,7 @@ typedef struct {
     uint32_t *pidx; int32_t *miss;
     lexent *lex0, *lex1, *lex2; uint32_t nl0, nl1, nl2;       /* exact host path only (hash-collision fallback) */
     cgx_lexent *L0, *L1, *L2;                                 /* lexicon lines as produced on the device */
+    int L_pinned;                                             /* L* live in the context's pinned arena: not freed here */
     cgx_gappat *p1d; int32_t *c2d; uint32_t *one2;            /* per distinct pattern: symbols of aXb, token c and one-gap id of aXbXc */
     range *rng0, *rng1, *rng2;
     cgx_lextask *tasks; uint32_t ntask;
@@ -324,7 +325,7 @@ static void batch_free(batch *b) {
     for (int32_t q = 0; q < b->nq; q++) { if (b->qblocks) free(b->qblocks[q].v); if (b->qone) free(b->qone[q].v); if (b->qtwo) free(b->qtwo[q].v); }
     free(b->qblocks); free(b->qone); free(b->qtwo); free(b->p1); free(b->s1); free(b->s2); free(b->c2); free(b->hits1);
     free(b->r0); free(b->r1); free(b->r2); free(b->pidx); free(b->miss); free(b->lex0); free(b->lex1); free(b->lex2);
-    free(b->rng0); free(b->rng1); free(b->rng2); free(b->tasks); free(b->L0); free(b->L1); free(b->L2); free(b->p1d); free(b->c2d); free(b->one2);
+    free(b->rng0); free(b->rng1); free(b->rng2); free(b->tasks); if (!b->L_pinned) { free(b->L0); free(b->L1); free(b->L2); } free(b->p1d); free(b->c2d); free(b->one2);
 }
 
 static int fetch_alloc(cgx_ctx *ctx, const char *name, void **out, size_t elem, uint32_t *count) {
@@ -805,8 +806,16 @@ static int run_batch(cgx_ctx *ctx, const cgx_corpus *c, batch *b, const char *ou
     score_tables();
     uint32_t nl0 = 0, nl1 = 0, nl2 = 0;
     if (!exact_host) {
-        if ((rc = fetch_alloc(ctx, "lex1", (void **)&b->L1, sizeof *b->L1, &nl1)) || (rc = fetch_alloc(ctx, "lex2", (void **)&b->L2, sizeof *b->L2, &nl2)) ||
-            (rc = fetch_alloc(ctx, "lex0", (void **)&b->L0, sizeof *b->L0, &nl0))) return rc;
+        int64_t by1 = 0, by2 = 0, by0 = 0;
+        cgx_pinned_next_batch(ctx);
+        if (cgx_fetch_pinned(ctx, "lex2", (void **)&b->L2, &by2) == CGX_OK && cgx_fetch_pinned(ctx, "lex1", (void **)&b->L1, &by1) == CGX_OK &&
+            cgx_fetch_pinned(ctx, "lex0", (void **)&b->L0, &by0) == CGX_OK) {
+            b->L_pinned = 1; nl1 = (uint32_t)((size_t)by1 / sizeof *b->L1); nl2 = (uint32_t)((size_t)by2 / sizeof *b->L2); nl0 = (uint32_t)((size_t)by0 / sizeof *b->L0);
+        } else {                                              /* no pinned memory: pageable copies */
+            b->L_pinned = 0; b->L0 = b->L1 = b->L2 = NULL;
+            if ((rc = fetch_alloc(ctx, "lex1", (void **)&b->L1, sizeof *b->L1, &nl1)) || (rc = fetch_alloc(ctx, "lex2", (void **)&b->L2, sizeof *b->L2, &nl2)) ||
+                (rc = fetch_alloc(ctx, "lex0", (void **)&b->L0, sizeof *b->L0, &nl0))) return rc;
+        }
     } else {
         /* exact host lexicon (ExtractPair.c:515-1276 restated on integer tuples) + MaxLex through the task ABI */
         if ((rc = fetch_alloc(ctx, "p1", (void **)&b->p1, sizeof *b->p1, NULL)) || (rc = fetch_alloc(ctx, "s1", (void **)&b->s1, sizeof *b->s1, NULL)) ||
@@ -832,9 +841,14 @@ static int run_batch(cgx_ctx *ctx, const cgx_corpus *c, batch *b, const char *ou
         free(fe); free(ef);
     }
     b->nl0 = nl0; b->nl1 = nl1; b->nl2 = nl2;
-    free(b->rng0); free(b->rng1); free(b->rng2);
-    b->rng1 = make_ranges_dev(b->L1, nl1, 2 * b->g + b->d1); b->rng2 = make_ranges_dev(b->L2, nl2, b->g + 2 * b->d1 + b->d2); b->rng0 = make_ranges_dev(b->L0, nl0, b->g);
-    if (!b->rng0 || !b->rng1 || !b->rng2) return CGX_ERR_NOMEM;
+    free(b->rng0); free(b->rng1); free(b->rng2); b->rng0 = b->rng1 = b->rng2 = NULL;
+    if (!exact_host) {                                        /* ranges were built on the device next to the lexicon */
+        if ((rc = fetch_alloc(ctx, "rng1", (void **)&b->rng1, sizeof *b->rng1, NULL)) || (rc = fetch_alloc(ctx, "rng2", (void **)&b->rng2, sizeof *b->rng2, NULL)) ||
+            (rc = fetch_alloc(ctx, "rng0", (void **)&b->rng0, sizeof *b->rng0, NULL))) return rc;
+    } else {
+        b->rng1 = make_ranges_dev(b->L1, nl1, 2 * b->g + b->d1); b->rng2 = make_ranges_dev(b->L2, nl2, b->g + 2 * b->d1 + b->d2); b->rng0 = make_ranges_dev(b->L0, nl0, b->g);
+        if (!b->rng0 || !b->rng1 || !b->rng2) return CGX_ERR_NOMEM;
+    }
     cgx__set_host_ms(ctx, "lexicon", now_ms() - t);
     uint64_t lines = count_lines(b);
     if (nrules) *nrules = lines;

@@ -104,8 +104,12 @@ int cgx_lex_features(cgx_ctx *ctx, const cgx_lextask *tasks, uint32_t ntask, uin
 /* ---- results: copy a named device/host result into caller memory.
  * dst == NULL returns the size in bytes; otherwise returns bytes written, or < 0. Names:
  *   "sa" "tokstart" "freq" "pidx" "miss" "phit_start" "phit_len"
- *   "lm" "up" "down" "g1" "p1" "pid1" "s1" "hits1" "g2" "c2" "pid2" "s2" "hits2" "r0" "r1" "r2" "p1d" "c2d" "one2" "lex0" "lex1" "lex2" "counts" */
+ *   "lm" "up" "down" "g1" "p1" "pid1" "s1" "hits1" "g2" "c2" "pid2" "s2" "hits2" "r0" "r1" "r2" "p1d" "c2d" "one2" "lex0" "lex1" "lex2" "rng0" "rng1" "rng2" (id -> first,last line; -1,-1 when empty) "counts" */
 int64_t cgx_fetch(cgx_ctx *ctx, const char *name, void *dst, int64_t cap);
+/* same, but into page-locked memory owned by the context (DMA speed); the pointer stays valid until
+ * cgx_pinned_next_batch has been called twice.  Returns CGX_ERR_NOMEM (and *out = NULL) when pinned memory is unavailable. */
+int cgx_fetch_pinned(cgx_ctx *ctx, const char *name, void **out, int64_t *nbytes);
+int cgx_pinned_next_batch(cgx_ctx *ctx);
 /* last-stage timings in milliseconds (hipEvent): "sa_lookup" "gappy" "extract" "lex" "build_sa" "precompute";
  * "sa_lookup_kernel" is the batched interval-search kernel alone */
 double cgx_stage_ms(cgx_ctx *ctx, const char *name);
