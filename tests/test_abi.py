@@ -67,3 +67,49 @@ def test_cli_argument_behaviour():
     assert r.returncode == 0 and "Please check your input arguments" in r.stdout
     r = subprocess.run([exe, "-t", "11", "a", "b", "c", "d", "e", "f"], capture_output=True, text=True)
     assert r.returncode == 0 and "finger length must be between 1 and 10" in r.stderr
+
+
+def _copy_tiny(tmp_path):
+    import shutil
+    fx = os.path.join(ROOT, "tests", "golden", "tiny"); d = tmp_path / "fx"; d.mkdir()
+    for n in ("corpus.f", "corpus.e", "corpus.a", "lex.txt", "query.f"):
+        shutil.copy(os.path.join(fx, n), d / n)
+    return d
+
+
+def test_loader_error_behaviour_matches_the_reference(lib, tmp_path):
+    """Host loaders run without a GPU: alignment index >= 255 -> "too long sentence" exit 1 (ExtractPair.cu:2683),
+    dangling "i-" -> "Not possible!" exit 0 (:2676), missing lexical table -> message, exit 0 (:2458-2461)."""
+    import cgx_amd
+    exe = os.path.join(ROOT, "bin", "strmatchcuda")
+    d = _copy_tiny(tmp_path); out = tmp_path / "out"; out.mkdir()
+    args = lambda: [str(d / n) for n in ("corpus.f", "query.f", "corpus.e", "corpus.a", "lex.txt")] + [str(out)]
+    lines = (d / "corpus.a").read_text().splitlines()
+    (d / "corpus.a").write_text("\n".join(["0-255"] + lines[1:]) + "\n")
+    with pytest.raises(cgx_amd.CgxError, match="too long sentence"):
+        cgx_amd.Corpus.load(*[str(d / n) for n in ("corpus.f", "corpus.e", "corpus.a", "lex.txt")])
+    r = subprocess.run([exe] + args(), capture_output=True, text=True)
+    assert r.returncode == 1 and "Not possible, too long sentence" in r.stdout
+    (d / "corpus.a").write_text("\n".join(["0-0 1"] + lines[1:]) + "\n")
+    r = subprocess.run([exe] + args(), capture_output=True, text=True)
+    assert r.returncode == 0 and "Not possible!" in r.stdout
+    (d / "corpus.a").write_text("\n".join(lines) + "\n")
+    os.remove(d / "lex.txt")
+    r = subprocess.run([exe] + args(), capture_output=True, text=True)
+    assert r.returncode == 0 and "The Word Possibility File is not Found!" in r.stderr
+
+
+def test_loader_tokenisation_quirks(lib, tmp_path):
+    """Start.cu:273-305: blanks are the only separators, a word starting with other white space ends the line,
+    an empty line is an empty sentence; source/target line counts must agree."""
+    import cgx_amd
+    d = tmp_path
+    (d / "s.f").write_text("a b  c\n\nd\te f\n" + "\n".join("w%d" % i for i in range(120)) + "\n")
+    (d / "s.e").write_text("x y\n\nz\n" + "\n".join("v%d" % i for i in range(120)) + "\n")
+    (d / "s.a").write_text("0-0\n\n0-0\n" + "\n".join("0-0" for _ in range(120)) + "\n")
+    (d / "lex").write_text("NULL NULL 0.1 0.1\na x 0.5 0.25\n")
+    c = cgx_amd.Corpus.load(str(d / "s.f"), str(d / "s.e"), str(d / "s.a"), str(d / "lex"))
+    c.close()
+    (d / "s.e").write_text("x y\n")
+    with pytest.raises(cgx_amd.CgxError, match="lines"):
+        cgx_amd.Corpus.load(str(d / "s.f"), str(d / "s.e"), str(d / "s.a"), str(d / "lex"))
