@@ -196,6 +196,7 @@ static void free_batch(cgx_ctx *c) {
     dfree(c->d_qoff); dfree(c->d_qtok); dfree(c->d_tok2q); dfree(c->d_lm); dfree(c->d_up); dfree(c->d_down);
     dfree(c->d_g1); dfree(c->d_p1); dfree(c->d_pid1); dfree(c->d_s1); dfree(c->d_hits1);
     dfree(c->d_g2); dfree(c->d_c2); dfree(c->d_pid2); dfree(c->d_s2); dfree(c->d_hits2); dfree(c->d_p1d); dfree(c->d_c2d); dfree(c->d_one2);
+    dfree(c->d_qb_off); dfree(c->d_qb_ids); dfree(c->d_qo_off); dfree(c->d_qo_ids); dfree(c->d_qt_off); dfree(c->d_qt_ids);
     dfree(c->d_blocks); dfree(c->d_r0); dfree(c->d_r1); dfree(c->d_r2); dfree(c->d_lex0); dfree(c->d_lex1); dfree(c->d_lex2); dfree(c->d_rng0); dfree(c->d_rng1); dfree(c->d_rng2); c->nl0 = c->nl1 = c->nl2 = 0;
     c->e1 = c->d1 = c->h1 = c->e2 = c->d2 = c->h2 = c->g = c->n0 = c->n1 = c->n2 = c->sep1 = c->sep2a = c->sep2b = 0;
     c->guard_exits = 0;
@@ -213,6 +214,9 @@ extern "C" void cgx_destroy(cgx_ctx *c) {
     (void)hipSetDevice(c->device);
     free_batch(c); free_index(c);
     for (int a = 0; a < 2; a++) if (c->arena[a]) { (void)hipHostFree(c->arena[a]); c->arena[a] = nullptr; }
+    for (int a = 0; a < 2; a++) { dfree(c->d_text[a]); dfree(c->d_qtext[a]); }
+    dfree(c->d_spool); dfree(c->d_soff); dfree(c->d_tpool); dfree(c->d_toff); dfree(c->d_aa); dfree(c->d_bb); dfree(c->d_fs);
+    for (int r = 0; r < 16; r++) if (c->copy_streams[r]) (void)hipStreamDestroy(c->copy_streams[r]);
     (void)hipStreamSynchronize(c->stream);
     g_pool.trim();
     (void)hipStreamDestroy(c->stream);
@@ -222,6 +226,7 @@ extern "C" const char *cgx_last_error(cgx_ctx *c) { return c ? c->err : "null co
 extern "C" int cgx_set_option(cgx_ctx *c, const char *name, int64_t value) {
     if (!c || !name) return CGX_ERR_ARG;
     if (!strcmp(name, "k1_limit")) { c->k1_limit = (int)value; return CGX_OK; }
+    if (!strcmp(name, "device_format")) { c->device_format = value != 0; return CGX_OK; }
     if (!strcmp(name, "use_bigrams")) { c->use_bigrams = value != 0; return CGX_OK; }
     if (!strcmp(name, "async_write")) { c->async_write = value != 0; return CGX_OK; }
     if (!strcmp(name, "force_host_lexicon")) { c->force_host_lexicon = value != 0; return CGX_OK; }
@@ -229,7 +234,14 @@ extern "C" int cgx_set_option(cgx_ctx *c, const char *name, int64_t value) {
     snprintf(c->err, sizeof c->err, "unknown option %s", name);
     return CGX_ERR_ARG;
 }
-extern "C" int64_t cgx__option(cgx_ctx *c, const char *name) { return (c && name && !strcmp(name, "async_write")) ? (int64_t)c->async_write : 0; }
+extern "C" int64_t cgx__option(cgx_ctx *c, const char *name) {
+    if (!c || !name) return 0;
+    if (!strcmp(name, "async_write")) return (int64_t)c->async_write;
+    if (!strcmp(name, "device_format")) return (int64_t)c->device_format;
+    return 0;
+}
+extern "C" const void *cgx__get_vocab_owner(cgx_ctx *c) { return c ? c->vocab_owner : nullptr; }
+extern "C" void cgx__set_vocab_owner(cgx_ctx *c, const void *p) { if (c) c->vocab_owner = p; }
 extern "C" void cgx__set_host_state(cgx_ctx *c, void *p) { if (c) c->host_state = p; }
 extern "C" void *cgx__get_host_state(cgx_ctx *c) { return c ? c->host_state : nullptr; }
 extern "C" void cgx__set_host_ms(cgx_ctx *c, const char *name, double ms) { if (c && name) c->host_ms[name] = ms; }
@@ -1714,6 +1726,8 @@ extern "C" int cgx_fetch_pinned(cgx_ctx *ctx, const char *name, void **out, int6
     *out = dst; *nbytes = bytes;
     return CGX_OK;
 }
+
+#include "cgx_format.inc"
 
 // ------------------------------------------------------------------------------------
 // result fetch

@@ -747,6 +747,67 @@ static int write_grammars(const batch *b, const char *outdir, int32_t first, uin
 /* ------------------------------------------------------------------ */
 /* the whole path for one batch of queries                             */
 /* ------------------------------------------------------------------ */
+/* ---- grammar text formatted on the device: the host only moves bytes into files ---- */
+static int ensure_vocab(cgx_ctx *ctx, const cgx_corpus *c) {
+    if (cgx__get_vocab_owner(ctx) == (const void *)c) return CGX_OK;
+    int rc = CGX_ERR_NOMEM;
+    uint32_t ns = (uint32_t)c->nsvocab, nt = (uint32_t)c->ntvocab;
+    uint32_t *soff = malloc(((size_t)ns + 1) * 4), *toff = malloc(((size_t)nt + 1) * 4);
+    if (!soff || !toff) return rc;
+    size_t sb = 0, tbytes = 0;
+    for (uint32_t i = 0; i < ns; i++) { soff[i] = (uint32_t)sb; sb += c->svocab && c->svocab[i] ? c->svlen[i] : 0; }
+    soff[ns] = (uint32_t)sb;
+    for (uint32_t i = 0; i < nt; i++) { toff[i] = (uint32_t)tbytes; tbytes += c->tvocab && c->tvocab[i] ? c->tvlen[i] : 0; }
+    toff[nt] = (uint32_t)tbytes;
+    char *sp = malloc(sb + 1), *tp = malloc(tbytes + 1);
+    if (sp && tp) {
+        for (uint32_t i = 0; i < ns; i++) if (soff[i + 1] > soff[i]) memcpy(sp + soff[i], c->svocab[i], soff[i + 1] - soff[i]);
+        for (uint32_t i = 0; i < nt; i++) if (toff[i + 1] > toff[i]) memcpy(tp + toff[i], c->tvocab[i], toff[i + 1] - toff[i]);
+        rc = cgx_upload_vocab(ctx, sp, soff, ns, tp, toff, nt);
+        if (rc == CGX_OK) { score_tables(); rc = cgx_upload_score_tables(ctx, &g_aa[0][0], g_bb, g_fs); }
+        if (rc == CGX_OK) cgx__set_vocab_owner(ctx, c);
+    }
+    free(sp); free(tp); free(soff); free(toff);
+    return rc;
+}
+typedef struct { cgx_ctx *ctx; int slot; const uint64_t *qtext; int32_t nq, first; const char *outdir; int32_t *next; int tid, rc; } devjob;
+#define PIN_BYTES (16u << 20)
+static void *g_pin[64];                                   /* one page-locked staging buffer per writer thread, kept for the life of the process */
+static void *dev_write_worker(void *arg) {
+    devjob *w = arg; char fn[4096]; w->rc = CGX_OK;
+    if (!g_pin[w->tid]) g_pin[w->tid] = cgx_pinned_alloc(PIN_BYTES);
+    void *buf = g_pin[w->tid];
+    if (!buf) { w->rc = CGX_ERR_NOMEM; return NULL; }
+    for (;;) {
+        int32_t q = __atomic_fetch_add(w->next, 1, __ATOMIC_RELAXED);
+        if (q >= w->nq) break;
+        uint64_t off = w->qtext[q], bytes = w->qtext[q + 1] - off;
+        snprintf(fn, sizeof fn, "%s/grammar.%d.s", w->outdir, w->first + q);
+        int fd = open(fn, O_WRONLY | O_CREAT, 0644);
+        if (fd < 0) { w->rc = CGX_ERR_IO; break; }
+        int bad = 0;
+        for (uint64_t o = 0; o < bytes && !bad; o += PIN_BYTES) {
+            uint64_t n = bytes - o < PIN_BYTES ? bytes - o : PIN_BYTES;
+            if (cgx_text_read(w->ctx, w->slot, off + o, n, buf, w->tid & 15) != CGX_OK) { bad = 2; break; }
+            for (uint64_t k = 0; k < n;) { ssize_t r = write(fd, (char *)buf + k, n - k); if (r <= 0) { bad = 1; break; } k += (uint64_t)r; }
+        }
+        if (!bad && ftruncate(fd, (off_t)bytes)) bad = 1;
+        close(fd);
+        if (bad) { w->rc = bad == 2 ? CGX_ERR_HIP : CGX_ERR_IO; break; }
+    }
+    return NULL;
+}
+static int write_from_device(cgx_ctx *ctx, int slot, const uint64_t *qtext, int32_t nq, const char *outdir, int32_t first) {
+    int nt = nthreads_host(); if (nt > 16) nt = 16; if (nt > nq) nt = nq > 0 ? nq : 1;
+    devjob jobs[16]; pthread_t th[16]; int32_t next = 0;
+    for (int t = 0; t < nt; t++) { jobs[t].ctx = ctx; jobs[t].slot = slot; jobs[t].qtext = qtext; jobs[t].nq = nq; jobs[t].first = first; jobs[t].outdir = outdir; jobs[t].next = &next; jobs[t].tid = t; jobs[t].rc = CGX_OK; }
+    for (int t = 1; t < nt; t++) if (pthread_create(&th[t], NULL, dev_write_worker, &jobs[t])) return CGX_ERR_NOMEM;
+    dev_write_worker(&jobs[0]);
+    for (int t = 1; t < nt; t++) pthread_join(th[t], NULL);
+    for (int t = 0; t < nt; t++) if (jobs[t].rc != CGX_OK) return jobs[t].rc;
+    return CGX_OK;
+}
+
 /* number of grammar lines the writer will produce (PrintResults.c:451-570 walked without formatting) */
 static uint64_t range_len(const range *r, uint32_t id) { return (r[id].down == -1 || r[id].up == -1) ? 0 : (uint64_t)(r[id].up - r[id].down + 1); }
 static uint64_t count_lines(const batch *b) {
@@ -758,10 +819,11 @@ static uint64_t count_lines(const batch *b) {
     }
     return n;
 }
-typedef struct { batch *b; char *outdir; int32_t first; pthread_t th; int active, rc; uint64_t lines; double ms; } pending;
+typedef struct { batch *b; char *outdir; int32_t first; pthread_t th; int active, rc; uint64_t lines; double ms;
+                 cgx_ctx *ctx; int dev, slot; uint64_t *qtext; int32_t nq; } pending;
 static void *pending_main(void *arg) {
     pending *pw = arg; double t = now_ms();
-    pw->rc = write_grammars(pw->b, pw->outdir, pw->first, &pw->lines);
+    pw->rc = pw->dev ? write_from_device(pw->ctx, pw->slot, pw->qtext, pw->nq, pw->outdir, pw->first) : write_grammars(pw->b, pw->outdir, pw->first, &pw->lines);
     pw->ms = now_ms() - t;
     return NULL;
 }
@@ -776,12 +838,56 @@ static int run_batch(cgx_ctx *ctx, const cgx_corpus *c, batch *b, const char *ou
     if ((rc = make_blocks(ctx, b)) != CGX_OK) return rc;
     cgx__set_host_ms(ctx, "blocks", now_ms() - t);
     if ((rc = cgx_set_blocks(ctx, b->blocks, b->g)) != CGX_OK) return rc;   /* also fills string_start = sa[start] (ExtractPair.cu:2798) */
+    const int devfmt = outdir && cgx__option(ctx, "device_format");
+    if (devfmt) {                                             /* per-query block lists as CSR for the device formatter */
+        uint32_t *off = malloc(((size_t)b->nq + 1) * 4); size_t tot = 0;
+        if (!off) return CGX_ERR_NOMEM;
+        for (int32_t q = 0; q < b->nq; q++) { off[q] = (uint32_t)tot; tot += b->qblocks[q].n; }
+        off[b->nq] = (uint32_t)tot;
+        uint32_t *ids = malloc((tot + 1) * 4);
+        if (!ids) { free(off); return CGX_ERR_NOMEM; }
+        for (int32_t q = 0; q < b->nq; q++) if (b->qblocks[q].n) memcpy(ids + off[q], b->qblocks[q].v, (size_t)b->qblocks[q].n * 4);
+        rc = cgx_set_query_blocks(ctx, off, ids);
+        free(off); free(ids);
+        if (rc == CGX_OK) rc = ensure_vocab(ctx, c);
+        if (rc != CGX_OK) return rc;
+    }
     if ((rc = cgx_gappy_search(ctx)) != CGX_OK) return rc;
     if ((rc = cgx_extract(ctx)) != CGX_OK) return rc;
     /* lexicon + MaxLex features on the device (host path only if a target-side hash collides) */
     int exact_host = 0;
     rc = cgx_lexicon(ctx);
     if (rc == CGX_ERR_STATE && strstr(cgx_last_error(ctx), "hash collision")) exact_host = 1; else if (rc != CGX_OK) return rc;
+    if (devfmt && !exact_host) {
+        /* the text of every file is laid out on the GPU; host threads only pull byte ranges and write them */
+        uint64_t bytes = 0, nl = 0; int slot = 0;
+        rc = cgx_format(ctx, &bytes, &nl, &slot);
+        if (rc == CGX_OK) {
+            uint64_t *qtext = malloc(((size_t)b->nq + 2) * 8);
+            if (!qtext) return CGX_ERR_NOMEM;
+            if ((rc = cgx_text_offsets(ctx, slot, qtext)) != CGX_OK) { free(qtext); return rc; }
+            if (nrules) *nrules = nl;
+            fprintf(stderr, "Start Printing Gappy Phrases...\n");
+            if (cgx__option(ctx, "async_write")) {
+                if ((rc = cgx_flush(ctx)) != CGX_OK) { free(qtext); return rc; }
+                pending *pw = calloc(1, sizeof *pw);
+                if (!pw) { free(qtext); return CGX_ERR_NOMEM; }
+                pw->dev = 1; pw->ctx = ctx; pw->slot = slot; pw->qtext = qtext; pw->nq = b->nq; pw->outdir = strdup(outdir); pw->first = first; pw->active = 1;
+                if (pthread_create(&pw->th, NULL, pending_main, pw)) { free(qtext); free(pw->outdir); free(pw); return CGX_ERR_NOMEM; }
+                cgx__set_host_state(ctx, pw);
+            } else {
+                t = now_ms();
+                rc = write_from_device(ctx, slot, qtext, b->nq, outdir, first);
+                free(qtext);
+                cgx__set_host_ms(ctx, "write", now_ms() - t);
+                if (rc != CGX_OK) return rc;
+            }
+            cgx__set_host_ms(ctx, "lists", 0); cgx__set_host_ms(ctx, "lexicon", 0);
+            cgx__set_host_ms(ctx, "total", now_ms() - t0);
+            return CGX_OK;
+        }
+        if (rc != CGX_ERR_STATE) return rc;                   /* CGX_ERR_STATE: a line the device cannot represent -> host formatter below */
+    }
     /* device results needed by the host stages */
     uint32_t *pid1 = NULL, *pid2 = NULL; cgx_gappy *g1 = NULL; cgx_twogappy *g2 = NULL; uint32_t counts[16];
     if (cgx_fetch(ctx, "counts", counts, sizeof counts) < 0) return CGX_ERR_HIP;
@@ -885,7 +991,8 @@ int cgx_flush(cgx_ctx *ctx) {
     int rc = pw->rc;
     cgx__set_host_ms(ctx, "write", pw->ms);
     cgx__set_host_state(ctx, NULL);
-    batch_free(pw->b); free(pw->b); free(pw->outdir); free(pw);
+    if (pw->b) { batch_free(pw->b); free(pw->b); }
+    free(pw->qtext); free(pw->outdir); free(pw);
     return rc;
 }
 void cgx__host_release(cgx_ctx *ctx) { (void)cgx_flush(ctx); }

@@ -9,7 +9,9 @@ void cgx__set_host_ms(cgx_ctx *ctx, const char *name, double ms);
 int64_t cgx__option(cgx_ctx *ctx, const char *name);          /* options the host side reads ("async_write") */
 void cgx__set_host_state(cgx_ctx *ctx, void *p);              /* per-context host state (background writer) */
 void *cgx__get_host_state(cgx_ctx *ctx);
-void cgx__host_release(cgx_ctx *ctx);                         /* implemented by the host TU, called from cgx_destroy */
+void cgx__host_release(cgx_ctx *ctx);
+const void *cgx__get_vocab_owner(cgx_ctx *ctx);               /* corpus whose spellings / score tables are on the device */
+void cgx__set_vocab_owner(cgx_ctx *ctx, const void *corpus);                         /* implemented by the host TU, called from cgx_destroy */
 #ifdef __cplusplus
 }
 #endif

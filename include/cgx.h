@@ -73,7 +73,7 @@ typedef struct {
 cgx_ctx *cgx_create(int device);                       /* replaces suffixArraySearchInit (SuffixArray.cu:769) */
 void cgx_destroy(cgx_ctx *ctx);                        /* replaces suffixArraySearchFinalize*, extractPairFinalize */
 const char *cgx_last_error(cgx_ctx *ctx);
-int cgx_set_option(cgx_ctx *ctx, const char *name, int64_t value); /* "k1_limit" (default 128), "chunk_items", "force_host_lexicon", "async_write", "use_bigrams" (default 1) */
+int cgx_set_option(cgx_ctx *ctx, const char *name, int64_t value); /* "k1_limit" (default 128), "chunk_items", "force_host_lexicon", "async_write", "use_bigrams" (default 1), "device_format" (default 1) */
 
 /* ---- index: upload, device suffix-array construction, frequent-pair precomputation ---- */
 int cgx_upload_index(cgx_ctx *ctx, const cgx_index_host *ix);   /* H2D of the index (SuffixArray.cu:1396-1412, ExtractPair.cu:3279-3282) */
@@ -100,6 +100,18 @@ int cgx_extract(cgx_ctx *ctx);          /* three extraction launches + sorts: Ex
 int cgx_lexicon(cgx_ctx *ctx);          /* device lexicon + MaxLex: createLexicon*Fast (ExtractPair.c:515-1276) + lexicalTaskMaxEF; results "lex1" "lex2" "lex0" */
 int cgx_lex_features(cgx_ctx *ctx, const cgx_lextask *tasks, uint32_t ntask, uint32_t n_onegap, uint32_t n_twogap,
                      float *max_fe, float *max_ef);             /* lexicalTaskMaxEF: ExtractPair.cu:2144-2432 */
+
+/* ---- grammar text laid out on the device (replaces the fprintf loops of PrintResults.c:339-577) ----
+ * vocabulary spellings as byte pools (word i = pool[off[i] .. off[i+1])), the host-libm score tables
+ * (aa[302*302], CountEF[302], SampleCountF[302]; ExtractPair.c:652-656) and the per-query block lists. */
+int cgx_upload_vocab(cgx_ctx *ctx, const char *spool, const uint32_t *soff, uint32_t ns, const char *tpool, const uint32_t *toff, uint32_t nt);
+int cgx_upload_score_tables(cgx_ctx *ctx, const float *aa, const float *bb, const float *fs);
+int cgx_set_query_blocks(cgx_ctx *ctx, const uint32_t *off, const uint32_t *ids);    /* CSR over the batch's queries */
+int cgx_format(cgx_ctx *ctx, uint64_t *total_bytes, uint64_t *total_lines, int *slot); /* after cgx_lexicon; two text slots alternate */
+int cgx_text_offsets(cgx_ctx *ctx, int slot, uint64_t *qtext);                       /* nq+1 byte offsets of the queries' text in that slot */
+int cgx_text_read(cgx_ctx *ctx, int slot, uint64_t off, uint64_t bytes, void *dst, int reader); /* D2H on side stream `reader` (0..15), thread safe per reader */
+void *cgx_pinned_alloc(size_t bytes);
+void cgx_pinned_free(void *p);
 
 /* ---- results: copy a named device/host result into caller memory.
  * dst == NULL returns the size in bytes; otherwise returns bytes written, or < 0. Names:

@@ -34,11 +34,14 @@ def run_product(cgx, fx, outdir, **opts):
     return ex, corpus, n
 
 
+@pytest.mark.parametrize("device_format", [1, 0])
 @pytest.mark.parametrize("name", ["tiny", "toy", "mid"])
-def test_grammar_files_bit_exact(name, cgx, oracle_bin, fixtures_dir, tmp_path):
+def test_grammar_files_bit_exact(name, device_format, cgx, oracle_bin, fixtures_dir, tmp_path):
+    """device_format=1: text laid out by the GPU formatter; 0: the threaded host formatter.  Both must equal the oracle."""
     fx = make_fixture(name, fixtures_dir)
     op.run_oracle(oracle_bin, fx, str(tmp_path / "o"))
-    ex, corpus, n = run_product(cgx, fx, str(tmp_path / "p"))
+    ex, corpus, n = run_product(cgx, fx, str(tmp_path / "p"), device_format=device_format)
+    assert n == sum(sum(1 for _ in open(tmp_path / "o" / ("grammar.%d.s" % q), "rb")) for q in range(META[name]["spec"][2]))
     nq = META[name]["spec"][2]
     assert op.sha_dir(str(tmp_path / "p"), nq) == op.sha_dir(str(tmp_path / "o"), nq) == META[name]["grammar"]
     assert ex.counts()["guard_exits"] == 0
@@ -116,7 +119,7 @@ def test_every_stage_matches_the_oracle(name, cgx, oracle_bin, fixtures_dir, tmp
 def test_exact_host_lexicon_path(cgx, fixtures_dir, tmp_path):
     """The host lexicon (taken only on a target-hash collision) must give the same files as the device lexicon."""
     fx = make_fixture("mid", fixtures_dir)
-    ex, corpus, n = run_product(cgx, fx, str(tmp_path / "h"), force_host_lexicon=1)
+    ex, corpus, n = run_product(cgx, fx, str(tmp_path / "h"), force_host_lexicon=1, device_format=0)
     assert op.sha_dir(str(tmp_path / "h"), META["mid"]["spec"][2]) == META["mid"]["grammar"]
     ex.close(); corpus.close()
 
