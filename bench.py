@@ -150,7 +150,18 @@ def main():
     # ---- queries: every rank gets its own shard of the global batch (weak scaling) ----
     gq_off, gq_tok = synth.make_queries(corpus, args.queries * world, args.seed + 3087)
     first, qoff, qtok = shard.take_shard(gq_off, gq_tok, rank, world)
-    base = args.outdir or ("/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None)
+    # output directory: the fastest writable place with room for this rank's files (about 2.2 MB per query on this workload)
+    need = int(len(qoff) * 3.0e6 * 1.2) + (1 << 30)
+    cands = [args.outdir] if args.outdir else [d for d in ("/dev/shm", tempfile.gettempdir()) if os.path.isdir(d) and os.access(d, os.W_OK)]
+    base = None
+    for d in cands:
+        try:
+            if shutil.disk_usage(d).free >= need * (world if not args.outdir else 1):
+                base = d; break
+        except OSError:
+            pass
+    if base is None and cands:
+        base = max(cands, key=lambda d: shutil.disk_usage(d).free)
     outdir = None if args.no_write else tempfile.mkdtemp(prefix="cgx_bench_r%d_" % rank, dir=base)
 
     def step():
@@ -159,7 +170,7 @@ def main():
     for _ in range(args.warmup):
         step()
     ex.flush()
-    kernel_ms = []; stage = {k: 0.0 for k in ("sa_lookup", "gappy", "extract", "lexicon")}; hoststage = {k: 0.0 for k in ("blocks", "lists", "lexicon", "write")}
+    kernel_ms = []; stage = {k: 0.0 for k in ("sa_lookup", "gappy", "extract", "lexicon", "format")}; hoststage = {k: 0.0 for k in ("blocks", "lists", "lexicon", "write")}
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
