@@ -782,6 +782,20 @@ template <class T> __global__ void k_permute(const T *src, const uint32_t *perm,
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; if (i < n) dst[i] = src[perm[i]];
 }
 
+
+// open-addressing hash (u64 key != 0 -> u32), linear probing, filled once per batch and then read-only
+__device__ __forceinline__ uint32_t h64_slot(uint64_t key, unsigned shift) { return (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> shift); }
+__device__ __forceinline__ void h64_insert(unsigned long long *keys, uint32_t *vals, uint32_t mask, unsigned shift, uint64_t key, uint32_t val) {
+    uint32_t s = h64_slot(key, shift) & mask;
+    for (;;) { unsigned long long prev = atomicCAS(&keys[s], 0ull, (unsigned long long)key); if (prev == 0ull || prev == key) break; s = (s + 1) & mask; }
+    vals[s] = val;
+}
+__device__ __forceinline__ bool h64_find(const uint64_t *keys, const uint32_t *vals, uint32_t mask, unsigned shift, uint64_t key, uint32_t *val) {
+    uint32_t s = h64_slot(key, shift) & mask;
+    for (;;) { uint64_t k = keys[s]; if (k == key) { *val = vals[s]; return true; } if (k == 0) return false; s = (s + 1) & mask; }
+}
+struct h64 { uint64_t *keys; uint32_t *vals; uint32_t mask; unsigned shift; };
+
 // ------------------------------------------------------------------------------------
 // one-gap lookup (oneGapLookUpSA, GappyLook.cu:128-474), inverted.
 // The reference scans, for EVERY distinct pattern aXb, the whole occurrence list of its rarer
@@ -850,6 +864,15 @@ __global__ void k_grpdown1(const grp1 *groups, uint32_t ng, const uint32_t *recp
     grp_down[g] = groups[g].backward ? (uint32_t)down[(size_t)(s.qrystart + s.gap + s.a_len) * 5 + s.b_len - 1] : (uint32_t)down[(size_t)s.qrystart * 5 + s.a_len - 1];
 }
 #define HITKEY(id, start, len) (((uint64_t)(id) << 36) | ((uint64_t)(uint32_t)(start) << 4) | (uint64_t)(len))
+// (group, first token of the other side) -> first record with that token, so that a window token costs one probe
+__global__ void k_rechash_fill(const uint64_t *reckey, const uint32_t *incl, uint32_t nrec, h64 H) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= nrec) return;
+    if (i == 0 || reckey[i] != reckey[i - 1]) {
+        uint64_t key = (((uint64_t)(incl[i] - 1) << REC_TOKBITS) | (reckey[i] & ((1u << REC_TOKBITS) - 1))) + 1;
+        h64_insert((unsigned long long *)H.keys, H.vals, H.mask, H.shift, key, (uint32_t)i);
+    }
+}
 // first record of [r0,r1) whose other-side first token is >= tk
 __device__ __forceinline__ uint32_t rec_lower(const uint64_t *reckey, uint32_t r0, uint32_t r1, uint32_t tk) {
     while (r0 < r1) { uint32_t m = (r0 + r1) >> 1; if ((uint32_t)(reckey[m] & ((1u << REC_TOKBITS) - 1)) < tk) r0 = m + 1; else r1 = m; }
@@ -857,7 +880,7 @@ __device__ __forceinline__ uint32_t rec_lower(const uint64_t *reckey, uint32_t r
 }
 template <bool FILL>
 __global__ void k_look1(cgx_view v, const int32_t *sa, const cgx_gapsearch *s1, const grp1 *groups, const uint64_t *woff, uint32_t ng,
-                        uint64_t w0, uint64_t nw, const int32_t *qtok, const uint64_t *reckey, const uint32_t *recpid,
+                        uint64_t w0, uint64_t nw, const int32_t *qtok, const uint64_t *reckey, const uint32_t *recpid, h64 H,
                         uint8_t *count, const uint32_t *offset, uint64_t *keys) {
     uint64_t wi = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (wi >= nw) return;
@@ -873,7 +896,8 @@ __global__ void k_look1(cgx_view v, const int32_t *sa, const cgx_gapsearch *s1, 
                 int64_t pos = go + dl + 1 + move;
                 int32_t tk = v.str[pos];
                 if (tk < 2) break;
-                uint32_t r = rec_lower(reckey, gr.rec0, gr.rec1, (uint32_t)tk);
+                uint32_t r;
+                if (!h64_find(H.keys, H.vals, H.mask, H.shift, (((uint64_t)g << REC_TOKBITS) | (uint32_t)tk) + 1, &r)) continue;
                 int gapok = -1;
                 for (; r < gr.rec1 && (uint32_t)(reckey[r] & ((1u << REC_TOKBITS) - 1)) == (uint32_t)tk; r++) {
                     uint32_t id = recpid[r]; cgx_gapsearch s = s1[id];
@@ -893,7 +917,8 @@ __global__ void k_look1(cgx_view v, const int32_t *sa, const cgx_gapsearch *s1, 
                 int64_t pa = go - 2 - move;
                 int32_t tk = pa < 0 ? -1 : v.str[pa];
                 if (tk < 2) break;
-                uint32_t r = rec_lower(reckey, gr.rec0, gr.rec1, (uint32_t)tk);
+                uint32_t r;
+                if (!h64_find(H.keys, H.vals, H.mask, H.shift, (((uint64_t)g << REC_TOKBITS) | (uint32_t)tk) + 1, &r)) continue;
                 int gapok = -1;
                 for (; r < gr.rec1 && (uint32_t)(reckey[r] & ((1u << REC_TOKBITS) - 1)) == (uint32_t)tk; r++) {
                     uint32_t id = recpid[r]; cgx_gapsearch s = s1[id];
@@ -1020,9 +1045,13 @@ __global__ void k_grpwork2(const grp2 *groups, uint32_t ng, const cgx_gapsearch 
     }
     work[gi] = w;
 }
+__global__ void k_s2hash_fill(const cgx_twogapsearch *s2, const int32_t *s2c, uint32_t d2, h64 H) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < d2 && s2[i].c_len == 1) h64_insert((unsigned long long *)H.keys, H.vals, H.mask, H.shift, (((uint64_t)s2[i].blockid << 32) | (uint32_t)s2c[i]) + 1, i);
+}
 template <bool FILL>
 __global__ void k_look2(cgx_view v, const cgx_twogapsearch *s2, const int32_t *s2c, const cgx_gapsearch *s1, const grp2 *groups, const uint64_t *woff, uint32_t ng,
-                        uint64_t w0, uint64_t nw, const cgx_hit1 *hits1, const uint32_t *pidx, const uint32_t *phs, const uint8_t *phl,
+                        uint64_t w0, uint64_t nw, const cgx_hit1 *hits1, const uint32_t *pidx, const uint32_t *phs, const uint8_t *phl, h64 H,
                         uint8_t *count, const uint32_t *offset, uint32_t *okey, uint64_t *oval) {
     uint64_t wi = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (wi >= nw) return;
@@ -1038,9 +1067,8 @@ __global__ void k_look2(cgx_view v, const cgx_twogapsearch *s2, const int32_t *s
         for (int move = 0; pl + 3 + move <= CGX_MAX_SPAN; move++) {
             int32_t tk = v.str[go + 2 + move];
             if (tk < 2) break;
-            uint32_t a = gr.s0, z = gr.s1;                   // segment sorted by c
-            while (a < z) { uint32_t m = (a + z) >> 1; if (s2c[m] < tk) a = m + 1; else z = m; }
-            if (a < gr.s1 && s2c[a] == tk && s2[a].c_len == 1 && cgx_gap_ok(v, ps + pl + 1, (uint32_t)(ps + pl + 1 + move))) {
+            uint32_t a;                                      // the pattern (this aXb, c = tk), if the batch has it
+            if (h64_find(H.keys, H.vals, H.mask, H.shift, (((uint64_t)gr.one << 32) | (uint32_t)tk) + 1, &a) && cgx_gap_ok(v, ps + pl + 1, (uint32_t)(ps + pl + 1 + move))) {
                 if (FILL) { okey[o + n] = a; oval[o + n] = ((uint64_t)ps << 8) | ((uint64_t)pl << 4) | (uint64_t)(pl + 2 + move); }
                 n++;
             }
@@ -1144,6 +1172,9 @@ extern "C" int cgx_gappy_search(cgx_ctx *ctx) {
             TRY(dalloc(ctx, &groups, NG)); TRY(dalloc(ctx, &gdown, NG)); TRY(dalloc(ctx, &work, (size_t)NG + 1)); TRY(dalloc(ctx, &woff, (size_t)NG + 1));
             HIPCHK(hipMemsetAsync(work, 0, ((size_t)NG + 1) * 8, st));
             k_groups1<<<nblocks(NR, 256), 256, 0, st>>>(sreckey, flags, incl, NR, groups);
+            h64 H; { uint64_t cap = 1024; while (cap < (uint64_t)NR * 2) cap <<= 1; H.mask = (uint32_t)(cap - 1); H.shift = 64 - (unsigned)bits_for(cap - 1);
+                     TRY(dalloc(ctx, &H.keys, cap)); TRY(dalloc(ctx, &H.vals, cap)); HIPCHK(hipMemsetAsync(H.keys, 0, cap * 8, st)); }
+            k_rechash_fill<<<nblocks(NR, 256), 256, 0, st>>>(sreckey, incl, NR, H);
             k_grpdown1<<<nblocks(NG, 256), 256, 0, st>>>(groups, NG, srecpid, ctx->d_s1, ctx->d_down, gdown);
             k_grpwork1<<<nblocks(NG, 256), 256, 0, st>>>(groups, NG, gdown, work);
             TRY(excl_scan(ctx, work, woff, (size_t)NG + 1));
@@ -1151,10 +1182,10 @@ extern "C" int cgx_gappy_search(cgx_ctx *ctx) {
             ctx->ms["look1_items"] = (double)W; ctx->ms["look1_groups"] = (double)NG;
             const cgx_gapsearch *s1 = ctx->d_s1; const int32_t *sa = ctx->d_sa, *qtok = ctx->d_qtok;
             TRY(chunked_count_fill(ctx, W, keys, [&](bool fill, uint64_t w0, uint64_t nw, uint8_t *c, uint32_t *o, uint64_t *out) {
-                if (fill) k_look1<true><<<nblocks(nw, 256), 256, 0, st>>>(v, sa, s1, groups, woff, NG, w0, nw, qtok, sreckey, srecpid, c, o, out);
-                else k_look1<false><<<nblocks(nw, 256), 256, 0, st>>>(v, sa, s1, groups, woff, NG, w0, nw, qtok, sreckey, srecpid, c, o, out);
+                if (fill) k_look1<true><<<nblocks(nw, 256), 256, 0, st>>>(v, sa, s1, groups, woff, NG, w0, nw, qtok, sreckey, srecpid, H, c, o, out);
+                else k_look1<false><<<nblocks(nw, 256), 256, 0, st>>>(v, sa, s1, groups, woff, NG, w0, nw, qtok, sreckey, srecpid, H, c, o, out);
             }));
-            dfree(flags); dfree(incl); dfree(groups); dfree(gdown); dfree(work); dfree(woff);
+            dfree(flags); dfree(incl); dfree(groups); dfree(gdown); dfree(work); dfree(woff); dfree(H.keys); dfree(H.vals);
         }
         if (keys.n > 0xFFFFFFF0ull) { snprintf(ctx->err, sizeof ctx->err, "too many one-gap occurrences"); return CGX_ERR_NOMEM; }
         uint32_t H1 = (uint32_t)keys.n; ctx->h1 = H1;
@@ -1223,11 +1254,14 @@ extern "C" int cgx_gappy_search(cgx_ctx *ctx) {
         ctx->ms["look2_items"] = (double)W; ctx->ms["look2_groups"] = (double)NG;
         uint64_t chunk = ctx->chunk_items; uint64_t cw = W < chunk ? W : chunk;
         uint8_t *c8 = nullptr; uint32_t *o32 = nullptr; TRY(dalloc(ctx, &c8, cw + 1)); TRY(dalloc(ctx, &o32, cw + 1));
+        h64 H2; { uint64_t cap = 1024; while (cap < (uint64_t)D2 * 2) cap <<= 1; H2.mask = (uint32_t)(cap - 1); H2.shift = 64 - (unsigned)bits_for(cap - 1);
+                  TRY(dalloc(ctx, &H2.keys, cap)); TRY(dalloc(ctx, &H2.vals, cap)); HIPCHK(hipMemsetAsync(H2.keys, 0, cap * 8, st)); }
+        k_s2hash_fill<<<nblocks(D2, 256), 256, 0, st>>>(ctx->d_s2, s2c, D2, H2);
         uint32_t *ak = nullptr; uint64_t *av = nullptr; size_t accn = 0, acccap = 0;
         for (uint64_t w0 = 0; w0 < W; w0 += chunk) {
             uint64_t nw = W - w0 < chunk ? W - w0 : chunk;
             HIPCHK(hipMemsetAsync(c8 + nw, 0, 1, st));
-            k_look2<false><<<nblocks(nw, 256), 256, 0, st>>>(v, ctx->d_s2, s2c, ctx->d_s1, groups, woff, NG, w0, nw, ctx->d_hits1, ctx->d_pidx, ctx->d_phit_start, ctx->d_phit_len, c8, o32, nullptr, nullptr);
+            k_look2<false><<<nblocks(nw, 256), 256, 0, st>>>(v, ctx->d_s2, s2c, ctx->d_s1, groups, woff, NG, w0, nw, ctx->d_hits1, ctx->d_pidx, ctx->d_phit_start, ctx->d_phit_len, H2, c8, o32, nullptr, nullptr);
             TRY(excl_scan(ctx, c8, o32, nw + 1));
             uint32_t total = 0; TRY(d2h(ctx, &total, o32 + nw, 1));
             if (accn + total > acccap) {
@@ -1236,7 +1270,7 @@ extern "C" int cgx_gappy_search(cgx_ctx *ctx) {
                 if (accn) { HIPCHK(hipMemcpyAsync(nk, ak, accn * 4, hipMemcpyDeviceToDevice, st)); HIPCHK(hipMemcpyAsync(nv, av, accn * 8, hipMemcpyDeviceToDevice, st)); }
                 HIPCHK(hipStreamSynchronize(st)); dfree(ak); dfree(av); ak = nk; av = nv; acccap = nc;
             }
-            if (total) k_look2<true><<<nblocks(nw, 256), 256, 0, st>>>(v, ctx->d_s2, s2c, ctx->d_s1, groups, woff, NG, w0, nw, ctx->d_hits1, ctx->d_pidx, ctx->d_phit_start, ctx->d_phit_len, c8, o32, ak + accn, av + accn);
+            if (total) k_look2<true><<<nblocks(nw, 256), 256, 0, st>>>(v, ctx->d_s2, s2c, ctx->d_s1, groups, woff, NG, w0, nw, ctx->d_hits1, ctx->d_pidx, ctx->d_phit_start, ctx->d_phit_len, H2, c8, o32, ak + accn, av + accn);
             HIPCHK(hipGetLastError());
             accn += total;
         }
@@ -1251,7 +1285,7 @@ extern "C" int cgx_gappy_search(cgx_ctx *ctx) {
             dfree(sk); dfree(sv);
         }
         ctx->h2 = (uint32_t)accn;
-        dfree(ak); dfree(av); dfree(c8); dfree(o32); dfree(work); dfree(woff); dfree(groups); dfree(s2c); dfree(flags); dfree(incl);
+        dfree(ak); dfree(av); dfree(c8); dfree(o32); dfree(work); dfree(woff); dfree(groups); dfree(s2c); dfree(flags); dfree(incl); dfree(H2.keys); dfree(H2.vals);
     }
     // compact per-distinct-pattern views for the host writer
     TRY(dalloc(ctx, &ctx->d_p1d, D1)); TRY(dalloc(ctx, &ctx->d_c2d, D2)); TRY(dalloc(ctx, &ctx->d_one2, D2));
