@@ -16,7 +16,9 @@ struct cgx_ctx {
     bool async_write = false;           // grammar files of batch k are written by host threads while the GPU runs batch k+1 (cgx_flush joins)
     void *host_state = nullptr;         // owned by the host TU
     bool force_host_lexicon = false;    // test hook: take the exact host lexicon path
-    uint64_t chunk_items = 1ull << 26;  // work items per count/fill chunk
+    uint64_t chunk_items = 1ull << 26;  // work items per lookup launch
+    uint64_t append_slack = 65536;
+    double look1_per_item = 2.0, look2_per_item = 2.0;   // output records per work item (capacity guess, adapts per batch)
     std::map<std::string, double> ms;   // stage timings
 
     // ---- index, resident for the life of the context ----
@@ -31,6 +33,7 @@ struct cgx_ctx {
     uint32_t *d_pidx = nullptr; int32_t *d_miss = nullptr; uint32_t *d_phit_start = nullptr; uint8_t *d_phit_len = nullptr;
     uint64_t *d_bg_key = nullptr; uint32_t *d_bg_lo = nullptr, *d_bg_hi = nullptr; uint32_t bg_cap = 0; unsigned bg_shift = 0;   // bigram -> SA interval
     bool use_bigrams = true;
+    bool wide_hits2 = false;            // test hook: take the >2^24-distinct-two-gap-patterns path
     int32_t freq[100] = {0};
 
     // ---- batch ----

@@ -150,6 +150,42 @@ __device__ __forceinline__ uint32_t wave_append(unsigned int *counter, bool vali
     return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
 }
 
+// ---- single-pass variable-output append ---------------------------------------------
+// A lane that produces a variable number of u64 records keeps its first STASH_K in LDS and
+// appends the rest directly (one atomic per group of lanes that overflow together).  At the end
+// of the kernel each wave reserves room for its stashed records with ONE atomic and copies them
+// out.  The global counter keeps counting past `cap`, so the host learns the exact size needed
+// when a launch overflows and can rerun it; nothing is written beyond `cap`.
+#define STASH_K 6
+struct appender { uint64_t *out; uint64_t cap; unsigned long long *total; };
+__device__ __forceinline__ uint64_t lanes_reserve(unsigned long long *ctr) {        // callable from divergent code
+    unsigned long long m = __ballot(1);
+    int lane = (int)(threadIdx.x & 63), leader = __ffsll((long long)m) - 1;
+    unsigned long long base = 0;
+    if (lane == leader) base = atomicAdd(ctr, (unsigned long long)__popcll(m));
+    base = __shfl(base, leader);
+    return base + (uint64_t)__popcll(m & ((1ull << lane) - 1ull));
+}
+__device__ __forceinline__ void stash_put(uint64_t (*stash)[256], uint32_t &n, const appender &ap, uint64_t rec) {
+    if (n < STASH_K) stash[n][threadIdx.x] = rec;
+    else { uint64_t slot = lanes_reserve(ap.total); if (slot < ap.cap) ap.out[slot] = rec; }
+    n++;
+}
+// every lane of the wave must reach this (no early return in the caller)
+__device__ __forceinline__ void stash_flush(uint64_t (*stash)[256], uint32_t n, const appender &ap) {
+    uint32_t m = n < STASH_K ? n : STASH_K;
+    int lane = (int)(threadIdx.x & 63);
+    uint32_t incl = m;
+    for (int d = 1; d < 64; d <<= 1) { uint32_t t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+    uint32_t wave_total = __shfl(incl, 63);
+    if (!wave_total) return;
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(ap.total, (unsigned long long)wave_total);
+    base = __shfl(base, 0);
+    uint64_t slot = base + (incl - m);
+    for (uint32_t j = 0; j < m; j++, slot++) if (slot < ap.cap) ap.out[slot] = stash[j][threadIdx.x];
+}
+
 __global__ void k_iota(uint32_t *p, size_t n) { size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; if (i < n) p[i] = (uint32_t)i; }
 template <class T> __global__ void k_gather(const T *src, const uint32_t *perm, T *dst, size_t n) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; if (i < n) dst[i] = src[perm[i]];
@@ -228,6 +264,9 @@ extern "C" int cgx_set_option(cgx_ctx *c, const char *name, int64_t value) {
     if (!strcmp(name, "k1_limit")) { c->k1_limit = (int)value; return CGX_OK; }
     if (!strcmp(name, "device_format")) { c->device_format = value != 0; return CGX_OK; }
     if (!strcmp(name, "use_bigrams")) { c->use_bigrams = value != 0; return CGX_OK; }
+    if (!strcmp(name, "wide_hits2")) { c->wide_hits2 = value != 0; return CGX_OK; }
+    if (!strcmp(name, "append_slack")) { if (value < 0) return CGX_ERR_ARG; c->append_slack = (uint64_t)value; return CGX_OK; }
+    if (!strcmp(name, "append_guess_milli")) { if (value < 0) return CGX_ERR_ARG; c->look1_per_item = c->look2_per_item = (double)value / 1000.0; return CGX_OK; }
     if (!strcmp(name, "async_write")) { c->async_write = value != 0; return CGX_OK; }
     if (!strcmp(name, "force_host_lexicon")) { c->force_host_lexicon = value != 0; return CGX_OK; }
     if (!strcmp(name, "chunk_items")) { if (value < 1024) return CGX_ERR_ARG; c->chunk_items = (uint64_t)value; return CGX_OK; }
@@ -878,18 +917,17 @@ __device__ __forceinline__ uint32_t rec_lower(const uint64_t *reckey, uint32_t r
     while (r0 < r1) { uint32_t m = (r0 + r1) >> 1; if ((uint32_t)(reckey[m] & ((1u << REC_TOKBITS) - 1)) < tk) r0 = m + 1; else r1 = m; }
     return r0;
 }
-template <bool FILL>
-__global__ void k_look1(cgx_view v, const int32_t *sa, const cgx_gapsearch *s1, const grp1 *groups, const uint64_t *woff, uint32_t ng,
-                        uint64_t w0, uint64_t nw, const int32_t *qtok, const uint64_t *reckey, const uint32_t *recpid, h64 H,
-                        uint8_t *count, const uint32_t *offset, uint64_t *keys) {
+__global__ __launch_bounds__(256) void k_look1(cgx_view v, const int32_t *sa, const cgx_gapsearch *s1, const grp1 *groups, const uint64_t *woff, uint32_t ng,
+                        uint64_t w0, uint64_t nw, const int32_t *qtok, const uint64_t *reckey, const uint32_t *recpid, h64 H, appender ap) {
+    __shared__ uint64_t stash[STASH_K][256];
     uint64_t wi = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-    if (wi >= nw) return;
+    uint32_t n = 0;
+    if (wi < nw) {
     uint32_t g = seg_of(woff, ng, w0 + wi);
     uint64_t x = w0 + wi - woff[g];
     grp1 gr = groups[g];
     const int dl = (int)gr.len;                            // length of the driving phrase
     int64_t go = sa[gr.base + x];
-    uint32_t n = 0; uint32_t o = FILL ? offset[wi] : 0;
     if (!gr.backward) {                                    // driving phrase is a: walk right (GappyLook.cu:335-396)
         if (v.str[go + dl] >= 2) {
             for (int move = 0; dl + 1 + move + 1 <= CGX_MAX_SPAN; move++) {
@@ -907,7 +945,7 @@ __global__ void k_look1(cgx_view v, const int32_t *sa, const cgx_gapsearch *s1, 
                     for (int k = 1; ok && k < bl; k++) ok = v.str[pos + k] == qtok[sb + k];
                     if (!ok) continue;
                     if (gapok < 0) gapok = cgx_gap_ok(v, (uint32_t)(go + dl), (uint32_t)(go + dl + move)) ? 1 : 0;
-                    if (gapok) { if (FILL) keys[o + n] = HITKEY(id, go, dl + 1 + move + bl - 1); n++; }
+                    if (gapok) stash_put(stash, n, ap, HITKEY(id, go, dl + 1 + move + bl - 1));
                 }
             }
         }
@@ -928,12 +966,13 @@ __global__ void k_look1(cgx_view v, const int32_t *sa, const cgx_gapsearch *s1, 
                     for (int k = 1; ok && k < al; k++) ok = pa - k >= 0 && v.str[pa - k] == qtok[t + al - 1 - k];
                     if (!ok) continue;
                     if (gapok < 0) gapok = cgx_gap_ok(v, (uint32_t)(pa + 1), (uint32_t)(go - 1)) ? 1 : 0;
-                    if (gapok) { if (FILL) keys[o + n] = HITKEY(id, pa - al + 1, dl + 1 + move + al - 1); n++; }
+                    if (gapok) stash_put(stash, n, ap, HITKEY(id, pa - al + 1, dl + 1 + move + al - 1));
                 }
             }
         }
     }
-    if (!FILL) count[wi] = (uint8_t)(n > 255 ? 255 : n);
+    }
+    stash_flush(stash, n, ap);
 }
 __global__ void k_unpack_hits1(const uint64_t *keys, uint32_t n, cgx_hit1 *hits, cgx_gapsearch *s1) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -957,26 +996,33 @@ static int dvec_reserve(cgx_ctx *ctx, dvec64 &v, size_t need) {
     return CGX_OK;
 }
 
-// run a count/fill kernel pair over work items [0,W) in chunks; the lambda launches one pass
+// Run a single-pass appending kernel over work items [0,W) (in launches of at most chunk_items).
+// `out` already holds out.n records; the kernel appends after them.  The capacity is a guess
+// (`per_item` records per work item, remembered from the previous batch); if the launch counted
+// more than fits it is rerun once with the exact size.
 template <class Launch>
-static int chunked_count_fill(cgx_ctx *ctx, uint64_t W, dvec64 &out, Launch launch) {
-    uint64_t chunk = ctx->chunk_items;
-    uint8_t *cnt = nullptr; uint32_t *off = nullptr;
-    uint64_t cw = W < chunk ? W : chunk;
-    TRY(dalloc(ctx, &cnt, cw + 1)); TRY(dalloc(ctx, &off, cw + 1));
-    for (uint64_t w0 = 0; w0 < W; w0 += chunk) {
-        uint64_t nw = W - w0 < chunk ? W - w0 : chunk;
-        HIPCHK(hipMemsetAsync(cnt + nw, 0, 1, ctx->stream));
-        launch(false, w0, nw, cnt, off, (uint64_t *)nullptr);
-        TRY(excl_scan(ctx, cnt, off, nw + 1));
-        uint32_t total = 0; TRY(d2h(ctx, &total, off + nw, 1));
-        TRY(dvec_reserve(ctx, out, out.n + total));
-        if (total) launch(true, w0, nw, cnt, off, out.p + out.n);
+static int append_pass(cgx_ctx *ctx, uint64_t W, dvec64 &out, double *per_item, Launch launch) {
+    unsigned long long *total = nullptr; TRY(dalloc(ctx, &total, 1));
+    const size_t n0 = out.n;
+    size_t want = n0 + (size_t)((double)W * *per_item) + ctx->append_slack;
+    for (int attempt = 0; ; attempt++) {
+        if (want > out.cap) { size_t keep = out.n; uint64_t *np = nullptr; TRY(dalloc(ctx, &np, want));
+            if (keep) HIPCHK(hipMemcpyAsync(np, out.p, keep * 8, hipMemcpyDeviceToDevice, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream)); dfree(out.p); out.p = np; out.cap = want; }
+        unsigned long long init = n0; TRY(h2d(ctx, total, &init, 1));
+        appender ap{out.p, out.cap, total};
+        for (uint64_t w0 = 0; w0 < W; w0 += ctx->chunk_items) {
+            uint64_t nw = W - w0 < ctx->chunk_items ? W - w0 : ctx->chunk_items;
+            launch(w0, nw, ap);
+        }
         HIPCHK(hipGetLastError());
-        out.n += total;
+        unsigned long long got = 0; TRY(d2h(ctx, &got, total, 1));
+        if (got <= out.cap) { out.n = (size_t)got; break; }
+        if (attempt) { snprintf(ctx->err, sizeof ctx->err, "append pass overflowed twice"); dfree(total); return CGX_ERR_STATE; }
+        want = (size_t)got;
     }
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    dfree(cnt); dfree(off);
+    if (W) { double r = (double)(out.n - n0) / (double)W * 1.25 + 0.05; if (r > *per_item || r < *per_item * 0.5) *per_item = r; }
+    dfree(total);
     return CGX_OK;
 }
 
@@ -1049,45 +1095,51 @@ __global__ void k_s2hash_fill(const cgx_twogapsearch *s2, const int32_t *s2c, ui
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < d2 && s2[i].c_len == 1) h64_insert((unsigned long long *)H.keys, H.vals, H.mask, H.shift, (((uint64_t)s2[i].blockid << 32) | (uint32_t)s2c[i]) + 1, i);
 }
-template <bool FILL>
-__global__ void k_look2(cgx_view v, const cgx_twogapsearch *s2, const int32_t *s2c, const cgx_gapsearch *s1, const grp2 *groups, const uint64_t *woff, uint32_t ng,
-                        uint64_t w0, uint64_t nw, const cgx_hit1 *hits1, const uint32_t *pidx, const uint32_t *phs, const uint8_t *phl, h64 H,
-                        uint8_t *count, const uint32_t *offset, uint32_t *okey, uint64_t *oval) {
+// hit record: pattern(<=24 bits) | start(32) | len(4) | len2(4) when the pattern id fits, else the id travels separately
+template <bool WIDE>
+__global__ __launch_bounds__(256) void k_look2(cgx_view v, const cgx_twogapsearch *s2, const int32_t *s2c, const cgx_gapsearch *s1, const grp2 *groups, const uint64_t *woff, uint32_t ng,
+                        uint64_t w0, uint64_t nw, const cgx_hit1 *hits1, const uint32_t *pidx, const uint32_t *phs, const uint8_t *phl, h64 H, appender ap, uint32_t *wide_id) {
+    __shared__ uint64_t stash[STASH_K][256];
     uint64_t wi = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-    if (wi >= nw) return;
-    uint32_t gi = seg_of(woff, ng, w0 + wi);
-    uint64_t x = w0 + wi - woff[gi];
-    grp2 gr = groups[gi]; cgx_gapsearch g = s1[gr.one];
-    uint32_t ps; int pl;
-    if (g.marker) { uint32_t pre = hits1[g.sa_start].str_position; uint32_t b = pidx[2 * pre]; ps = phs[b + x]; pl = phl[b + x]; }
-    else { cgx_hit1 h = hits1[g.sa_start + x]; ps = h.str_position; pl = h.length; }
-    uint32_t n = 0; uint32_t o = FILL ? offset[wi] : 0;
-    int64_t go = (int64_t)ps + pl;
-    if (pl > 0 && v.str[go + 1] >= 2) {
-        for (int move = 0; pl + 3 + move <= CGX_MAX_SPAN; move++) {
-            int32_t tk = v.str[go + 2 + move];
-            if (tk < 2) break;
-            uint32_t a;                                      // the pattern (this aXb, c = tk), if the batch has it
-            if (h64_find(H.keys, H.vals, H.mask, H.shift, (((uint64_t)gr.one << 32) | (uint32_t)tk) + 1, &a) && cgx_gap_ok(v, ps + pl + 1, (uint32_t)(ps + pl + 1 + move))) {
-                if (FILL) { okey[o + n] = a; oval[o + n] = ((uint64_t)ps << 8) | ((uint64_t)pl << 4) | (uint64_t)(pl + 2 + move); }
-                n++;
+    uint32_t n = 0;
+    if (wi < nw) {
+        uint32_t gi = seg_of(woff, ng, w0 + wi);
+        uint64_t x = w0 + wi - woff[gi];
+        grp2 gr = groups[gi]; cgx_gapsearch g = s1[gr.one];
+        uint32_t ps; int pl;
+        if (g.marker) { uint32_t pre = hits1[g.sa_start].str_position; uint32_t b = pidx[2 * pre]; ps = phs[b + x]; pl = phl[b + x]; }
+        else { cgx_hit1 h = hits1[g.sa_start + x]; ps = h.str_position; pl = h.length; }
+        int64_t go = (int64_t)ps + pl;
+        if (pl > 0 && v.str[go + 1] >= 2) {
+            for (int move = 0; pl + 3 + move <= CGX_MAX_SPAN; move++) {
+                int32_t tk = v.str[go + 2 + move];
+                if (tk < 2) break;
+                uint32_t a;                                      // the pattern (this aXb, c = tk), if the batch has it
+                if (h64_find(H.keys, H.vals, H.mask, H.shift, (((uint64_t)gr.one << 32) | (uint32_t)tk) + 1, &a) && cgx_gap_ok(v, ps + pl + 1, (uint32_t)(ps + pl + 1 + move))) {
+                    uint64_t rec = ((uint64_t)ps << 8) | ((uint64_t)pl << 4) | (uint64_t)(pl + 2 + move);
+                    if (!WIDE) stash_put(stash, n, ap, ((uint64_t)a << 40) | rec);
+                    else { uint64_t slot = lanes_reserve(ap.total); if (slot < ap.cap) { ap.out[slot] = rec; wide_id[slot] = a; } }
+                }
             }
         }
     }
-    if (!FILL) count[wi] = (uint8_t)n;
+    if (!WIDE) stash_flush(stash, n, ap);
 }
 __global__ void k_s2c(const cgx_twogapsearch *s2, const int32_t *c2, uint32_t d2, int32_t *s2c) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < d2) s2c[i] = c2[s2[i].position];
 }
+template <bool WIDE>
 __global__ void k_unpack_hits2(const uint32_t *key, const uint64_t *val, uint32_t n, cgx_hit2 *hits, cgx_twogapsearch *s2) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
-    uint32_t id = key[i]; uint64_t w = val[i];
+    uint64_t w = val[i];
+    uint32_t id = WIDE ? key[i] : (uint32_t)(w >> 40);
     cgx_hit2 h; h.position = id; h.str_position = (uint32_t)(w >> 8); h.length = (uint8_t)((w >> 4) & 15); h.length2 = (uint8_t)(w & 15);
     hits[i] = h;
-    if (i == 0 || key[i - 1] != id) s2[id].sa_start = (int32_t)i;
-    if (i + 1 == n || key[i + 1] != id) s2[id].sa_end = (int32_t)i;
+    uint32_t prev = i ? (WIDE ? key[i - 1] : (uint32_t)(val[i - 1] >> 40)) : 0, next = i + 1 < n ? (WIDE ? key[i + 1] : (uint32_t)(val[i + 1] >> 40)) : 0;
+    if (i == 0 || prev != id) s2[id].sa_start = (int32_t)i;
+    if (i + 1 == n || next != id) s2[id].sa_end = (int32_t)i;
 }
 
 __global__ void k_compact1(const cgx_gapsearch *s1, const cgx_gappat *p1, uint32_t d1, cgx_gappat *out) {
@@ -1181,9 +1233,8 @@ extern "C" int cgx_gappy_search(cgx_ctx *ctx) {
             uint64_t W = 0; TRY(d2h(ctx, &W, woff + NG, 1));
             ctx->ms["look1_items"] = (double)W; ctx->ms["look1_groups"] = (double)NG;
             const cgx_gapsearch *s1 = ctx->d_s1; const int32_t *sa = ctx->d_sa, *qtok = ctx->d_qtok;
-            TRY(chunked_count_fill(ctx, W, keys, [&](bool fill, uint64_t w0, uint64_t nw, uint8_t *c, uint32_t *o, uint64_t *out) {
-                if (fill) k_look1<true><<<nblocks(nw, 256), 256, 0, st>>>(v, sa, s1, groups, woff, NG, w0, nw, qtok, sreckey, srecpid, H, c, o, out);
-                else k_look1<false><<<nblocks(nw, 256), 256, 0, st>>>(v, sa, s1, groups, woff, NG, w0, nw, qtok, sreckey, srecpid, H, c, o, out);
+            TRY(append_pass(ctx, W, keys, &ctx->look1_per_item, [&](uint64_t w0, uint64_t nw, appender ap) {
+                k_look1<<<nblocks(nw, 256), 256, 0, st>>>(v, sa, s1, groups, woff, NG, w0, nw, qtok, sreckey, srecpid, H, ap);
             }));
             dfree(flags); dfree(incl); dfree(groups); dfree(gdown); dfree(work); dfree(woff); dfree(H.keys); dfree(H.vals);
         }
@@ -1252,40 +1303,53 @@ extern "C" int cgx_gappy_search(cgx_ctx *ctx) {
         TRY(excl_scan(ctx, work, woff, (size_t)NG + 1));
         uint64_t W = 0; TRY(d2h(ctx, &W, woff + NG, 1));
         ctx->ms["look2_items"] = (double)W; ctx->ms["look2_groups"] = (double)NG;
-        uint64_t chunk = ctx->chunk_items; uint64_t cw = W < chunk ? W : chunk;
-        uint8_t *c8 = nullptr; uint32_t *o32 = nullptr; TRY(dalloc(ctx, &c8, cw + 1)); TRY(dalloc(ctx, &o32, cw + 1));
         h64 H2; { uint64_t cap = 1024; while (cap < (uint64_t)D2 * 2) cap <<= 1; H2.mask = (uint32_t)(cap - 1); H2.shift = 64 - (unsigned)bits_for(cap - 1);
                   TRY(dalloc(ctx, &H2.keys, cap)); TRY(dalloc(ctx, &H2.vals, cap)); HIPCHK(hipMemsetAsync(H2.keys, 0, cap * 8, st)); }
         k_s2hash_fill<<<nblocks(D2, 256), 256, 0, st>>>(ctx->d_s2, s2c, D2, H2);
-        uint32_t *ak = nullptr; uint64_t *av = nullptr; size_t accn = 0, acccap = 0;
-        for (uint64_t w0 = 0; w0 < W; w0 += chunk) {
-            uint64_t nw = W - w0 < chunk ? W - w0 : chunk;
-            HIPCHK(hipMemsetAsync(c8 + nw, 0, 1, st));
-            k_look2<false><<<nblocks(nw, 256), 256, 0, st>>>(v, ctx->d_s2, s2c, ctx->d_s1, groups, woff, NG, w0, nw, ctx->d_hits1, ctx->d_pidx, ctx->d_phit_start, ctx->d_phit_len, H2, c8, o32, nullptr, nullptr);
-            TRY(excl_scan(ctx, c8, o32, nw + 1));
-            uint32_t total = 0; TRY(d2h(ctx, &total, o32 + nw, 1));
-            if (accn + total > acccap) {
-                size_t nc = acccap ? acccap : 1024; while (nc < accn + total) nc *= 2;
-                uint32_t *nk = nullptr; uint64_t *nv = nullptr; TRY(dalloc(ctx, &nk, nc)); TRY(dalloc(ctx, &nv, nc));
-                if (accn) { HIPCHK(hipMemcpyAsync(nk, ak, accn * 4, hipMemcpyDeviceToDevice, st)); HIPCHK(hipMemcpyAsync(nv, av, accn * 8, hipMemcpyDeviceToDevice, st)); }
-                HIPCHK(hipStreamSynchronize(st)); dfree(ak); dfree(av); ak = nk; av = nv; acccap = nc;
+        const unsigned idbits = (unsigned)bits_for(D2);
+        const bool wide = idbits > 24 || ctx->wide_hits2;          // the pattern id does not fit beside the 40-bit occurrence
+        dvec64 recs; uint32_t *wid = nullptr; size_t accn = 0;
+        if (!wide) {
+            TRY(append_pass(ctx, W, recs, &ctx->look2_per_item, [&](uint64_t w0, uint64_t nw, appender ap) {
+                k_look2<false><<<nblocks(nw, 256), 256, 0, st>>>(v, ctx->d_s2, s2c, ctx->d_s1, groups, woff, NG, w0, nw, ctx->d_hits1, ctx->d_pidx, ctx->d_phit_start, ctx->d_phit_len, H2, ap, nullptr);
+            }));
+            accn = recs.n;
+        } else {
+            // ids travel in a parallel array, so capacity is fixed before launching: count first with cap 0
+            for (int pass = 0; pass < 2; pass++) {
+                unsigned long long *total = nullptr; TRY(dalloc(ctx, &total, 1)); HIPCHK(hipMemsetAsync(total, 0, 8, st));
+                appender ap{recs.p, recs.cap, total};
+                for (uint64_t w0 = 0; w0 < W; w0 += ctx->chunk_items) {
+                    uint64_t nw = W - w0 < ctx->chunk_items ? W - w0 : ctx->chunk_items;
+                    k_look2<true><<<nblocks(nw, 256), 256, 0, st>>>(v, ctx->d_s2, s2c, ctx->d_s1, groups, woff, NG, w0, nw, ctx->d_hits1, ctx->d_pidx, ctx->d_phit_start, ctx->d_phit_len, H2, ap, wid);
+                }
+                unsigned long long got = 0; TRY(d2h(ctx, &got, total, 1)); dfree(total);
+                accn = (size_t)got;
+                if (pass == 0) { TRY(dvec_reserve(ctx, recs, accn + 1)); TRY(dalloc(ctx, &wid, accn + 1)); }
             }
-            if (total) k_look2<true><<<nblocks(nw, 256), 256, 0, st>>>(v, ctx->d_s2, s2c, ctx->d_s1, groups, woff, NG, w0, nw, ctx->d_hits1, ctx->d_pidx, ctx->d_phit_start, ctx->d_phit_len, H2, c8, o32, ak + accn, av + accn);
-            HIPCHK(hipGetLastError());
-            accn += total;
         }
-        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(hipGetLastError());
         if (accn > 0xFFFFFFF0ull) { snprintf(ctx->err, sizeof ctx->err, "too many two-gap occurrences"); return CGX_ERR_NOMEM; }
         if (accn) {
-            uint32_t *sk = nullptr; uint64_t *sv = nullptr; TRY(dalloc(ctx, &sk, accn)); TRY(dalloc(ctx, &sv, accn));
-            TRY(sort_pairs(ctx, ak, sk, av, sv, accn, 0, (unsigned)bits_for(D2)));          // stable: keeps (start, length, length2) order inside a pattern
+            // order: pattern, then (start, length, length2) -- thrust::sort(twoGapSACompare) + canonical tie order
+            uint64_t *sv = nullptr; TRY(dalloc(ctx, &sv, accn));
             dfree(ctx->d_hits2); TRY(dalloc(ctx, &ctx->d_hits2, accn));
-            k_unpack_hits2<<<nblocks(accn, 256), 256, 0, st>>>(sk, sv, (uint32_t)accn, ctx->d_hits2, ctx->d_s2);
+            if (!wide) {
+                TRY(sort_keys(ctx, recs.p, sv, accn, 0, 40 + idbits));
+                k_unpack_hits2<false><<<nblocks(accn, 256), 256, 0, st>>>(nullptr, sv, (uint32_t)accn, ctx->d_hits2, ctx->d_s2);
+            } else {
+                uint32_t *sk = nullptr, *sk2 = nullptr; uint64_t *sv2 = nullptr; TRY(dalloc(ctx, &sk, accn)); TRY(dalloc(ctx, &sk2, accn)); TRY(dalloc(ctx, &sv2, accn));
+                TRY(sort_pairs(ctx, recs.p, sv, wid, sk, accn, 0, 40));
+                TRY(sort_pairs(ctx, sk, sk2, sv, sv2, accn, 0, idbits));
+                k_unpack_hits2<true><<<nblocks(accn, 256), 256, 0, st>>>(sk2, sv2, (uint32_t)accn, ctx->d_hits2, ctx->d_s2);
+                HIPCHK(hipStreamSynchronize(st));
+                dfree(sk); dfree(sk2); dfree(sv2);
+            }
             HIPCHK(hipStreamSynchronize(st));
-            dfree(sk); dfree(sv);
+            dfree(sv);
         }
         ctx->h2 = (uint32_t)accn;
-        dfree(ak); dfree(av); dfree(c8); dfree(o32); dfree(work); dfree(woff); dfree(groups); dfree(s2c); dfree(flags); dfree(incl); dfree(H2.keys); dfree(H2.vals);
+        dfree(recs.p); dfree(wid); dfree(work); dfree(woff); dfree(groups); dfree(s2c); dfree(flags); dfree(incl); dfree(H2.keys); dfree(H2.vals);
     }
     // compact per-distinct-pattern views for the host writer
     TRY(dalloc(ctx, &ctx->d_p1d, D1)); TRY(dalloc(ctx, &ctx->d_c2d, D2)); TRY(dalloc(ctx, &ctx->d_one2, D2));
