@@ -170,7 +170,7 @@ def main():
     for _ in range(args.warmup):
         step()
     ex.flush()
-    kernel_ms = []; stage = {k: 0.0 for k in ("sa_lookup", "gappy", "extract", "lexicon", "format")}; hoststage = {k: 0.0 for k in ("blocks", "lists", "lexicon", "write")}
+    kernel_ms = []; stage = {k: 0.0 for k in ("sa_lookup", "gappy", "extract", "lexicon", "format")}; hoststage = {k: 0.0 for k in ("blocks", "lists", "lexicon", "write", "write_wait_d2h", "write_file", "total", "t_upload_sa", "t_fetch_lm", "t_blocks", "t_qblocks", "t_gappy", "t_extract", "t_lexicon", "t_format", "t_offsets", "t_flush_wait")}
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -187,6 +187,8 @@ def main():
     dt = shard.max_over_ranks(time.perf_counter() - t0, dist if world > 1 else None)
     total_q = shard.sum_over_ranks(len(qoff) * args.steps, dist if world > 1 else None)
     total_rules = shard.sum_over_ranks(rules, dist if world > 1 else None)
+
+    out_bytes = sum(e.stat().st_size for e in os.scandir(outdir)) if outdir else 0
 
     if rank == 0:
         lm = ex.fetch("lm"); c = ex.counts()
@@ -210,7 +212,7 @@ def main():
                                    % (args.pairs, args.queries),
                        "sentence_pairs": args.pairs, "source_tokens": int(len(corpus["str"])), "vocab": args.vocab,
                        "queries_per_gpu": int(len(qoff)), "query_tokens_per_gpu": int(len(qtok)), "parallelism": "query-shard x%d, index replicated" % world,
-                       "grammar_files_written": not args.no_write, "writer": "sync" if args.sync_write else "async (host threads overlap the next step; flushed before the clock stops)", "outdir": os.path.dirname(outdir) if outdir else None},
+                       "grammar_files_written": not args.no_write, "grammar_bytes_per_step": out_bytes, "writer": "sync" if args.sync_write else "async (host threads overlap the next step; flushed before the clock stops)", "outdir": os.path.dirname(outdir) if outdir else None},
             "roofline": {"bound": "hbm", "kernel": "k_sa_lookup (batched SA interval search)", "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(ach / 8000.0, 4), "traffic": traffic, "algorithmic_bytes_per_launch": int(abytes), "lookups_per_launch": int(lookups),
                          "kernel_ms": round(kms, 4), "pmc_GBps": (round(traffic / (kms * 1e-3) / 1e9, 1) if traffic and kms > 0 else None),

@@ -58,7 +58,7 @@ struct cgx_ctx {
     float *d_aa = nullptr, *d_bb = nullptr, *d_fs = nullptr;
     uint32_t *d_qb_off = nullptr, *d_qb_ids = nullptr, *d_qo_off = nullptr, *d_qo_ids = nullptr, *d_qt_off = nullptr, *d_qt_ids = nullptr;
     char *d_text[2] = {nullptr, nullptr}; size_t text_cap[2] = {0, 0}; uint64_t text_bytes[2] = {0, 0}; uint64_t *d_qtext[2] = {nullptr, nullptr}; int32_t text_nq[2] = {0, 0}; int text_sel = 0;
-    hipStream_t copy_streams[16] = {nullptr};
+    hipStream_t copy_streams[CGX_MAX_READERS] = {nullptr};
     const void *vocab_owner = nullptr;
     bool device_format = true;          // lay the grammar text out on the GPU (host formatter kept as the fallback)
 

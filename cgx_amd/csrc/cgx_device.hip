@@ -252,7 +252,7 @@ extern "C" void cgx_destroy(cgx_ctx *c) {
     for (int a = 0; a < 2; a++) if (c->arena[a]) { (void)hipHostFree(c->arena[a]); c->arena[a] = nullptr; }
     for (int a = 0; a < 2; a++) { dfree(c->d_text[a]); dfree(c->d_qtext[a]); }
     dfree(c->d_spool); dfree(c->d_soff); dfree(c->d_tpool); dfree(c->d_toff); dfree(c->d_aa); dfree(c->d_bb); dfree(c->d_fs);
-    for (int r = 0; r < 16; r++) if (c->copy_streams[r]) (void)hipStreamDestroy(c->copy_streams[r]);
+    for (int r = 0; r < CGX_MAX_READERS; r++) if (c->copy_streams[r]) (void)hipStreamDestroy(c->copy_streams[r]);
     (void)hipStreamSynchronize(c->stream);
     g_pool.trim();
     (void)hipStreamDestroy(c->stream);

@@ -770,41 +770,65 @@ static int ensure_vocab(cgx_ctx *ctx, const cgx_corpus *c) {
     free(sp); free(tp); free(soff); free(toff);
     return rc;
 }
-typedef struct { cgx_ctx *ctx; int slot; const uint64_t *qtext; int32_t nq, first; const char *outdir; int32_t *next; int tid, rc; } devjob;
-#define PIN_BYTES (16u << 20)
-static void *g_pin[64];                                   /* one page-locked staging buffer per writer thread, kept for the life of the process */
-static void *dev_write_worker(void *arg) {
-    devjob *w = arg; char fn[4096]; w->rc = CGX_OK;
-    if (!g_pin[w->tid]) g_pin[w->tid] = cgx_pinned_alloc(PIN_BYTES);
-    void *buf = g_pin[w->tid];
-    if (!buf) { w->rc = CGX_ERR_NOMEM; return NULL; }
-    for (;;) {
+typedef struct { cgx_ctx *ctx; int slot; const uint64_t *qtext; int32_t nq, first; const char *outdir; int32_t *next; int tid, rc; double wait_ms, write_ms; } devjob;
+#define PIN_BYTES (8u << 20)
+#define MAX_WRITERS (CGX_MAX_READERS / 2)
+static void *g_pin[MAX_WRITERS][2];                       /* two page-locked staging buffers per writer thread, kept for the life of the process */
+/* the next <= PIN_BYTES piece of text this thread should move: continues the current file or claims the next one */
+typedef struct { int32_t q; uint64_t o, n, total; } piece;
+static int next_piece(devjob *w, piece *prev, piece *out) {
+    if (prev->q >= 0 && prev->o + prev->n < prev->total) { out->q = prev->q; out->total = prev->total; out->o = prev->o + prev->n; }
+    else {
         int32_t q = __atomic_fetch_add(w->next, 1, __ATOMIC_RELAXED);
-        if (q >= w->nq) break;
-        uint64_t off = w->qtext[q], bytes = w->qtext[q + 1] - off;
-        snprintf(fn, sizeof fn, "%s/grammar.%d.s", w->outdir, w->first + q);
-        int fd = open(fn, O_WRONLY | O_CREAT, 0644);
-        if (fd < 0) { w->rc = CGX_ERR_IO; break; }
-        int bad = 0;
-        for (uint64_t o = 0; o < bytes && !bad; o += PIN_BYTES) {
-            uint64_t n = bytes - o < PIN_BYTES ? bytes - o : PIN_BYTES;
-            if (cgx_text_read(w->ctx, w->slot, off + o, n, buf, w->tid & 15) != CGX_OK) { bad = 2; break; }
-            for (uint64_t k = 0; k < n;) { ssize_t r = write(fd, (char *)buf + k, n - k); if (r <= 0) { bad = 1; break; } k += (uint64_t)r; }
+        if (q >= w->nq) return 0;
+        out->q = q; out->o = 0; out->total = w->qtext[q + 1] - w->qtext[q];
+    }
+    out->n = out->total - out->o < PIN_BYTES ? out->total - out->o : PIN_BYTES;
+    return 1;
+}
+/* D2H of piece k+1 (own side stream) runs while piece k is being written to its file */
+static void *dev_write_worker(void *arg) {
+    devjob *w = arg; char fn[4096]; w->rc = CGX_OK; w->wait_ms = w->write_ms = 0;
+    for (int k = 0; k < 2; k++) { if (!g_pin[w->tid][k]) g_pin[w->tid][k] = cgx_pinned_alloc(PIN_BYTES); if (!g_pin[w->tid][k]) { w->rc = CGX_ERR_NOMEM; return NULL; } }
+    piece none = {-1, 0, 0, 0}, cur, nxt; int b = 0, fd = -1, have;
+    have = next_piece(w, &none, &cur);
+    if (have && cgx_text_read_begin(w->ctx, w->slot, w->qtext[cur.q] + cur.o, cur.n, g_pin[w->tid][0], 2 * w->tid) != CGX_OK) { w->rc = CGX_ERR_HIP; return NULL; }
+    while (have) {
+        int more = next_piece(w, &cur, &nxt);
+        if (more && cgx_text_read_begin(w->ctx, w->slot, w->qtext[nxt.q] + nxt.o, nxt.n, g_pin[w->tid][b ^ 1], 2 * w->tid + (b ^ 1)) != CGX_OK) w->rc = CGX_ERR_HIP;
+        double t0 = now_ms();
+        if (cgx_text_read_wait(w->ctx, 2 * w->tid + b) != CGX_OK) w->rc = CGX_ERR_HIP;
+        double t1 = now_ms(); w->wait_ms += t1 - t0;
+        if (w->rc == CGX_OK) {
+            if (cur.o == 0) {
+                snprintf(fn, sizeof fn, "%s/grammar.%d.s", w->outdir, w->first + cur.q);
+                fd = open(fn, O_WRONLY | O_CREAT, 0644);
+                if (fd < 0) w->rc = CGX_ERR_IO;
+            }
+            const char *src = g_pin[w->tid][b];
+            for (uint64_t k = 0; w->rc == CGX_OK && k < cur.n;) { ssize_t r = write(fd, src + k, cur.n - k); if (r <= 0) w->rc = CGX_ERR_IO; else k += (uint64_t)r; }
+            if (fd >= 0 && cur.o + cur.n >= cur.total) { if (w->rc == CGX_OK && ftruncate(fd, (off_t)cur.total)) w->rc = CGX_ERR_IO; close(fd); fd = -1; }
         }
-        if (!bad && ftruncate(fd, (off_t)bytes)) bad = 1;
-        close(fd);
-        if (bad) { w->rc = bad == 2 ? CGX_ERR_HIP : CGX_ERR_IO; break; }
+        w->write_ms += now_ms() - t1;
+        if (w->rc != CGX_OK) {                              /* drain the copy in flight before the buffers are reused */
+            if (more) (void)cgx_text_read_wait(w->ctx, 2 * w->tid + (b ^ 1));
+            if (fd >= 0) close(fd);
+            return NULL;
+        }
+        cur = nxt; have = more; b ^= 1;
     }
     return NULL;
 }
-static int write_from_device(cgx_ctx *ctx, int slot, const uint64_t *qtext, int32_t nq, const char *outdir, int32_t first) {
-    int nt = nthreads_host(); if (nt > 16) nt = 16; if (nt > nq) nt = nq > 0 ? nq : 1;
-    devjob jobs[16]; pthread_t th[16]; int32_t next = 0;
+static int write_from_device(cgx_ctx *ctx, int slot, const uint64_t *qtext, int32_t nq, const char *outdir, int32_t first, double *wait_ms, double *file_ms) {
+    int nt = nthreads_host(); if (nt > MAX_WRITERS) nt = MAX_WRITERS; if (nt > nq) nt = nq > 0 ? nq : 1;
+    devjob jobs[MAX_WRITERS]; pthread_t th[MAX_WRITERS]; int32_t next = 0;
     for (int t = 0; t < nt; t++) { jobs[t].ctx = ctx; jobs[t].slot = slot; jobs[t].qtext = qtext; jobs[t].nq = nq; jobs[t].first = first; jobs[t].outdir = outdir; jobs[t].next = &next; jobs[t].tid = t; jobs[t].rc = CGX_OK; }
     for (int t = 1; t < nt; t++) if (pthread_create(&th[t], NULL, dev_write_worker, &jobs[t])) return CGX_ERR_NOMEM;
     dev_write_worker(&jobs[0]);
     for (int t = 1; t < nt; t++) pthread_join(th[t], NULL);
-    for (int t = 0; t < nt; t++) if (jobs[t].rc != CGX_OK) return jobs[t].rc;
+    double wait = 0, wr = 0;
+    for (int t = 0; t < nt; t++) { if (jobs[t].rc != CGX_OK) return jobs[t].rc; wait += jobs[t].wait_ms; wr += jobs[t].write_ms; }
+    *wait_ms = wait / nt; *file_ms = wr / nt;                /* per-thread averages; reported by the caller's thread */
     return CGX_OK;
 }
 
@@ -819,25 +843,29 @@ static uint64_t count_lines(const batch *b) {
     }
     return n;
 }
-typedef struct { batch *b; char *outdir; int32_t first; pthread_t th; int active, rc; uint64_t lines; double ms;
+typedef struct { batch *b; char *outdir; int32_t first; pthread_t th; int active, rc; uint64_t lines; double ms, wait_ms, file_ms;
                  cgx_ctx *ctx; int dev, slot; uint64_t *qtext; int32_t nq; } pending;
 static void *pending_main(void *arg) {
     pending *pw = arg; double t = now_ms();
-    pw->rc = pw->dev ? write_from_device(pw->ctx, pw->slot, pw->qtext, pw->nq, pw->outdir, pw->first) : write_grammars(pw->b, pw->outdir, pw->first, &pw->lines);
+    pw->rc = pw->dev ? write_from_device(pw->ctx, pw->slot, pw->qtext, pw->nq, pw->outdir, pw->first, &pw->wait_ms, &pw->file_ms) : write_grammars(pw->b, pw->outdir, pw->first, &pw->lines);
     pw->ms = now_ms() - t;
     return NULL;
 }
 
 static int run_batch(cgx_ctx *ctx, const cgx_corpus *c, batch *b, const char *outdir, int32_t first, uint64_t *nrules, int *handed_off) {
-    int rc; double t0 = now_ms(), t;
+    int rc; double t0 = now_ms(), t, tl = t0;
+#define LAP(name) do { double n_ = now_ms(); cgx__set_host_ms(ctx, "t_" name, n_ - tl); tl = n_; } while (0)
     b->c = c;
     if ((rc = cgx_upload_queries(ctx, b->qoff, b->nq, b->qtok, b->ntok)) != CGX_OK) return rc;
     if ((rc = cgx_sa_lookup(ctx)) != CGX_OK) return rc;
+    LAP("upload_sa");
     if ((rc = fetch_alloc(ctx, "lm", (void **)&b->lm, 4, NULL)) || (rc = fetch_alloc(ctx, "up", (void **)&b->up, 4, NULL)) || (rc = fetch_alloc(ctx, "down", (void **)&b->down, 4, NULL))) return rc;
+    LAP("fetch_lm");
     t = now_ms();
     if ((rc = make_blocks(ctx, b)) != CGX_OK) return rc;
     cgx__set_host_ms(ctx, "blocks", now_ms() - t);
     if ((rc = cgx_set_blocks(ctx, b->blocks, b->g)) != CGX_OK) return rc;   /* also fills string_start = sa[start] (ExtractPair.cu:2798) */
+    LAP("blocks");
     const int devfmt = outdir && cgx__option(ctx, "device_format");
     if (devfmt) {                                             /* per-query block lists as CSR for the device formatter */
         uint32_t *off = malloc(((size_t)b->nq + 1) * 4); size_t tot = 0;
@@ -852,16 +880,21 @@ static int run_batch(cgx_ctx *ctx, const cgx_corpus *c, batch *b, const char *ou
         if (rc == CGX_OK) rc = ensure_vocab(ctx, c);
         if (rc != CGX_OK) return rc;
     }
+    LAP("qblocks");
     if ((rc = cgx_gappy_search(ctx)) != CGX_OK) return rc;
+    LAP("gappy");
     if ((rc = cgx_extract(ctx)) != CGX_OK) return rc;
+    LAP("extract");
     /* lexicon + MaxLex features on the device (host path only if a target-side hash collides) */
     int exact_host = 0;
     rc = cgx_lexicon(ctx);
     if (rc == CGX_ERR_STATE && strstr(cgx_last_error(ctx), "hash collision")) exact_host = 1; else if (rc != CGX_OK) return rc;
+    LAP("lexicon");
     if (devfmt && !exact_host) {
         /* the text of every file is laid out on the GPU; host threads only pull byte ranges and write them */
         uint64_t bytes = 0, nl = 0; int slot = 0;
         rc = cgx_format(ctx, &bytes, &nl, &slot);
+        LAP("format");
         if (rc == CGX_OK) {
             uint64_t *qtext = malloc(((size_t)b->nq + 2) * 8);
             if (!qtext) return CGX_ERR_NOMEM;
@@ -869,7 +902,9 @@ static int run_batch(cgx_ctx *ctx, const cgx_corpus *c, batch *b, const char *ou
             if (nrules) *nrules = nl;
             fprintf(stderr, "Start Printing Gappy Phrases...\n");
             if (cgx__option(ctx, "async_write")) {
+                LAP("offsets");
                 if ((rc = cgx_flush(ctx)) != CGX_OK) { free(qtext); return rc; }
+                LAP("flush_wait");
                 pending *pw = calloc(1, sizeof *pw);
                 if (!pw) { free(qtext); return CGX_ERR_NOMEM; }
                 pw->dev = 1; pw->ctx = ctx; pw->slot = slot; pw->qtext = qtext; pw->nq = b->nq; pw->outdir = strdup(outdir); pw->first = first; pw->active = 1;
@@ -877,9 +912,10 @@ static int run_batch(cgx_ctx *ctx, const cgx_corpus *c, batch *b, const char *ou
                 cgx__set_host_state(ctx, pw);
             } else {
                 t = now_ms();
-                rc = write_from_device(ctx, slot, qtext, b->nq, outdir, first);
+                double wm = 0, fm = 0;
+                rc = write_from_device(ctx, slot, qtext, b->nq, outdir, first, &wm, &fm);
                 free(qtext);
-                cgx__set_host_ms(ctx, "write", now_ms() - t);
+                cgx__set_host_ms(ctx, "write", now_ms() - t); cgx__set_host_ms(ctx, "write_wait_d2h", wm); cgx__set_host_ms(ctx, "write_file", fm);
                 if (rc != CGX_OK) return rc;
             }
             cgx__set_host_ms(ctx, "lists", 0); cgx__set_host_ms(ctx, "lexicon", 0);
@@ -990,6 +1026,7 @@ int cgx_flush(cgx_ctx *ctx) {
     pthread_join(pw->th, NULL);
     int rc = pw->rc;
     cgx__set_host_ms(ctx, "write", pw->ms);
+    if (pw->dev) { cgx__set_host_ms(ctx, "write_wait_d2h", pw->wait_ms); cgx__set_host_ms(ctx, "write_file", pw->file_ms); }
     cgx__set_host_state(ctx, NULL);
     if (pw->b) { batch_free(pw->b); free(pw->b); }
     free(pw->qtext); free(pw->outdir); free(pw);

@@ -109,7 +109,10 @@ int cgx_upload_score_tables(cgx_ctx *ctx, const float *aa, const float *bb, cons
 int cgx_set_query_blocks(cgx_ctx *ctx, const uint32_t *off, const uint32_t *ids);    /* CSR over the batch's queries */
 int cgx_format(cgx_ctx *ctx, uint64_t *total_bytes, uint64_t *total_lines, int *slot); /* after cgx_lexicon; two text slots alternate */
 int cgx_text_offsets(cgx_ctx *ctx, int slot, uint64_t *qtext);                       /* nq+1 byte offsets of the queries' text in that slot */
-int cgx_text_read(cgx_ctx *ctx, int slot, uint64_t off, uint64_t bytes, void *dst, int reader); /* D2H on side stream `reader` (0..15), thread safe per reader */
+#define CGX_MAX_READERS 64
+int cgx_text_read(cgx_ctx *ctx, int slot, uint64_t off, uint64_t bytes, void *dst, int reader); /* D2H on side stream `reader` (0..CGX_MAX_READERS-1), thread safe per reader */
+int cgx_text_read_begin(cgx_ctx *ctx, int slot, uint64_t off, uint64_t bytes, void *dst, int reader); /* the same copy, only enqueued */
+int cgx_text_read_wait(cgx_ctx *ctx, int reader);                                                      /* wait for everything enqueued on `reader` */
 void *cgx_pinned_alloc(size_t bytes);
 void cgx_pinned_free(void *p);
 
