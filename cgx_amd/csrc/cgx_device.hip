@@ -917,62 +917,163 @@ __device__ __forceinline__ uint32_t rec_lower(const uint64_t *reckey, uint32_t r
     while (r0 < r1) { uint32_t m = (r0 + r1) >> 1; if ((uint32_t)(reckey[m] & ((1u << REC_TOKBITS) - 1)) < tk) r0 = m + 1; else r1 = m; }
     return r0;
 }
-__global__ __launch_bounds__(256) void k_look1(cgx_view v, const int32_t *sa, const cgx_gapsearch *s1, const grp1 *groups, const uint64_t *woff, uint32_t ng,
-                        uint64_t w0, uint64_t nw, const int32_t *qtok, const uint64_t *reckey, const uint32_t *recpid, h64 H, appender ap) {
+// One block = one tile of L1_TILE occurrences of ONE group's driving phrase.  The group's pattern
+// records (other side's tokens, pattern id) are staged in LDS with a small hash on the first token,
+// so that walking a window costs LDS probes only; global memory is touched for the SA slice
+// (coalesced), the text window, the alignment words of the gap (same stride as the window) and,
+// for candidates whose tokens match, the target-side tightness test.  The gap's target span is
+// accumulated while the window is walked (cgx_gap_ok restated incrementally: start/end token
+// aligned, span < 15, tight) instead of being rebuilt per candidate.
+// Groups with more than L1_REC records (or an over-long other side) take the same walk with the
+// records read from global memory through the batch-wide hash.
+#define L1_TILE 1024
+#define L1_REC 256
+#define L1_SLOTS 512
+#define L1_EMPTY 0xFFFFFFFFu
+// cgx_tight for a target span of at most 16 words (te - ts <= 15): both byte tables are read
+// with five aligned dword loads each instead of a byte per word (the tables are padded).
+__device__ __forceinline__ bool tight16(const cgx_view &v, int ts, int te, int s_chk, int e_chk, int src0) {
+    const uint32_t *pl = (const uint32_t *)(v.ltar + (ts & ~3)), *pr = (const uint32_t *)(v.rtar + (ts & ~3));
+    uint32_t a[5], b[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) { a[i] = pl[i]; b[i] = pr[i]; }
+    const unsigned sh = (unsigned)ts & 3u;
+    int lo = 255, hi = 0; const int last = te - ts;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t l4 = __builtin_amdgcn_alignbyte(a[i + 1], a[i], sh), r4 = __builtin_amdgcn_alignbyte(b[i + 1], b[i], sh);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int L = (int)((l4 >> (8 * k)) & 0xFF), R = (int)((r4 >> (8 * k)) & 0xFF);
+            if (4 * i + k <= last && L != 255 && R != 255) { if (lo > L) lo = L; if (hi < R) hi = R; }
+        }
+    }
+    return src0 + lo == s_chk && src0 + hi == e_chk;
+}
+// 16 consecutive text tokens and their alignment words starting at the first gap token and
+// running away from the driving phrase (ascending addresses when walking right, descending when
+// walking left), fetched with wide loads in one go.  The arrays are padded past the corpus end;
+// only a window that would start before token 0 takes the guarded path.
+__device__ __forceinline__ void load_window(const cgx_view &v, int64_t edge, bool bw, int32_t (&ws)[16], uint32_t (&wr)[16]) {
+    const int64_t base = bw ? edge - 15 : edge;
+    if (base >= 0) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) { ws[j] = v.str[base + j]; wr[j] = v.rlp[base + j]; }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; j++) { const int64_t q = base + j; ws[j] = q >= 0 ? v.str[q] : 0; wr[j] = q >= 0 ? v.rlp[q] : 0xFFFFFFFFu; }
+    }
+    if (bw) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) { int32_t t = ws[j]; ws[j] = ws[15 - j]; ws[15 - j] = t; uint32_t u = wr[j]; wr[j] = wr[15 - j]; wr[15 - j] = u; }
+    }
+}
+struct l1rec { uint32_t tok, id; int32_t extra[2]; uint32_t olen; };
+__device__ __forceinline__ l1rec l1_load(const grp1 &gr, uint32_t r, const uint64_t *reckey, const uint32_t *recpid, const cgx_gapsearch *s1, const int32_t *qtok) {
+    l1rec o; o.tok = (uint32_t)(reckey[r] & ((1u << REC_TOKBITS) - 1)); o.id = recpid[r];
+    cgx_gapsearch s = s1[o.id];
+    o.extra[0] = o.extra[1] = -1;
+    if (!gr.backward) { o.olen = (uint32_t)s.b_len; const int32_t sb = s.qrystart + s.gap + s.a_len; for (uint32_t k = 1; k < o.olen && k < 3; k++) o.extra[k - 1] = qtok[sb + k]; }
+    else { o.olen = (uint32_t)s.a_len; const int32_t t = s.qrystart; for (uint32_t k = 1; k < o.olen && k < 3; k++) o.extra[k - 1] = qtok[t + (int)o.olen - 1 - (int)k]; }
+    return o;
+}
+__global__ __launch_bounds__(256) void k_look1(cgx_view v, const int32_t *sa, const cgx_gapsearch *s1, const grp1 *groups, const uint64_t *toff, const uint64_t *work, uint32_t ng,
+                        uint64_t tile0, const int32_t *qtok, const uint64_t *reckey, const uint32_t *recpid, h64 H, appender ap) {
     __shared__ uint64_t stash[STASH_K][256];
-    uint64_t wi = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-    uint32_t n = 0;
-    if (wi < nw) {
-    uint32_t g = seg_of(woff, ng, w0 + wi);
-    uint64_t x = w0 + wi - woff[g];
-    grp1 gr = groups[g];
-    const int dl = (int)gr.len;                            // length of the driving phrase
-    int64_t go = sa[gr.base + x];
-    if (!gr.backward) {                                    // driving phrase is a: walk right (GappyLook.cu:335-396)
-        if (v.str[go + dl] >= 2) {
-            for (int move = 0; dl + 1 + move + 1 <= CGX_MAX_SPAN; move++) {
-                int64_t pos = go + dl + 1 + move;
-                int32_t tk = v.str[pos];
-                if (tk < 2) break;
-                uint32_t r;
-                if (!h64_find(H.keys, H.vals, H.mask, H.shift, (((uint64_t)g << REC_TOKBITS) | (uint32_t)tk) + 1, &r)) continue;
-                int gapok = -1;
-                for (; r < gr.rec1 && (uint32_t)(reckey[r] & ((1u << REC_TOKBITS) - 1)) == (uint32_t)tk; r++) {
-                    uint32_t id = recpid[r]; cgx_gapsearch s = s1[id];
-                    const int bl = s.b_len; const int32_t sb = s.qrystart + s.gap + s.a_len;
-                    if (dl + 1 + move + bl > CGX_MAX_SPAN) continue;
-                    bool ok = true;
-                    for (int k = 1; ok && k < bl; k++) ok = v.str[pos + k] == qtok[sb + k];
-                    if (!ok) continue;
-                    if (gapok < 0) gapok = cgx_gap_ok(v, (uint32_t)(go + dl), (uint32_t)(go + dl + move)) ? 1 : 0;
-                    if (gapok) stash_put(stash, n, ap, HITKEY(id, go, dl + 1 + move + bl - 1));
-                }
-            }
-        }
-    } else {                                               // driving phrase is b: walk left (GappyLook.cu:397-470)
-        if (go - 1 >= 0 && v.str[go - 1] >= 2) {
-            for (int move = 0; dl + 1 + move + 1 <= CGX_MAX_SPAN; move++) {
-                int64_t pa = go - 2 - move;
-                int32_t tk = pa < 0 ? -1 : v.str[pa];
-                if (tk < 2) break;
-                uint32_t r;
-                if (!h64_find(H.keys, H.vals, H.mask, H.shift, (((uint64_t)g << REC_TOKBITS) | (uint32_t)tk) + 1, &r)) continue;
-                int gapok = -1;
-                for (; r < gr.rec1 && (uint32_t)(reckey[r] & ((1u << REC_TOKBITS) - 1)) == (uint32_t)tk; r++) {
-                    uint32_t id = recpid[r]; cgx_gapsearch s = s1[id];
-                    const int al = s.a_len; const int32_t t = s.qrystart;
-                    if (al + 1 + move + dl > CGX_MAX_SPAN) continue;
-                    bool ok = true;
-                    for (int k = 1; ok && k < al; k++) ok = pa - k >= 0 && v.str[pa - k] == qtok[t + al - 1 - k];
-                    if (!ok) continue;
-                    if (gapok < 0) gapok = cgx_gap_ok(v, (uint32_t)(pa + 1), (uint32_t)(go - 1)) ? 1 : 0;
-                    if (gapok) stash_put(stash, n, ap, HITKEY(id, pa - al + 1, dl + 1 + move + al - 1));
-                }
+    __shared__ l1rec recs[L1_REC];
+    __shared__ uint32_t hkey[L1_SLOTS];
+    __shared__ uint16_t hval[L1_SLOTS];
+    __shared__ int s_big;
+    const uint64_t tg = tile0 + blockIdx.x;
+    const uint32_t g = seg_of(toff, ng, tg);
+    const uint64_t x0 = (tg - toff[g]) * L1_TILE, wg = work[g];
+    const grp1 gr = groups[g];
+    const uint32_t R = gr.rec1 - gr.rec0;
+    for (uint32_t i = threadIdx.x; i < L1_SLOTS; i += 256) hkey[i] = L1_EMPTY;
+    if (threadIdx.x == 0) s_big = R > L1_REC ? 1 : 0;
+    __syncthreads();
+    if (R <= L1_REC) {
+        for (uint32_t r = threadIdx.x; r < R; r += 256) {
+            l1rec e = l1_load(gr, gr.rec0 + r, reckey, recpid, s1, qtok);
+            recs[r] = e;
+            if (e.olen > 3) s_big = 1;
+            if (r == 0 || (uint32_t)(reckey[gr.rec0 + r - 1] & ((1u << REC_TOKBITS) - 1)) != e.tok) {
+                uint32_t slot = (e.tok * 0x9E3779B1u) >> 23;
+                while (atomicCAS(&hkey[slot], L1_EMPTY, e.tok) != L1_EMPTY) slot = (slot + 1) & (L1_SLOTS - 1);
+                hval[slot] = (uint16_t)r;
             }
         }
     }
+    __syncthreads();
+    const bool big = s_big != 0;
+    const int dl = (int)gr.len;                              // length of the driving phrase
+    const bool bw = gr.backward != 0;
+    for (uint32_t it = 0; it < L1_TILE / 256; it++) {
+        uint32_t n = 0;
+        const uint64_t x = x0 + (uint64_t)it * 256 + threadIdx.x;
+        if (x < wg) {
+            const int64_t go = sa[gr.base + x];
+            // first gap token (walking right: just after a; walking left: just before b)
+            const int64_t edge = bw ? go - 1 : go + dl;
+            if (edge >= 0) {
+                // the whole window in registers, logical index j = distance from the first gap token
+                int32_t ws[16]; uint32_t wr[16];
+                load_window(v, edge, bw, ws, wr);
+                if (ws[0] >= 2 && !cgx_unaligned(wr[0])) {
+                    const int64_t prev_delim = edge - cgx_P(wr[0]) - 1;
+                    const int src0 = (int)(prev_delim + 1), tb = prev_delim == -1 ? 0 : (int)v.rlp[prev_delim];
+                    int lo = cgx_L(wr[0]), hi = cgx_R(wr[0]);
+#pragma unroll
+                    for (int move = 0; move <= CGX_MAX_SPAN - 3; move++) {
+                        if (dl + 1 + move + 1 > CGX_MAX_SPAN) break;
+                        const int32_t tk = ws[move + 1];          // first token of the other side
+                        if (tk < 2) break;
+                        bool far_ok = true;                       // the gap token next to the other side must be aligned too
+                        if (move > 0) {
+                            const uint32_t w = wr[move];
+                            far_ok = !cgx_unaligned(w);
+                            if (far_ok) { int L = cgx_L(w), Rr = cgx_R(w); if (lo > L) lo = L; if (hi < Rr) hi = Rr; }
+                        }
+                        if (hi - lo >= CGX_MAX_SPAN) break;       // the span only grows
+                        uint32_t r, rend;
+                        if (!big) {
+                            uint32_t slot = ((uint32_t)tk * 0x9E3779B1u) >> 23; bool found = false;
+                            for (;;) { uint32_t k = hkey[slot]; if (k == (uint32_t)tk) { found = true; break; } if (k == L1_EMPTY) break; slot = (slot + 1) & (L1_SLOTS - 1); }
+                            if (!found) continue;
+                            r = hval[slot]; rend = R;
+                        } else {
+                            if (!h64_find(H.keys, H.vals, H.mask, H.shift, (((uint64_t)g << REC_TOKBITS) | (uint32_t)tk) + 1, &r)) continue;
+                            rend = gr.rec1;
+                        }
+                        const int64_t pos = bw ? edge - 1 - move : edge + 1 + move;
+                        int gapok = far_ok ? -1 : 0;
+                        for (; r < rend; r++) {
+                            l1rec e;
+                            if (!big) e = recs[r]; else e = l1_load(gr, r, reckey, recpid, s1, qtok);
+                            if (e.tok != (uint32_t)tk) break;
+                            const int ol = (int)e.olen;
+                            if (dl + 1 + move + ol > CGX_MAX_SPAN) continue;
+                            bool ok = true;
+                            if (ol <= 3) { if (ol > 1) ok = ws[move + 2] == e.extra[0]; if (ok && ol > 2) ok = ws[(move + 3) & 15] == e.extra[1]; }
+                            else {                                 // over-long other side: compare against the query text
+                                cgx_gapsearch sq = s1[e.id];
+                                for (int k = 1; ok && k < ol; k++) { int64_t q = bw ? pos - k : pos + k; ok = q >= 0 && v.str[q] == (bw ? qtok[sq.qrystart + ol - 1 - k] : qtok[sq.qrystart + sq.gap + sq.a_len + k]); }
+                            }
+                            if (!ok) continue;
+                            if (gapok < 0) gapok = bw ? (tight16(v, lo + tb, hi + tb, (int)(pos + 1), (int)edge, src0) ? 1 : 0)
+                                                      : (tight16(v, lo + tb, hi + tb, (int)edge, (int)(pos - 1), src0) ? 1 : 0);
+                            if (gapok) stash_put(stash, n, ap, bw ? HITKEY(e.id, pos - ol + 1, dl + 1 + move + ol - 1) : HITKEY(e.id, go, dl + 1 + move + ol - 1));
+                        }
+                    }
+                }
+            }
+        }
+        stash_flush(stash, n, ap);
     }
-    stash_flush(stash, n, ap);
+}
+__global__ void k_tiles(const uint64_t *work, uint32_t ng, uint32_t tile, uint64_t *tiles) {
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < ng) tiles[g] = (work[g] + tile - 1) / tile;
 }
 __global__ void k_unpack_hits1(const uint64_t *keys, uint32_t n, cgx_hit1 *hits, cgx_gapsearch *s1) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -996,12 +1097,13 @@ static int dvec_reserve(cgx_ctx *ctx, dvec64 &v, size_t need) {
     return CGX_OK;
 }
 
-// Run a single-pass appending kernel over work items [0,W) (in launches of at most chunk_items).
+// Run a single-pass appending kernel over `units` launch units (in launches of at most `chunk`)
+// that together cover W work items.
 // `out` already holds out.n records; the kernel appends after them.  The capacity is a guess
 // (`per_item` records per work item, remembered from the previous batch); if the launch counted
 // more than fits it is rerun once with the exact size.
 template <class Launch>
-static int append_pass(cgx_ctx *ctx, uint64_t W, dvec64 &out, double *per_item, Launch launch) {
+static int append_pass(cgx_ctx *ctx, uint64_t units, uint64_t chunk, uint64_t W, dvec64 &out, double *per_item, Launch launch) {
     unsigned long long *total = nullptr; TRY(dalloc(ctx, &total, 1));
     const size_t n0 = out.n;
     size_t want = n0 + (size_t)((double)W * *per_item) + ctx->append_slack;
@@ -1011,8 +1113,8 @@ static int append_pass(cgx_ctx *ctx, uint64_t W, dvec64 &out, double *per_item, 
             HIPCHK(hipStreamSynchronize(ctx->stream)); dfree(out.p); out.p = np; out.cap = want; }
         unsigned long long init = n0; TRY(h2d(ctx, total, &init, 1));
         appender ap{out.p, out.cap, total};
-        for (uint64_t w0 = 0; w0 < W; w0 += ctx->chunk_items) {
-            uint64_t nw = W - w0 < ctx->chunk_items ? W - w0 : ctx->chunk_items;
+        for (uint64_t w0 = 0; w0 < units; w0 += chunk) {
+            uint64_t nw = units - w0 < chunk ? units - w0 : chunk;
             launch(w0, nw, ap);
         }
         HIPCHK(hipGetLastError());
@@ -1095,35 +1197,84 @@ __global__ void k_s2hash_fill(const cgx_twogapsearch *s2, const int32_t *s2c, ui
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < d2 && s2[i].c_len == 1) h64_insert((unsigned long long *)H.keys, H.vals, H.mask, H.shift, (((uint64_t)s2[i].blockid << 32) | (uint32_t)s2c[i]) + 1, i);
 }
-// hit record: pattern(<=24 bits) | start(32) | len(4) | len2(4) when the pattern id fits, else the id travels separately
+// hit record: pattern(<=24 bits) | start(32) | len(4) | len2(4) when the pattern id fits, else the id travels separately.
+// Same shape as k_look1: one block = one tile of occurrences of ONE aXb; the c tokens that extend
+// it in this batch sit in an LDS hash (token -> two-gap pattern), the window after b and its
+// alignment words are fetched once into registers and the second gap's span is accumulated
+// while walking.  An aXb extended by more than L2_REC different c uses the batch-wide hash.
+#define L2_TILE 1024
+#define L2_REC 512
+#define L2_SLOTS 1024
 template <bool WIDE>
-__global__ __launch_bounds__(256) void k_look2(cgx_view v, const cgx_twogapsearch *s2, const int32_t *s2c, const cgx_gapsearch *s1, const grp2 *groups, const uint64_t *woff, uint32_t ng,
-                        uint64_t w0, uint64_t nw, const cgx_hit1 *hits1, const uint32_t *pidx, const uint32_t *phs, const uint8_t *phl, h64 H, appender ap, uint32_t *wide_id) {
+__global__ __launch_bounds__(256) void k_look2(cgx_view v, const cgx_twogapsearch *s2, const int32_t *s2c, const cgx_gapsearch *s1, const grp2 *groups, const uint64_t *toff, const uint64_t *work, uint32_t ng,
+                        uint64_t tile0, const cgx_hit1 *hits1, const uint32_t *pidx, const uint32_t *phs, const uint8_t *phl, h64 H, appender ap, uint32_t *wide_id) {
     __shared__ uint64_t stash[STASH_K][256];
-    uint64_t wi = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-    uint32_t n = 0;
-    if (wi < nw) {
-        uint32_t gi = seg_of(woff, ng, w0 + wi);
-        uint64_t x = w0 + wi - woff[gi];
-        grp2 gr = groups[gi]; cgx_gapsearch g = s1[gr.one];
-        uint32_t ps; int pl;
-        if (g.marker) { uint32_t pre = hits1[g.sa_start].str_position; uint32_t b = pidx[2 * pre]; ps = phs[b + x]; pl = phl[b + x]; }
-        else { cgx_hit1 h = hits1[g.sa_start + x]; ps = h.str_position; pl = h.length; }
-        int64_t go = (int64_t)ps + pl;
-        if (pl > 0 && v.str[go + 1] >= 2) {
-            for (int move = 0; pl + 3 + move <= CGX_MAX_SPAN; move++) {
-                int32_t tk = v.str[go + 2 + move];
-                if (tk < 2) break;
-                uint32_t a;                                      // the pattern (this aXb, c = tk), if the batch has it
-                if (h64_find(H.keys, H.vals, H.mask, H.shift, (((uint64_t)gr.one << 32) | (uint32_t)tk) + 1, &a) && cgx_gap_ok(v, ps + pl + 1, (uint32_t)(ps + pl + 1 + move))) {
-                    uint64_t rec = ((uint64_t)ps << 8) | ((uint64_t)pl << 4) | (uint64_t)(pl + 2 + move);
-                    if (!WIDE) stash_put(stash, n, ap, ((uint64_t)a << 40) | rec);
-                    else { uint64_t slot = lanes_reserve(ap.total); if (slot < ap.cap) { ap.out[slot] = rec; wide_id[slot] = a; } }
+    __shared__ uint32_t hkey[L2_SLOTS];
+    __shared__ uint32_t hval[L2_SLOTS];
+    const uint64_t tg = tile0 + blockIdx.x;
+    const uint32_t gi = seg_of(toff, ng, tg);
+    const uint64_t x0 = (tg - toff[gi]) * L2_TILE, wg = work[gi];
+    const grp2 gr = groups[gi]; const cgx_gapsearch g = s1[gr.one];
+    const uint32_t R = gr.s1 - gr.s0;
+    const bool big = R > L2_REC;
+    if (!big) {
+        for (uint32_t i = threadIdx.x; i < L2_SLOTS; i += 256) hkey[i] = L1_EMPTY;
+        __syncthreads();
+        for (uint32_t r = threadIdx.x; r < R; r += 256) {
+            if (s2[gr.s0 + r].c_len != 1) continue;
+            const uint32_t tok = (uint32_t)s2c[gr.s0 + r];
+            uint32_t slot = (tok * 0x9E3779B1u) >> 22;
+            while (atomicCAS(&hkey[slot], L1_EMPTY, tok) != L1_EMPTY) slot = (slot + 1) & (L2_SLOTS - 1);
+            hval[slot] = gr.s0 + r;
+        }
+        __syncthreads();
+    }
+    uint32_t listbase = 0;
+    if (g.marker) listbase = pidx[2 * hits1[g.sa_start].str_position];
+    for (uint32_t it = 0; it < L2_TILE / 256; it++) {
+        uint32_t n = 0;
+        const uint64_t x = x0 + (uint64_t)it * 256 + threadIdx.x;
+        if (x < wg) {
+            uint32_t ps; int pl;
+            if (g.marker) { ps = phs[listbase + x]; pl = phl[listbase + x]; }
+            else { cgx_hit1 h = hits1[g.sa_start + x]; ps = h.str_position; pl = h.length; }
+            const int64_t edge = (int64_t)ps + pl + 1;          // first token of the second gap
+            if (pl > 0) {
+                int32_t ws[16]; uint32_t wr[16];
+                load_window(v, edge, false, ws, wr);
+                if (ws[0] >= 2 && !cgx_unaligned(wr[0])) {
+                    const int64_t prev_delim = edge - cgx_P(wr[0]) - 1;
+                    const int src0 = (int)(prev_delim + 1), tb = prev_delim == -1 ? 0 : (int)v.rlp[prev_delim];
+                    int lo = cgx_L(wr[0]), hi = cgx_R(wr[0]);
+#pragma unroll
+                    for (int move = 0; move <= CGX_MAX_SPAN - 4; move++) {
+                        if (pl + 3 + move > CGX_MAX_SPAN) break;
+                        const int32_t tk = ws[move + 1];
+                        if (tk < 2) break;
+                        bool far_ok = true;
+                        if (move > 0) {
+                            const uint32_t w = wr[move];
+                            far_ok = !cgx_unaligned(w);
+                            if (far_ok) { int L = cgx_L(w), Rr = cgx_R(w); if (lo > L) lo = L; if (hi < Rr) hi = Rr; }
+                        }
+                        if (hi - lo >= CGX_MAX_SPAN) break;
+                        uint32_t a;                                  // the pattern (this aXb, c = tk), if the batch has it
+                        if (!big) {
+                            uint32_t slot = ((uint32_t)tk * 0x9E3779B1u) >> 22; bool found = false;
+                            for (;;) { uint32_t k = hkey[slot]; if (k == (uint32_t)tk) { found = true; break; } if (k == L1_EMPTY) break; slot = (slot + 1) & (L2_SLOTS - 1); }
+                            if (!found) continue;
+                            a = hval[slot];
+                        } else if (!h64_find(H.keys, H.vals, H.mask, H.shift, (((uint64_t)gr.one << 32) | (uint32_t)tk) + 1, &a)) continue;
+                        if (!far_ok || !tight16(v, lo + tb, hi + tb, (int)edge, (int)(edge + move), src0)) continue;
+                        const uint64_t rec = ((uint64_t)ps << 8) | ((uint64_t)pl << 4) | (uint64_t)(pl + 2 + move);
+                        if (!WIDE) stash_put(stash, n, ap, ((uint64_t)a << 40) | rec);
+                        else { uint64_t slot = lanes_reserve(ap.total); if (slot < ap.cap) { ap.out[slot] = rec; wide_id[slot] = a; } }
+                    }
                 }
             }
         }
+        if (!WIDE) stash_flush(stash, n, ap);
     }
-    if (!WIDE) stash_flush(stash, n, ap);
 }
 __global__ void k_s2c(const cgx_twogapsearch *s2, const int32_t *c2, uint32_t d2, int32_t *s2c) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1233,9 +1384,30 @@ extern "C" int cgx_gappy_search(cgx_ctx *ctx) {
             uint64_t W = 0; TRY(d2h(ctx, &W, woff + NG, 1));
             ctx->ms["look1_items"] = (double)W; ctx->ms["look1_groups"] = (double)NG;
             const cgx_gapsearch *s1 = ctx->d_s1; const int32_t *sa = ctx->d_sa, *qtok = ctx->d_qtok;
-            TRY(append_pass(ctx, W, keys, &ctx->look1_per_item, [&](uint64_t w0, uint64_t nw, appender ap) {
-                k_look1<<<nblocks(nw, 256), 256, 0, st>>>(v, sa, s1, groups, woff, NG, w0, nw, qtok, sreckey, srecpid, H, ap);
+            if (getenv("CGX_DIAG_GROUPS")) {                    // work / record-count distribution of the groups (stderr)
+                std::vector<grp1> hg(NG); std::vector<uint64_t> hw((size_t)NG + 1);
+                TRY(d2h(ctx, hg.data(), groups, NG)); TRY(d2h(ctx, hw.data(), woff, (size_t)NG + 1));
+                double wsum[8] = {0}, rsum[8] = {0}; uint64_t cnt[8] = {0};
+                double wr[8] = {0};
+                for (uint32_t g = 0; g < NG; g++) {
+                    uint64_t w = hw[g + 1] - hw[g]; uint32_t r = hg[g].rec1 - hg[g].rec0;
+                    int bw = w < 64 ? 0 : w < 256 ? 1 : w < 1024 ? 2 : w < 4096 ? 3 : w < 16384 ? 4 : w < 65536 ? 5 : w < 262144 ? 6 : 7;
+                    int br = r < 16 ? 0 : r < 64 ? 1 : r < 256 ? 2 : r < 1024 ? 3 : r < 4096 ? 4 : r < 16384 ? 5 : r < 65536 ? 6 : 7;
+                    wsum[bw] += (double)w; cnt[bw]++; rsum[bw] += r; wr[br] += (double)w;
+                }
+                fprintf(stderr, "look1 groups=%u items=%llu records=%u\n", NG, (unsigned long long)W, NR);
+                for (int k = 0; k < 8; k++) fprintf(stderr, "  work-bucket %d: groups %llu work %.3g (%.1f%%) avg records %.1f | work in record-bucket %d: %.1f%%\n", k, (unsigned long long)cnt[k], wsum[k], 100 * wsum[k] / (double)W, cnt[k] ? rsum[k] / cnt[k] : 0.0, k, 100 * wr[k] / (double)W);
+            }
+            uint64_t *tiles = nullptr, *toff = nullptr; TRY(dalloc(ctx, &tiles, (size_t)NG + 1)); TRY(dalloc(ctx, &toff, (size_t)NG + 1));
+            HIPCHK(hipMemsetAsync(tiles, 0, ((size_t)NG + 1) * 8, st));
+            k_tiles<<<nblocks(NG, 256), 256, 0, st>>>(work, NG, L1_TILE, tiles);
+            TRY(excl_scan(ctx, tiles, toff, (size_t)NG + 1));
+            uint64_t NT = 0; TRY(d2h(ctx, &NT, toff + NG, 1));
+            const uint64_t tile_chunk = ctx->chunk_items / 64 ? (ctx->chunk_items / 64 < (1ull << 30) ? ctx->chunk_items / 64 : (1ull << 30)) : 1;
+            TRY(append_pass(ctx, NT, tile_chunk, W, keys, &ctx->look1_per_item, [&](uint64_t t0, uint64_t nt, appender ap) {
+                k_look1<<<(unsigned)nt, 256, 0, st>>>(v, sa, s1, groups, toff, work, NG, t0, qtok, sreckey, srecpid, H, ap);
             }));
+            dfree(tiles); dfree(toff);
             dfree(flags); dfree(incl); dfree(groups); dfree(gdown); dfree(work); dfree(woff); dfree(H.keys); dfree(H.vals);
         }
         if (keys.n > 0xFFFFFFF0ull) { snprintf(ctx->err, sizeof ctx->err, "too many one-gap occurrences"); return CGX_ERR_NOMEM; }
@@ -1309,9 +1481,15 @@ extern "C" int cgx_gappy_search(cgx_ctx *ctx) {
         const unsigned idbits = (unsigned)bits_for(D2);
         const bool wide = idbits > 24 || ctx->wide_hits2;          // the pattern id does not fit beside the 40-bit occurrence
         dvec64 recs; uint32_t *wid = nullptr; size_t accn = 0;
+        uint64_t *tiles = nullptr, *toff = nullptr; TRY(dalloc(ctx, &tiles, (size_t)NG + 1)); TRY(dalloc(ctx, &toff, (size_t)NG + 1));
+        HIPCHK(hipMemsetAsync(tiles, 0, ((size_t)NG + 1) * 8, st));
+        k_tiles<<<nblocks(NG, 256), 256, 0, st>>>(work, NG, L2_TILE, tiles);
+        TRY(excl_scan(ctx, tiles, toff, (size_t)NG + 1));
+        uint64_t NT = 0; TRY(d2h(ctx, &NT, toff + NG, 1));
+        const uint64_t tile_chunk = ctx->chunk_items / 64 ? (ctx->chunk_items / 64 < (1ull << 30) ? ctx->chunk_items / 64 : (1ull << 30)) : 1;
         if (!wide) {
-            TRY(append_pass(ctx, W, recs, &ctx->look2_per_item, [&](uint64_t w0, uint64_t nw, appender ap) {
-                k_look2<false><<<nblocks(nw, 256), 256, 0, st>>>(v, ctx->d_s2, s2c, ctx->d_s1, groups, woff, NG, w0, nw, ctx->d_hits1, ctx->d_pidx, ctx->d_phit_start, ctx->d_phit_len, H2, ap, nullptr);
+            TRY(append_pass(ctx, NT, tile_chunk, W, recs, &ctx->look2_per_item, [&](uint64_t t0, uint64_t nt, appender ap) {
+                k_look2<false><<<(unsigned)nt, 256, 0, st>>>(v, ctx->d_s2, s2c, ctx->d_s1, groups, toff, work, NG, t0, ctx->d_hits1, ctx->d_pidx, ctx->d_phit_start, ctx->d_phit_len, H2, ap, nullptr);
             }));
             accn = recs.n;
         } else {
@@ -1319,15 +1497,16 @@ extern "C" int cgx_gappy_search(cgx_ctx *ctx) {
             for (int pass = 0; pass < 2; pass++) {
                 unsigned long long *total = nullptr; TRY(dalloc(ctx, &total, 1)); HIPCHK(hipMemsetAsync(total, 0, 8, st));
                 appender ap{recs.p, recs.cap, total};
-                for (uint64_t w0 = 0; w0 < W; w0 += ctx->chunk_items) {
-                    uint64_t nw = W - w0 < ctx->chunk_items ? W - w0 : ctx->chunk_items;
-                    k_look2<true><<<nblocks(nw, 256), 256, 0, st>>>(v, ctx->d_s2, s2c, ctx->d_s1, groups, woff, NG, w0, nw, ctx->d_hits1, ctx->d_pidx, ctx->d_phit_start, ctx->d_phit_len, H2, ap, wid);
+                for (uint64_t t0 = 0; t0 < NT; t0 += tile_chunk) {
+                    uint64_t nt = NT - t0 < tile_chunk ? NT - t0 : tile_chunk;
+                    k_look2<true><<<(unsigned)nt, 256, 0, st>>>(v, ctx->d_s2, s2c, ctx->d_s1, groups, toff, work, NG, t0, ctx->d_hits1, ctx->d_pidx, ctx->d_phit_start, ctx->d_phit_len, H2, ap, wid);
                 }
                 unsigned long long got = 0; TRY(d2h(ctx, &got, total, 1)); dfree(total);
                 accn = (size_t)got;
                 if (pass == 0) { TRY(dvec_reserve(ctx, recs, accn + 1)); TRY(dalloc(ctx, &wid, accn + 1)); }
             }
         }
+        dfree(tiles); dfree(toff);
         HIPCHK(hipGetLastError());
         if (accn > 0xFFFFFFF0ull) { snprintf(ctx->err, sizeof ctx->err, "too many two-gap occurrences"); return CGX_ERR_NOMEM; }
         if (accn) {
