@@ -151,13 +151,16 @@ __device__ __forceinline__ uint32_t wave_append(unsigned int *counter, bool vali
 }
 
 // ---- single-pass variable-output append ---------------------------------------------
-// A lane that produces a variable number of u64 records keeps its first STASH_K in LDS and
-// appends the rest directly (one atomic per group of lanes that overflow together).  At the end
-// of the kernel each wave reserves room for its stashed records with ONE atomic and copies them
-// out.  The global counter keeps counting past `cap`, so the host learns the exact size needed
-// when a launch overflows and can rerun it; nothing is written beyond `cap`.
-#define STASH_K 6
+// Lanes that produce a variable number of u64 records put them into a per-block LDS pool (LDS
+// atomic on the fill count).  At block-uniform points the pool is drained: ONE global atomic
+// reserves room for the whole pool and the block copies it out coalesced -- a single output
+// counter cannot absorb one atomic per wave (same-address atomics serialise in one L2 channel).
+// A record that finds the pool full is appended directly.  The global counter keeps counting
+// past `cap`, so the host learns the exact size needed when a launch overflows and can rerun
+// it; nothing is written beyond `cap`.
+#define POOL_N 2048
 struct appender { uint64_t *out; uint64_t cap; unsigned long long *total; };
+struct pool_t { uint64_t buf[POOL_N]; unsigned int n, snap; unsigned long long base; };
 __device__ __forceinline__ uint64_t lanes_reserve(unsigned long long *ctr) {        // callable from divergent code
     unsigned long long m = __ballot(1);
     int lane = (int)(threadIdx.x & 63), leader = __ffsll((long long)m) - 1;
@@ -166,24 +169,27 @@ __device__ __forceinline__ uint64_t lanes_reserve(unsigned long long *ctr) {    
     base = __shfl(base, leader);
     return base + (uint64_t)__popcll(m & ((1ull << lane) - 1ull));
 }
-__device__ __forceinline__ void stash_put(uint64_t (*stash)[256], uint32_t &n, const appender &ap, uint64_t rec) {
-    if (n < STASH_K) stash[n][threadIdx.x] = rec;
-    else { uint64_t slot = lanes_reserve(ap.total); if (slot < ap.cap) ap.out[slot] = rec; }
-    n++;
+__device__ __forceinline__ void pool_put(pool_t &P, const appender &ap, uint64_t rec) {
+    unsigned int slot = atomicAdd(&P.n, 1u);
+    if (slot < POOL_N) P.buf[slot] = rec;
+    else { uint64_t g = lanes_reserve(ap.total); if (g < ap.cap) ap.out[g] = rec; }
 }
-// every lane of the wave must reach this (no early return in the caller)
-__device__ __forceinline__ void stash_flush(uint64_t (*stash)[256], uint32_t n, const appender &ap) {
-    uint32_t m = n < STASH_K ? n : STASH_K;
-    int lane = (int)(threadIdx.x & 63);
-    uint32_t incl = m;
-    for (int d = 1; d < 64; d <<= 1) { uint32_t t = __shfl_up(incl, d); if (lane >= d) incl += t; }
-    uint32_t wave_total = __shfl(incl, 63);
-    if (!wave_total) return;
-    unsigned long long base = 0;
-    if (lane == 0) base = atomicAdd(ap.total, (unsigned long long)wave_total);
-    base = __shfl(base, 0);
-    uint64_t slot = base + (incl - m);
-    for (uint32_t j = 0; j < m; j++, slot++) if (slot < ap.cap) ap.out[slot] = stash[j][threadIdx.x];
+// block-uniform: every thread of the block must call it.  Drains when the pool is at least
+// `threshold` full (0 = always).
+__device__ __forceinline__ void pool_drain(pool_t &P, const appender &ap, unsigned int threshold) {
+    __syncthreads();
+    if (threadIdx.x == 0) P.snap = P.n;                      // one thread decides, so the branch below is uniform
+    __syncthreads();
+    unsigned int cnt = P.snap;
+    if (cnt < threshold || cnt == 0) return;
+    if (cnt > POOL_N) cnt = POOL_N;
+    if (threadIdx.x == 0) P.base = atomicAdd(ap.total, (unsigned long long)cnt);
+    __syncthreads();
+    const unsigned long long base = P.base;
+    for (unsigned int i = threadIdx.x; i < cnt; i += blockDim.x) { unsigned long long g = base + i; if (g < ap.cap) ap.out[g] = P.buf[i]; }
+    __syncthreads();
+    if (threadIdx.x == 0) P.n = 0;
+    __syncthreads();
 }
 
 __global__ void k_iota(uint32_t *p, size_t n) { size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; if (i < n) p[i] = (uint32_t)i; }
@@ -225,7 +231,10 @@ extern "C" cgx_ctx *cgx_create(int device) {
     if (hipSetDevice(device) != hipSuccess) return nullptr;
     cgx_ctx *c = new cgx_ctx();
     c->device = device;
-    if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return nullptr; }
+    {   // compute stream at the highest priority: the text copies of the previous batch run beside it on side streams
+        int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (hipStreamCreateWithPriority(&c->stream, hipStreamDefault, hi) != hipSuccess) { (void)hipGetLastError(); if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return nullptr; } }
+    }
     return c;
 }
 static void free_batch(cgx_ctx *c) {
@@ -252,7 +261,8 @@ extern "C" void cgx_destroy(cgx_ctx *c) {
     for (int a = 0; a < 2; a++) if (c->arena[a]) { (void)hipHostFree(c->arena[a]); c->arena[a] = nullptr; }
     for (int a = 0; a < 2; a++) { dfree(c->d_text[a]); dfree(c->d_qtext[a]); }
     dfree(c->d_spool); dfree(c->d_soff); dfree(c->d_tpool); dfree(c->d_toff); dfree(c->d_aa); dfree(c->d_bb); dfree(c->d_fs);
-    for (int r = 0; r < CGX_MAX_READERS; r++) if (c->copy_streams[r]) (void)hipStreamDestroy(c->copy_streams[r]);
+    for (int r = 0; r < CGX_COPY_STREAMS; r++) if (c->copy_streams[r]) (void)hipStreamDestroy(c->copy_streams[r]);
+    for (int r = 0; r < CGX_MAX_READERS; r++) if (c->copy_done[r]) (void)hipEventDestroy(c->copy_done[r]);
     (void)hipStreamSynchronize(c->stream);
     g_pool.trim();
     (void)hipStreamDestroy(c->stream);
@@ -979,7 +989,7 @@ __device__ __forceinline__ l1rec l1_load(const grp1 &gr, uint32_t r, const uint6
 }
 __global__ __launch_bounds__(256) void k_look1(cgx_view v, const int32_t *sa, const cgx_gapsearch *s1, const grp1 *groups, const uint64_t *toff, const uint64_t *work, uint32_t ng,
                         uint64_t tile0, const int32_t *qtok, const uint64_t *reckey, const uint32_t *recpid, h64 H, appender ap) {
-    __shared__ uint64_t stash[STASH_K][256];
+    __shared__ pool_t pool;
     __shared__ l1rec recs[L1_REC];
     __shared__ uint32_t hkey[L1_SLOTS];
     __shared__ uint16_t hval[L1_SLOTS];
@@ -990,7 +1000,7 @@ __global__ __launch_bounds__(256) void k_look1(cgx_view v, const int32_t *sa, co
     const grp1 gr = groups[g];
     const uint32_t R = gr.rec1 - gr.rec0;
     for (uint32_t i = threadIdx.x; i < L1_SLOTS; i += 256) hkey[i] = L1_EMPTY;
-    if (threadIdx.x == 0) s_big = R > L1_REC ? 1 : 0;
+    if (threadIdx.x == 0) { s_big = R > L1_REC ? 1 : 0; pool.n = 0; }
     __syncthreads();
     if (R <= L1_REC) {
         for (uint32_t r = threadIdx.x; r < R; r += 256) {
@@ -1009,7 +1019,6 @@ __global__ __launch_bounds__(256) void k_look1(cgx_view v, const int32_t *sa, co
     const int dl = (int)gr.len;                              // length of the driving phrase
     const bool bw = gr.backward != 0;
     for (uint32_t it = 0; it < L1_TILE / 256; it++) {
-        uint32_t n = 0;
         const uint64_t x = x0 + (uint64_t)it * 256 + threadIdx.x;
         if (x < wg) {
             const int64_t go = sa[gr.base + x];
@@ -1062,13 +1071,13 @@ __global__ __launch_bounds__(256) void k_look1(cgx_view v, const int32_t *sa, co
                             if (!ok) continue;
                             if (gapok < 0) gapok = bw ? (tight16(v, lo + tb, hi + tb, (int)(pos + 1), (int)edge, src0) ? 1 : 0)
                                                       : (tight16(v, lo + tb, hi + tb, (int)edge, (int)(pos - 1), src0) ? 1 : 0);
-                            if (gapok) stash_put(stash, n, ap, bw ? HITKEY(e.id, pos - ol + 1, dl + 1 + move + ol - 1) : HITKEY(e.id, go, dl + 1 + move + ol - 1));
+                            if (gapok) pool_put(pool, ap, bw ? HITKEY(e.id, pos - ol + 1, dl + 1 + move + ol - 1) : HITKEY(e.id, go, dl + 1 + move + ol - 1));
                         }
                     }
                 }
             }
         }
-        stash_flush(stash, n, ap);
+        pool_drain(pool, ap, it + 1 < L1_TILE / 256 ? POOL_N / 2 : 0);
     }
 }
 __global__ void k_tiles(const uint64_t *work, uint32_t ng, uint32_t tile, uint64_t *tiles) {
@@ -1208,7 +1217,7 @@ __global__ void k_s2hash_fill(const cgx_twogapsearch *s2, const int32_t *s2c, ui
 template <bool WIDE>
 __global__ __launch_bounds__(256) void k_look2(cgx_view v, const cgx_twogapsearch *s2, const int32_t *s2c, const cgx_gapsearch *s1, const grp2 *groups, const uint64_t *toff, const uint64_t *work, uint32_t ng,
                         uint64_t tile0, const cgx_hit1 *hits1, const uint32_t *pidx, const uint32_t *phs, const uint8_t *phl, h64 H, appender ap, uint32_t *wide_id) {
-    __shared__ uint64_t stash[STASH_K][256];
+    __shared__ pool_t pool;
     __shared__ uint32_t hkey[L2_SLOTS];
     __shared__ uint32_t hval[L2_SLOTS];
     const uint64_t tg = tile0 + blockIdx.x;
@@ -1217,6 +1226,8 @@ __global__ __launch_bounds__(256) void k_look2(cgx_view v, const cgx_twogapsearc
     const grp2 gr = groups[gi]; const cgx_gapsearch g = s1[gr.one];
     const uint32_t R = gr.s1 - gr.s0;
     const bool big = R > L2_REC;
+    if (threadIdx.x == 0) pool.n = 0;
+    __syncthreads();
     if (!big) {
         for (uint32_t i = threadIdx.x; i < L2_SLOTS; i += 256) hkey[i] = L1_EMPTY;
         __syncthreads();
@@ -1232,7 +1243,6 @@ __global__ __launch_bounds__(256) void k_look2(cgx_view v, const cgx_twogapsearc
     uint32_t listbase = 0;
     if (g.marker) listbase = pidx[2 * hits1[g.sa_start].str_position];
     for (uint32_t it = 0; it < L2_TILE / 256; it++) {
-        uint32_t n = 0;
         const uint64_t x = x0 + (uint64_t)it * 256 + threadIdx.x;
         if (x < wg) {
             uint32_t ps; int pl;
@@ -1267,13 +1277,13 @@ __global__ __launch_bounds__(256) void k_look2(cgx_view v, const cgx_twogapsearc
                         } else if (!h64_find(H.keys, H.vals, H.mask, H.shift, (((uint64_t)gr.one << 32) | (uint32_t)tk) + 1, &a)) continue;
                         if (!far_ok || !tight16(v, lo + tb, hi + tb, (int)edge, (int)(edge + move), src0)) continue;
                         const uint64_t rec = ((uint64_t)ps << 8) | ((uint64_t)pl << 4) | (uint64_t)(pl + 2 + move);
-                        if (!WIDE) stash_put(stash, n, ap, ((uint64_t)a << 40) | rec);
+                        if (!WIDE) pool_put(pool, ap, ((uint64_t)a << 40) | rec);
                         else { uint64_t slot = lanes_reserve(ap.total); if (slot < ap.cap) { ap.out[slot] = rec; wide_id[slot] = a; } }
                     }
                 }
             }
         }
-        if (!WIDE) stash_flush(stash, n, ap);
+        if (!WIDE) pool_drain(pool, ap, it + 1 < L2_TILE / 256 ? POOL_N / 2 : 0);
     }
 }
 __global__ void k_s2c(const cgx_twogapsearch *s2, const int32_t *c2, uint32_t d2, int32_t *s2c) {
