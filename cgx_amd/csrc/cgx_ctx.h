@@ -34,6 +34,7 @@ struct cgx_ctx {
     uint32_t *d_pidx = nullptr; int32_t *d_miss = nullptr; uint32_t *d_phit_start = nullptr; uint8_t *d_phit_len = nullptr;
     uint64_t *d_bg_key = nullptr; uint32_t *d_bg_lo = nullptr, *d_bg_hi = nullptr; uint32_t bg_cap = 0; unsigned bg_shift = 0;   // bigram -> SA interval
     bool use_bigrams = true;
+    int64_t sub_batch = 0;              // queries per internal batch of cgx_extract_grammars* (0 = all at once)
     bool wide_hits2 = false;            // test hook: take the >2^24-distinct-two-gap-patterns path
     int32_t freq[100] = {0};
 

@@ -275,6 +275,7 @@ extern "C" int cgx_set_option(cgx_ctx *c, const char *name, int64_t value) {
     if (!strcmp(name, "device_format")) { c->device_format = value != 0; return CGX_OK; }
     if (!strcmp(name, "use_bigrams")) { c->use_bigrams = value != 0; return CGX_OK; }
     if (!strcmp(name, "wide_hits2")) { c->wide_hits2 = value != 0; return CGX_OK; }
+    if (!strcmp(name, "sub_batch")) { if (value < 0) return CGX_ERR_ARG; c->sub_batch = value; return CGX_OK; }
     if (!strcmp(name, "append_slack")) { if (value < 0) return CGX_ERR_ARG; c->append_slack = (uint64_t)value; return CGX_OK; }
     if (!strcmp(name, "append_guess_milli")) { if (value < 0) return CGX_ERR_ARG; c->look1_per_item = c->look2_per_item = (double)value / 1000.0; return CGX_OK; }
     if (!strcmp(name, "async_write")) { c->async_write = value != 0; return CGX_OK; }
@@ -287,6 +288,7 @@ extern "C" int64_t cgx__option(cgx_ctx *c, const char *name) {
     if (!c || !name) return 0;
     if (!strcmp(name, "async_write")) return (int64_t)c->async_write;
     if (!strcmp(name, "device_format")) return (int64_t)c->device_format;
+    if (!strcmp(name, "sub_batch")) return c->sub_batch;
     return 0;
 }
 extern "C" const void *cgx__get_vocab_owner(cgx_ctx *c) { return c ? c->vocab_owner : nullptr; }

@@ -770,59 +770,80 @@ static int ensure_vocab(cgx_ctx *ctx, const cgx_corpus *c) {
     free(sp); free(tp); free(soff); free(toff);
     return rc;
 }
-typedef struct { cgx_ctx *ctx; int slot; const uint64_t *qtext; int32_t nq, first; const char *outdir; int32_t *next; int tid, rc; double wait_ms, write_ms; } devjob;
-#define PIN_BYTES (8u << 20)
-#define MAX_WRITERS (CGX_MAX_READERS / 2)
-static void *g_pin[MAX_WRITERS][2];                       /* two page-locked staging buffers per writer thread, kept for the life of the process */
-/* the next <= PIN_BYTES piece of text this thread should move: continues the current file or claims the next one */
-typedef struct { int32_t q; uint64_t o, n, total; } piece;
-static int next_piece(devjob *w, piece *prev, piece *out) {
-    if (prev->q >= 0 && prev->o + prev->n < prev->total) { out->q = prev->q; out->total = prev->total; out->o = prev->o + prev->n; }
-    else {
-        int32_t q = __atomic_fetch_add(w->next, 1, __ATOMIC_RELAXED);
-        if (q >= w->nq) return 0;
-        out->q = q; out->o = 0; out->total = w->qtext[q + 1] - w->qtext[q];
+typedef struct { cgx_ctx *ctx; int slot; const uint64_t *qtext; int32_t nq, first; const char *outdir; int64_t *next; int64_t npieces; int tid, rc; double wait_ms, write_ms; } devjob;
+#define PIN_BYTES (16u << 20)
+#define PIN_RING 3                                        /* copies in flight per writer thread: keeps PCIe busy while the thread sits in pwrite() */
+#define MAX_WRITERS (CGX_MAX_READERS / PIN_RING)
+static void *g_pin[MAX_WRITERS][PIN_RING];                /* page-locked staging buffers, kept for the life of the process */
+/* The text of a batch is one byte stream (query after query).  Writers claim fixed PIN_BYTES pieces of the
+ * STREAM, not files: every D2H copy is large whatever the file sizes are, and a piece is then scattered
+ * into the files it overlaps with pwrite (a file cut by a piece boundary is completed by two writers). */
+static int write_piece(devjob *w, int64_t pc, const char *src) {
+    const uint64_t lo = (uint64_t)pc * PIN_BYTES, total = w->qtext[w->nq], hi = lo + PIN_BYTES < total ? lo + PIN_BYTES : total;
+    int32_t a = 0, b = w->nq;                               /* first query whose text ends after lo */
+    while (a < b) { int32_t m = (a + b) / 2; if (w->qtext[m + 1] <= lo) a = m + 1; else b = m; }
+    char fn[4096];
+    for (int32_t q = a; q < w->nq && w->qtext[q] < hi; q++) {
+        const uint64_t qs = w->qtext[q], qe = w->qtext[q + 1];
+        const uint64_t s = qs > lo ? qs : lo, e = qe < hi ? qe : hi;
+        if (qe == qs) continue;                            /* empty files were created up front */
+        snprintf(fn, sizeof fn, "%s/grammar.%d.s", w->outdir, w->first + q);
+        int fd = open(fn, O_WRONLY | O_CREAT, 0644);
+        if (fd < 0) return CGX_ERR_IO;
+        int bad = 0;
+        for (uint64_t k = s; k < e && !bad;) { ssize_t r = pwrite(fd, src + (k - lo), e - k, (off_t)(k - qs)); if (r <= 0) bad = 1; else k += (uint64_t)r; }
+        if (!bad && e == qe && ftruncate(fd, (off_t)(qe - qs))) bad = 1;   /* whoever writes the last byte sets the length (in-place overwrite of an older, longer file) */
+        close(fd);
+        if (bad) return CGX_ERR_IO;
     }
-    out->n = out->total - out->o < PIN_BYTES ? out->total - out->o : PIN_BYTES;
-    return 1;
+    return CGX_OK;
 }
-/* D2H of piece k+1 (own side stream) runs while piece k is being written to its file */
 static void *dev_write_worker(void *arg) {
-    devjob *w = arg; char fn[4096]; w->rc = CGX_OK; w->wait_ms = w->write_ms = 0;
-    for (int k = 0; k < 2; k++) { if (!g_pin[w->tid][k]) g_pin[w->tid][k] = cgx_pinned_alloc(PIN_BYTES); if (!g_pin[w->tid][k]) { w->rc = CGX_ERR_NOMEM; return NULL; } }
-    piece none = {-1, 0, 0, 0}, cur, nxt; int b = 0, fd = -1, have;
-    have = next_piece(w, &none, &cur);
-    if (have && cgx_text_read_begin(w->ctx, w->slot, w->qtext[cur.q] + cur.o, cur.n, g_pin[w->tid][0], 2 * w->tid) != CGX_OK) { w->rc = CGX_ERR_HIP; return NULL; }
-    while (have) {
-        int more = next_piece(w, &cur, &nxt);
-        if (more && cgx_text_read_begin(w->ctx, w->slot, w->qtext[nxt.q] + nxt.o, nxt.n, g_pin[w->tid][b ^ 1], 2 * w->tid + (b ^ 1)) != CGX_OK) w->rc = CGX_ERR_HIP;
+    devjob *w = arg; w->rc = CGX_OK; w->wait_ms = w->write_ms = 0;
+    for (int k = 0; k < PIN_RING; k++) { if (!g_pin[w->tid][k]) g_pin[w->tid][k] = cgx_pinned_alloc(PIN_BYTES); if (!g_pin[w->tid][k]) { w->rc = CGX_ERR_NOMEM; return NULL; } }
+    const uint64_t total = w->qtext[w->nq];
+    int64_t ring[PIN_RING]; int head = 0, count = 0, more = 1;
+    for (;;) {
+        while (more && count < PIN_RING && w->rc == CGX_OK) {  /* top up the ring */
+            int64_t pc = __atomic_fetch_add(w->next, 1, __ATOMIC_RELAXED);
+            if (pc >= w->npieces) { more = 0; break; }
+            int k = (head + count) % PIN_RING;
+            uint64_t lo = (uint64_t)pc * PIN_BYTES, n = total - lo < PIN_BYTES ? total - lo : PIN_BYTES;
+            if (cgx_text_read_begin(w->ctx, w->slot, lo, n, g_pin[w->tid][k], w->tid * PIN_RING + k) != CGX_OK) w->rc = CGX_ERR_HIP;
+            ring[k] = pc; count++;
+        }
+        if (!count) break;
         double t0 = now_ms();
-        if (cgx_text_read_wait(w->ctx, 2 * w->tid + b) != CGX_OK) w->rc = CGX_ERR_HIP;
+        if (cgx_text_read_wait(w->ctx, w->tid * PIN_RING + head) != CGX_OK && w->rc == CGX_OK) w->rc = CGX_ERR_HIP;
         double t1 = now_ms(); w->wait_ms += t1 - t0;
-        if (w->rc == CGX_OK) {
-            if (cur.o == 0) {
-                snprintf(fn, sizeof fn, "%s/grammar.%d.s", w->outdir, w->first + cur.q);
-                fd = open(fn, O_WRONLY | O_CREAT, 0644);
-                if (fd < 0) w->rc = CGX_ERR_IO;
-            }
-            const char *src = g_pin[w->tid][b];
-            for (uint64_t k = 0; w->rc == CGX_OK && k < cur.n;) { ssize_t r = write(fd, src + k, cur.n - k); if (r <= 0) w->rc = CGX_ERR_IO; else k += (uint64_t)r; }
-            if (fd >= 0 && cur.o + cur.n >= cur.total) { if (w->rc == CGX_OK && ftruncate(fd, (off_t)cur.total)) w->rc = CGX_ERR_IO; close(fd); fd = -1; }
-        }
+        if (w->rc == CGX_OK) w->rc = write_piece(w, ring[head], g_pin[w->tid][head]);
         w->write_ms += now_ms() - t1;
-        if (w->rc != CGX_OK) {                              /* drain the copy in flight before the buffers are reused */
-            if (more) (void)cgx_text_read_wait(w->ctx, 2 * w->tid + (b ^ 1));
-            if (fd >= 0) close(fd);
-            return NULL;
-        }
-        cur = nxt; have = more; b ^= 1;
+        head = (head + 1) % PIN_RING; count--;
+        if (w->rc != CGX_OK) more = 0;                      /* on error: stop claiming, but drain the copies in flight before the buffers go away */
     }
     return NULL;
 }
+/* queries without any text still get their (empty) file */
+static int write_empty_files(const uint64_t *qtext, int32_t nq, const char *outdir, int32_t first) {
+    char fn[4096];
+    for (int32_t q = 0; q < nq; q++) if (qtext[q + 1] == qtext[q]) {
+        snprintf(fn, sizeof fn, "%s/grammar.%d.s", outdir, first + q);
+        int fd = open(fn, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        if (fd < 0) return CGX_ERR_IO;
+        close(fd);
+    }
+    return CGX_OK;
+}
 static int write_from_device(cgx_ctx *ctx, int slot, const uint64_t *qtext, int32_t nq, const char *outdir, int32_t first, double *wait_ms, double *file_ms) {
-    int nt = nthreads_host(); if (nt > MAX_WRITERS) nt = MAX_WRITERS; if (nt > nq) nt = nq > 0 ? nq : 1;
-    devjob jobs[MAX_WRITERS]; pthread_t th[MAX_WRITERS]; int32_t next = 0;
-    for (int t = 0; t < nt; t++) { jobs[t].ctx = ctx; jobs[t].slot = slot; jobs[t].qtext = qtext; jobs[t].nq = nq; jobs[t].first = first; jobs[t].outdir = outdir; jobs[t].next = &next; jobs[t].tid = t; jobs[t].rc = CGX_OK; }
+    int rc = write_empty_files(qtext, nq, outdir, first);
+    if (rc != CGX_OK) return rc;
+    *wait_ms = *file_ms = 0;
+    const uint64_t total = qtext[nq];
+    int64_t npieces = (int64_t)((total + PIN_BYTES - 1) / PIN_BYTES), next = 0;
+    if (!npieces) return CGX_OK;
+    int nt = nthreads_host(); if (nt > MAX_WRITERS) nt = MAX_WRITERS; if (nt > npieces) nt = (int)npieces;
+    devjob jobs[MAX_WRITERS]; pthread_t th[MAX_WRITERS];
+    for (int t = 0; t < nt; t++) { jobs[t].ctx = ctx; jobs[t].slot = slot; jobs[t].qtext = qtext; jobs[t].nq = nq; jobs[t].first = first; jobs[t].outdir = outdir; jobs[t].next = &next; jobs[t].npieces = npieces; jobs[t].tid = t; jobs[t].rc = CGX_OK; }
     for (int t = 1; t < nt; t++) if (pthread_create(&th[t], NULL, dev_write_worker, &jobs[t])) return CGX_ERR_NOMEM;
     dev_write_worker(&jobs[0]);
     for (int t = 1; t < nt; t++) pthread_join(th[t], NULL);
@@ -1034,19 +1055,35 @@ int cgx_flush(cgx_ctx *ctx) {
 }
 void cgx__host_release(cgx_ctx *ctx) { (void)cgx_flush(ctx); }
 
-int cgx_extract_grammars_ids(cgx_ctx *ctx, const cgx_corpus *c, const int32_t *qoff, int32_t nq, const int32_t *qtok, int32_t ntok,
-                             const char *outdir, int32_t first, uint64_t *nrules) {
-    if (!ctx || !c || nq < 0 || ntok < 0) return CGX_ERR_ARG;
+static int extract_ids_once(cgx_ctx *ctx, const cgx_corpus *c, const int32_t *qoff, int32_t nq, const int32_t *qtok, int32_t ntok,
+                            const char *outdir, int32_t first, uint64_t *nrules) {
     batch *b = calloc(1, sizeof *b);
     if (!b) return CGX_ERR_NOMEM;
     b->nq = nq; b->ntok = ntok;
     b->qoff = malloc(((size_t)nq + 1) * 4); b->qtok = malloc(((size_t)ntok + 1) * 4);
     if (!b->qoff || !b->qtok) return CGX_ERR_NOMEM;
-    memcpy(b->qoff, qoff, (size_t)nq * 4); b->qoff[nq] = ntok; memcpy(b->qtok, qtok, (size_t)ntok * 4);
+    for (int32_t q = 0; q < nq; q++) b->qoff[q] = qoff[q] - qoff[0];
+    b->qoff[nq] = ntok; memcpy(b->qtok, qtok + qoff[0], (size_t)ntok * 4);
     int handed_off = 0;
     int rc = run_batch(ctx, c, b, outdir, first, nrules, &handed_off);
     if (!handed_off) { batch_free(b); free(b); }
     return rc;
+}
+int cgx_extract_grammars_ids(cgx_ctx *ctx, const cgx_corpus *c, const int32_t *qoff, int32_t nq, const int32_t *qtok, int32_t ntok,
+                             const char *outdir, int32_t first, uint64_t *nrules) {
+    if (!ctx || !c || nq < 0 || ntok < 0 || (nq && !qoff) || (ntok && !qtok)) return CGX_ERR_ARG;
+    const int64_t sub = cgx__option(ctx, "sub_batch");
+    if (sub <= 0 || sub >= nq) return extract_ids_once(ctx, c, qoff, nq, qtok, ntok, outdir, first, nrules);
+    uint64_t total = 0;
+    for (int32_t q0 = 0; q0 < nq; q0 += (int32_t)sub) {      /* queries are independent: any split gives the same files */
+        int32_t q1 = q0 + (int32_t)sub < nq ? q0 + (int32_t)sub : nq; uint64_t n = 0;
+        int32_t t1 = q1 < nq ? qoff[q1] : ntok;
+        int rc = extract_ids_once(ctx, c, qoff + q0, q1 - q0, qtok, t1 - qoff[q0], outdir, first + q0, &n);
+        if (rc != CGX_OK) return rc;
+        total += n;
+    }
+    if (nrules) *nrules = total;
+    return CGX_OK;
 }
 
 int cgx_extract_grammars(cgx_ctx *ctx, const cgx_corpus *c, const char *qryfile, const char *outdir, int32_t q_begin, int32_t q_end, uint64_t *nrules) {
