@@ -2,6 +2,7 @@
 #ifndef CGX_CTX_H
 #define CGX_CTX_H
 #include <hip/hip_runtime.h>
+#include "cgx_rules.h"
 #define CGX_COPY_STREAMS 3
 #include <stdint.h>
 #include <map>
@@ -30,11 +31,15 @@ struct cgx_ctx {
     uint8_t *d_ltar = nullptr, *d_rtar = nullptr;
     uint64_t *d_lexkey = nullptr; float *d_lexv1 = nullptr, *d_lexv2 = nullptr, *d_lexn1 = nullptr, *d_lexn2 = nullptr;
     uint32_t *d_lexrow = nullptr; int32_t *d_lexnullt = nullptr; uint32_t lex_nrow = 0, lex_ntgt = 0;
+    cgx_lexslot *d_lexslot = nullptr; cgx_lexnull *d_lexnullv = nullptr;
+    uint64_t *d_lexhkey = nullptr; uint32_t *d_lexhidx = nullptr; uint32_t lex_hmask = 0; unsigned lex_hshift = 0;   // pair hash (derived, rebuilt on replicas)
     int32_t *d_tokstart = nullptr; int8_t *d_tokrank = nullptr; int32_t *d_freq = nullptr;
     uint32_t *d_pidx = nullptr; int32_t *d_miss = nullptr; uint32_t *d_phit_start = nullptr; uint8_t *d_phit_len = nullptr;
     uint64_t *d_bg_key = nullptr; uint32_t *d_bg_lo = nullptr, *d_bg_hi = nullptr; uint32_t bg_cap = 0; unsigned bg_shift = 0;   // bigram -> SA interval
     bool use_bigrams = true;
+    bool use_lex_hash = true;           // MaxLex pair lookups through the pair hash (0: binary search in the source word's row)
     int64_t sub_batch = 0;              // queries per internal batch of cgx_extract_grammars* (0 = all at once)
+    uint32_t look_rec_cap = 65535;      // test hook: groups with more records than this read them from global memory
     bool wide_hits2 = false;            // test hook: take the >2^24-distinct-two-gap-patterns path
     int32_t freq[100] = {0};
 

@@ -248,7 +248,7 @@ static void free_batch(cgx_ctx *c) {
 }
 static void free_index(cgx_ctx *c) {
     dfree(c->d_str); dfree(c->d_sa); dfree(c->d_rlp); dfree(c->d_tstr); dfree(c->d_ltar); dfree(c->d_rtar);
-    dfree(c->d_lexkey); dfree(c->d_lexv1); dfree(c->d_lexv2); dfree(c->d_lexn1); dfree(c->d_lexn2); dfree(c->d_lexrow); dfree(c->d_lexnullt);
+    dfree(c->d_lexkey); dfree(c->d_lexv1); dfree(c->d_lexv2); dfree(c->d_lexn1); dfree(c->d_lexn2); dfree(c->d_lexrow); dfree(c->d_lexnullt); dfree(c->d_lexhkey); dfree(c->d_lexhidx); dfree(c->d_lexslot); dfree(c->d_lexnullv); c->lex_hmask = 0;
     dfree(c->d_tokstart); dfree(c->d_tokrank); dfree(c->d_freq); dfree(c->d_pidx); dfree(c->d_miss);
     dfree(c->d_phit_start); dfree(c->d_phit_len); dfree(c->d_bg_key); dfree(c->d_bg_lo); dfree(c->d_bg_hi); c->bg_cap = 0;
     c->n = c->nt = c->nlex = c->nphits = 0; c->have_sa = c->have_pre = false;
@@ -274,7 +274,9 @@ extern "C" int cgx_set_option(cgx_ctx *c, const char *name, int64_t value) {
     if (!strcmp(name, "k1_limit")) { c->k1_limit = (int)value; return CGX_OK; }
     if (!strcmp(name, "device_format")) { c->device_format = value != 0; return CGX_OK; }
     if (!strcmp(name, "use_bigrams")) { c->use_bigrams = value != 0; return CGX_OK; }
+    if (!strcmp(name, "use_lex_hash")) { c->use_lex_hash = value != 0; return CGX_OK; }
     if (!strcmp(name, "wide_hits2")) { c->wide_hits2 = value != 0; return CGX_OK; }
+    if (!strcmp(name, "look_rec_cap")) { if (value < 0) return CGX_ERR_ARG; c->look_rec_cap = (uint32_t)(value > 65535 ? 65535 : value); return CGX_OK; }
     if (!strcmp(name, "sub_batch")) { if (value < 0) return CGX_ERR_ARG; c->sub_batch = value; return CGX_OK; }
     if (!strcmp(name, "append_slack")) { if (value < 0) return CGX_ERR_ARG; c->append_slack = (uint64_t)value; return CGX_OK; }
     if (!strcmp(name, "append_guess_milli")) { if (value < 0) return CGX_ERR_ARG; c->look1_per_item = c->look2_per_item = (double)value / 1000.0; return CGX_OK; }
@@ -324,6 +326,49 @@ static int build_tokstart(cgx_ctx *ctx, const int32_t *str, uint32_t n) {
     TRY(h2d(ctx, ctx->d_tokstart, ts.data(), ts.size()));
     return CGX_OK;
 }
+// pair hash over the sorted lexical table: key -> LOWEST entry index (duplicate keys resolve to the first in file order)
+__global__ void k_lexhash_fill(const uint64_t *key, uint32_t n, unsigned long long *hkey, uint32_t *hidx, uint32_t mask, unsigned shift) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long k = key[i];
+    uint32_t slot = (uint32_t)((k * 0x9E3779B97F4A7C15ull) >> shift) & mask;
+    for (;;) { unsigned long long prev = atomicCAS(&hkey[slot], 0ull, k); if (prev == 0ull || prev == k) break; slot = (slot + 1) & mask; }
+    atomicMin(&hidx[slot], i);
+}
+__global__ void k_lexslot_fill(const uint64_t *hkey, const uint32_t *hidx, size_t cap, const float *v1, const float *v2, const float *n1, const float *n2, cgx_lexslot *slot) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= cap) return;
+    cgx_lexslot e; e.key = hkey[i]; e.pad = 0; e.v1 = e.v2 = e.n1 = e.n2 = 0.0f;
+    if (e.key) { uint32_t m = hidx[i]; e.v1 = v1[m]; e.v2 = v2[m]; e.n1 = n1[m]; e.n2 = n2[m]; }
+    slot[i] = e;
+}
+__global__ void k_lexnull_fill(const int32_t *nullt, uint32_t ntgt, const float *v1, const float *n1, cgx_lexnull *out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ntgt) return;
+    int32_t m = nullt[i]; cgx_lexnull e; e.v1 = -1.0f; e.n1 = 0.0f;
+    if (m >= 0) { e.v1 = v1[m]; e.n1 = n1[m]; }
+    out[i] = e;
+}
+static int build_lex_hash(cgx_ctx *ctx) {
+    dfree(ctx->d_lexhkey); dfree(ctx->d_lexhidx); dfree(ctx->d_lexslot); dfree(ctx->d_lexnullv); ctx->lex_hmask = 0;
+    if (!ctx->nlex) return CGX_OK;
+    uint64_t cap = 1024; while (cap < (uint64_t)ctx->nlex * 2) cap <<= 1;
+    if (cap > (1ull << 32)) return CGX_OK;                       // too large for 32-bit slots: lookups fall back to the row search
+    TRY(dalloc(ctx, &ctx->d_lexhkey, cap)); TRY(dalloc(ctx, &ctx->d_lexhidx, cap));
+    HIPCHK(hipMemsetAsync(ctx->d_lexhkey, 0, cap * 8, ctx->stream)); HIPCHK(hipMemsetAsync(ctx->d_lexhidx, 0xFF, cap * 4, ctx->stream));
+    ctx->lex_hmask = (uint32_t)(cap - 1); ctx->lex_hshift = 64 - (unsigned)bits_for(cap - 1);
+    k_lexhash_fill<<<nblocks(ctx->nlex, 256), 256, 0, ctx->stream>>>(ctx->d_lexkey, ctx->nlex, (unsigned long long *)ctx->d_lexhkey, ctx->d_lexhidx, ctx->lex_hmask, ctx->lex_hshift);
+    TRY(dalloc(ctx, &ctx->d_lexslot, cap)); TRY(dalloc(ctx, &ctx->d_lexnullv, (size_t)ctx->lex_ntgt + 1));
+    k_lexslot_fill<<<nblocks(cap, 256), 256, 0, ctx->stream>>>(ctx->d_lexhkey, ctx->d_lexhidx, (size_t)cap, ctx->d_lexv1, ctx->d_lexv2, ctx->d_lexn1, ctx->d_lexn2, ctx->d_lexslot);
+    if (ctx->lex_ntgt) k_lexnull_fill<<<nblocks(ctx->lex_ntgt, 256), 256, 0, ctx->stream>>>(ctx->d_lexnullt, ctx->lex_ntgt, ctx->d_lexv1, ctx->d_lexn1, ctx->d_lexnullv);
+    HIPCHK(hipStreamSynchronize(ctx->stream)); HIPCHK(hipGetLastError());
+    return CGX_OK;
+}
+static cgx_lexview lex_view(const cgx_ctx *ctx) {
+    cgx_lexview t{ctx->d_lexkey, ctx->d_lexv1, ctx->d_lexv2, ctx->d_lexn1, ctx->d_lexn2, ctx->nlex, ctx->d_lexrow, ctx->d_lexnullt, ctx->lex_nrow, ctx->lex_ntgt};
+    if (ctx->lex_hmask && ctx->use_lex_hash) { t.hkey = ctx->d_lexhkey; t.hidx = ctx->d_lexhidx; t.hmask = ctx->lex_hmask; t.hshift = ctx->lex_hshift; t.hslot = ctx->d_lexslot; t.nullv = ctx->d_lexnullv; }
+    return t;
+}
 static int upload_lex(cgx_ctx *ctx, const cgx_lexkey *k, const cgx_lexval *v, uint32_t nlex) {
     // sort rows by (src,tgt) like thrust::sort_by_key(lexFileCompare) (ExtractPair.cu:2537) and
     // precompute -log10f of both probabilities with the host libm (bit-exact MaxLex sums).
@@ -352,7 +397,7 @@ static int upload_lex(cgx_ctx *ctx, const cgx_lexkey *k, const cgx_lexval *v, ui
     TRY(dalloc(ctx, &ctx->d_lexrow, row.size())); TRY(h2d(ctx, ctx->d_lexrow, row.data(), row.size()));
     TRY(dalloc(ctx, &ctx->d_lexnullt, nullt.size())); TRY(h2d(ctx, ctx->d_lexnullt, nullt.data(), nullt.size()));
     ctx->nlex = nlex;
-    return CGX_OK;
+    return build_lex_hash(ctx);
 }
 #define STR_PAD 32   // zero tokens after the corpus so window scans never leave the buffer
 extern "C" int cgx_upload_index(cgx_ctx *ctx, const cgx_index_host *ix) {
@@ -631,7 +676,7 @@ extern "C" int cgx_index_finalize(cgx_ctx *ctx) {
     if (!ctx || !ctx->d_freq) return CGX_ERR_STATE;
     TRY(d2h(ctx, ctx->freq, ctx->d_freq, CGX_TOP));
     ctx->have_sa = ctx->have_pre = true;
-    return CGX_OK;
+    return build_lex_hash(ctx);                               // derived data: rebuilt on the replica instead of being shipped
 }
 
 
@@ -990,7 +1035,7 @@ __device__ __forceinline__ l1rec l1_load(const grp1 &gr, uint32_t r, const uint6
     return o;
 }
 __global__ __launch_bounds__(256) void k_look1(cgx_view v, const int32_t *sa, const cgx_gapsearch *s1, const grp1 *groups, const uint64_t *toff, const uint64_t *work, uint32_t ng,
-                        uint64_t tile0, const int32_t *qtok, const uint64_t *reckey, const uint32_t *recpid, h64 H, appender ap) {
+                        uint64_t tile0, const int32_t *qtok, const uint64_t *reckey, const uint32_t *recpid, h64 H, appender ap, uint32_t rec_cap) {
     __shared__ pool_t pool;
     __shared__ l1rec recs[L1_REC];
     __shared__ uint32_t hkey[L1_SLOTS];
@@ -1002,9 +1047,9 @@ __global__ __launch_bounds__(256) void k_look1(cgx_view v, const int32_t *sa, co
     const grp1 gr = groups[g];
     const uint32_t R = gr.rec1 - gr.rec0;
     for (uint32_t i = threadIdx.x; i < L1_SLOTS; i += 256) hkey[i] = L1_EMPTY;
-    if (threadIdx.x == 0) { s_big = R > L1_REC ? 1 : 0; pool.n = 0; }
+    if (threadIdx.x == 0) { s_big = R > rec_cap ? 1 : 0; pool.n = 0; }
     __syncthreads();
-    if (R <= L1_REC) {
+    if (R <= rec_cap) {
         for (uint32_t r = threadIdx.x; r < R; r += 256) {
             l1rec e = l1_load(gr, gr.rec0 + r, reckey, recpid, s1, qtok);
             recs[r] = e;
@@ -1218,7 +1263,7 @@ __global__ void k_s2hash_fill(const cgx_twogapsearch *s2, const int32_t *s2c, ui
 #define L2_SLOTS 1024
 template <bool WIDE>
 __global__ __launch_bounds__(256) void k_look2(cgx_view v, const cgx_twogapsearch *s2, const int32_t *s2c, const cgx_gapsearch *s1, const grp2 *groups, const uint64_t *toff, const uint64_t *work, uint32_t ng,
-                        uint64_t tile0, const cgx_hit1 *hits1, const uint32_t *pidx, const uint32_t *phs, const uint8_t *phl, h64 H, appender ap, uint32_t *wide_id) {
+                        uint64_t tile0, const cgx_hit1 *hits1, const uint32_t *pidx, const uint32_t *phs, const uint8_t *phl, h64 H, appender ap, uint32_t *wide_id, uint32_t rec_cap) {
     __shared__ pool_t pool;
     __shared__ uint32_t hkey[L2_SLOTS];
     __shared__ uint32_t hval[L2_SLOTS];
@@ -1227,7 +1272,7 @@ __global__ __launch_bounds__(256) void k_look2(cgx_view v, const cgx_twogapsearc
     const uint64_t x0 = (tg - toff[gi]) * L2_TILE, wg = work[gi];
     const grp2 gr = groups[gi]; const cgx_gapsearch g = s1[gr.one];
     const uint32_t R = gr.s1 - gr.s0;
-    const bool big = R > L2_REC;
+    const bool big = R > rec_cap;
     if (threadIdx.x == 0) pool.n = 0;
     __syncthreads();
     if (!big) {
@@ -1417,7 +1462,7 @@ extern "C" int cgx_gappy_search(cgx_ctx *ctx) {
             uint64_t NT = 0; TRY(d2h(ctx, &NT, toff + NG, 1));
             const uint64_t tile_chunk = ctx->chunk_items / 64 ? (ctx->chunk_items / 64 < (1ull << 30) ? ctx->chunk_items / 64 : (1ull << 30)) : 1;
             TRY(append_pass(ctx, NT, tile_chunk, W, keys, &ctx->look1_per_item, [&](uint64_t t0, uint64_t nt, appender ap) {
-                k_look1<<<(unsigned)nt, 256, 0, st>>>(v, sa, s1, groups, toff, work, NG, t0, qtok, sreckey, srecpid, H, ap);
+                k_look1<<<(unsigned)nt, 256, 0, st>>>(v, sa, s1, groups, toff, work, NG, t0, qtok, sreckey, srecpid, H, ap, ctx->look_rec_cap < L1_REC ? ctx->look_rec_cap : L1_REC);
             }));
             dfree(tiles); dfree(toff);
             dfree(flags); dfree(incl); dfree(groups); dfree(gdown); dfree(work); dfree(woff); dfree(H.keys); dfree(H.vals);
@@ -1501,7 +1546,7 @@ extern "C" int cgx_gappy_search(cgx_ctx *ctx) {
         const uint64_t tile_chunk = ctx->chunk_items / 64 ? (ctx->chunk_items / 64 < (1ull << 30) ? ctx->chunk_items / 64 : (1ull << 30)) : 1;
         if (!wide) {
             TRY(append_pass(ctx, NT, tile_chunk, W, recs, &ctx->look2_per_item, [&](uint64_t t0, uint64_t nt, appender ap) {
-                k_look2<false><<<(unsigned)nt, 256, 0, st>>>(v, ctx->d_s2, s2c, ctx->d_s1, groups, toff, work, NG, t0, ctx->d_hits1, ctx->d_pidx, ctx->d_phit_start, ctx->d_phit_len, H2, ap, nullptr);
+                k_look2<false><<<(unsigned)nt, 256, 0, st>>>(v, ctx->d_s2, s2c, ctx->d_s1, groups, toff, work, NG, t0, ctx->d_hits1, ctx->d_pidx, ctx->d_phit_start, ctx->d_phit_len, H2, ap, nullptr, ctx->look_rec_cap < L2_REC ? ctx->look_rec_cap : L2_REC);
             }));
             accn = recs.n;
         } else {
@@ -1511,7 +1556,7 @@ extern "C" int cgx_gappy_search(cgx_ctx *ctx) {
                 appender ap{recs.p, recs.cap, total};
                 for (uint64_t t0 = 0; t0 < NT; t0 += tile_chunk) {
                     uint64_t nt = NT - t0 < tile_chunk ? NT - t0 : tile_chunk;
-                    k_look2<true><<<(unsigned)nt, 256, 0, st>>>(v, ctx->d_s2, s2c, ctx->d_s1, groups, toff, work, NG, t0, ctx->d_hits1, ctx->d_pidx, ctx->d_phit_start, ctx->d_phit_len, H2, ap, wid);
+                    k_look2<true><<<(unsigned)nt, 256, 0, st>>>(v, ctx->d_s2, s2c, ctx->d_s1, groups, toff, work, NG, t0, ctx->d_hits1, ctx->d_pidx, ctx->d_phit_start, ctx->d_phit_len, H2, ap, wid, ctx->look_rec_cap < L2_REC ? ctx->look_rec_cap : L2_REC);
                 }
                 unsigned long long got = 0; TRY(d2h(ctx, &got, total, 1)); dfree(total);
                 accn = (size_t)got;
@@ -1788,7 +1833,7 @@ extern "C" int cgx_lex_features(cgx_ctx *ctx, const cgx_lextask *tasks, uint32_t
         cgx_lextask *d = nullptr; float *fe = nullptr, *ef = nullptr;
         TRY(dalloc(ctx, &d, ntask)); TRY(dalloc(ctx, &fe, ntask)); TRY(dalloc(ctx, &ef, ntask));
         TRY(h2d(ctx, d, tasks, ntask));
-        cgx_lexview t{ctx->d_lexkey, ctx->d_lexv1, ctx->d_lexv2, ctx->d_lexn1, ctx->d_lexn2, ctx->nlex, ctx->d_lexrow, ctx->d_lexnullt, ctx->lex_nrow, ctx->lex_ntgt};
+        cgx_lexview t = lex_view(ctx);
         k_lextask<<<nblocks(ntask, 128), 128, 0, ctx->stream>>>(t, ctx->d_tstr, d, ntask, n_onegap, n_onegap + n_twogap, fe, ef);
         HIPCHK(hipGetLastError());
         TRY(d2h(ctx, max_fe, fe, ntask)); TRY(d2h(ctx, max_ef, ef, ntask));
@@ -1972,7 +2017,7 @@ extern "C" int cgx_lexicon(cgx_ctx *ctx) {
     dfree(ctx->d_lex0); dfree(ctx->d_lex1); dfree(ctx->d_lex2); ctx->nl0 = ctx->nl1 = ctx->nl2 = 0;
     lexsrc L{ctx->d_blocks, ctx->d_s1, ctx->d_s2, ctx->d_p1, ctx->d_c2, ctx->d_str, ctx->d_tstr, ctx->d_hits1, ctx->d_pidx, ctx->d_miss,
              ctx->g, ctx->d1, ctx->d2, ctx->sep1, ctx->sep2a, ctx->sep2b};
-    cgx_lexview T{ctx->d_lexkey, ctx->d_lexv1, ctx->d_lexv2, ctx->d_lexn1, ctx->d_lexn2, ctx->nlex, ctx->d_lexrow, ctx->d_lexnullt, ctx->lex_nrow, ctx->lex_ntgt};
+    cgx_lexview T = lex_view(ctx);
     dfree(ctx->d_rng0); dfree(ctx->d_rng1); dfree(ctx->d_rng2);
     TRY(lexicon_kind(ctx, L, T, 1, ctx->n1, 2 * ctx->g + ctx->d1, &ctx->d_lex1, &ctx->nl1, &ctx->d_rng1));
     TRY(lexicon_kind(ctx, L, T, 2, ctx->n2, ctx->g + 2 * ctx->d1 + ctx->d2, &ctx->d_lex2, &ctx->nl2, &ctx->d_rng2));

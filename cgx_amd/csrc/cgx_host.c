@@ -1062,8 +1062,9 @@ static int extract_ids_once(cgx_ctx *ctx, const cgx_corpus *c, const int32_t *qo
     b->nq = nq; b->ntok = ntok;
     b->qoff = malloc(((size_t)nq + 1) * 4); b->qtok = malloc(((size_t)ntok + 1) * 4);
     if (!b->qoff || !b->qtok) return CGX_ERR_NOMEM;
-    for (int32_t q = 0; q < nq; q++) b->qoff[q] = qoff[q] - qoff[0];
-    b->qoff[nq] = ntok; memcpy(b->qtok, qtok + qoff[0], (size_t)ntok * 4);
+    const int32_t base = nq ? qoff[0] : 0;                   /* sub-batches start in the middle of the caller's arrays */
+    for (int32_t q = 0; q < nq; q++) b->qoff[q] = qoff[q] - base;
+    b->qoff[nq] = ntok; if (ntok) memcpy(b->qtok, qtok + base, (size_t)ntok * 4);
     int handed_off = 0;
     int rc = run_batch(ctx, c, b, outdir, first, nrules, &handed_off);
     if (!handed_off) { batch_free(b); free(b); }
@@ -1071,7 +1072,7 @@ static int extract_ids_once(cgx_ctx *ctx, const cgx_corpus *c, const int32_t *qo
 }
 int cgx_extract_grammars_ids(cgx_ctx *ctx, const cgx_corpus *c, const int32_t *qoff, int32_t nq, const int32_t *qtok, int32_t ntok,
                              const char *outdir, int32_t first, uint64_t *nrules) {
-    if (!ctx || !c || nq < 0 || ntok < 0 || (nq && !qoff) || (ntok && !qtok)) return CGX_ERR_ARG;
+    if (!ctx || !c || nq < 0 || ntok < 0 || (nq && !qoff) || (ntok && !qtok) || (ntok && !nq)) return CGX_ERR_ARG;
     const int64_t sub = cgx__option(ctx, "sub_batch");
     if (sub <= 0 || sub >= nq) return extract_ids_once(ctx, c, qoff, nq, qtok, ntok, outdir, first, nrules);
     uint64_t total = 0;

@@ -20,8 +20,10 @@
 
 #if defined(__HIPCC__)
 #define CGX_HD __host__ __device__ __forceinline__
+#define CGX_UNROLL _Pragma("unroll")
 #else
 #define CGX_HD inline
+#define CGX_UNROLL
 #endif
 
 #define CGX_MAX_SPAN 15
@@ -353,29 +355,107 @@ struct cgx_lexview {
     const uint32_t *row;     // row[s] = first entry whose (src+1) >= s, s = 0..nrow; the table is sorted by (src+1, tgt+1)
     const int32_t *nullt;    // entry index of (NULL, tgt) per target id, -1 if absent
     uint32_t nrow, ntgt;     // valid src+1 values are < nrow; target ids are < ntgt
+    // optional open-addressing hash key -> lowest entry index (device index only): one or two probes
+    // instead of a binary search over the source word's row
+    const uint64_t *hkey = nullptr; const uint32_t *hidx = nullptr; uint32_t hmask = 0; unsigned hshift = 0;
+    // optional packed copies for MaxLex: the four values next to the key (one 32-byte slot per probe instead of
+    // key + index + four arrays), and (NULL, tgt) as a direct {v1, n1} table (v1 < 0: absent)
+    const struct cgx_lexslot *hslot = nullptr; const struct cgx_lexnull *nullv = nullptr;
 };
+struct cgx_lexslot { uint64_t key; float v1, v2, n1, n2; uint64_t pad; };
+struct cgx_lexnull { float v1, n1; };
 CGX_HD uint64_t cgx_lexkey_pack(int32_t src, int32_t tgt) { return ((uint64_t)(uint32_t)(src + 1) << 32) | (uint32_t)(tgt + 1); }
 // index of the (src,tgt) row or -1.  Replaces searchLexFile's binary search over the whole table
-// (ExtractPair.cu:2108-2142): a per-source row pointer narrows the search to that word's few
-// translations, and (NULL,tgt) is a direct table.
+// (ExtractPair.cu:2108-2142): (NULL,tgt) is a direct table, other pairs go through the pair hash
+// when the view has one, else a per-source row pointer narrows the search to that word's few
+// translations.
 CGX_HD int64_t cgx_lex_find(const cgx_lexview &t, int32_t src, int32_t tgt) {
     if (src < -1 || tgt < -1) return -1;
     if (src == -1 && tgt >= 0) return (uint32_t)tgt < t.ntgt ? (int64_t)t.nullt[tgt] : -1;
     uint32_t s = (uint32_t)(src + 1);
     if (s >= t.nrow) return -1;
+    if (t.hkey) {
+        const uint64_t want = cgx_lexkey_pack(src, tgt);
+        if (want == 0) return -1;                              // (NULL,NULL) is never a row; 0 marks an empty slot
+        uint32_t slot = (uint32_t)((want * 0x9E3779B97F4A7C15ull) >> t.hshift) & t.hmask;
+        for (;;) { uint64_t k = t.hkey[slot]; if (k == want) return (int64_t)t.hidx[slot]; if (k == 0) return -1; slot = (slot + 1) & t.hmask; }
+    }
     int64_t lo = t.row[s], hi = (int64_t)t.row[s + 1] - 1;
     const uint32_t want = (uint32_t)(tgt + 1);
     while (lo <= hi) { int64_t m = lo + ((hi - lo) >> 1); uint32_t x = (uint32_t)t.key[m]; if (want < x) hi = m - 1; else if (want > x) lo = m + 1; else return m; }
     return -1;
 }
 
+// values of the (src,tgt) row: v[0..3] = v1, v2, n1, n2.  false when the pair is not in the table.
+CGX_HD bool cgx_lex_get(const cgx_lexview &t, int32_t src, int32_t tgt, float *v) {
+    if (src < -1 || tgt < -1) return false;
+    if (t.hslot) {
+        if (src == -1 && tgt >= 0) {
+            if ((uint32_t)tgt >= t.ntgt) return false;
+            const cgx_lexnull e = t.nullv[tgt];
+            if (e.v1 < 0.0f) return false;
+            v[0] = e.v1; v[1] = 0.0f; v[2] = e.n1; v[3] = 0.0f;   // only v1/n1 are read for (NULL, tgt)
+            return true;
+        }
+        if ((uint32_t)(src + 1) >= t.nrow) return false;
+        const uint64_t want = cgx_lexkey_pack(src, tgt);
+        if (want == 0) return false;
+        uint32_t slot = (uint32_t)((want * 0x9E3779B97F4A7C15ull) >> t.hshift) & t.hmask;
+        for (;;) {
+            const cgx_lexslot e = t.hslot[slot];
+            if (e.key == want) { v[0] = e.v1; v[1] = e.v2; v[2] = e.n1; v[3] = e.n2; return true; }
+            if (e.key == 0) return false;
+            slot = (slot + 1) & t.hmask;
+        }
+    }
+    const int64_t m = cgx_lex_find(t, src, tgt);
+    if (m < 0) return false;
+    v[0] = t.v1[m]; v[1] = t.v2[m]; v[2] = t.n1[m]; v[3] = t.n2[m];
+    return true;
+}
+
 // MaxLexFgivenE / MaxLexEgivenF of one rule (kind 0: one gap, 1: two gaps, 2: contiguous).
 // The reference adds -log10(max) per word in float; the log of every table value is
 // precomputed by the host libm, so the kernel only picks the arg-max and adds.
+// The reference walks the (source word, target word) pairs twice, once per direction
+// (ExtractPair.cu:2145-2290).  Here every pair is looked up ONCE, target word outer, source word
+// inner: the per-target maximum is a scalar, the per-source maxima are kept in a small array.
+// Each maximum still sees its candidates in the reference's order (NULL first, then ascending
+// position, strict '>'), and the two sums are still added in ascending word order, so the
+// floats are identical.
+#define CGX_MAXLEX_SRC 8
 CGX_HD void cgx_maxlex(const cgx_lexview &t, const int32_t *tstr, const int32_t *src, int nsrc, uint32_t tstart,
                        int end, int gap1, int gap1_1, int gap2, int gap2_1, int kind, float *fe, float *ef) {
     float fgivene = 0.0f, egivenf = 0.0f;
     const int t0 = (int)tstart, tend = t0 + end, g1s = t0 + gap1, g1e = t0 + gap1_1, g2s = t0 + gap2, g2e = t0 + gap2_1;
+    if (nsrc <= CGX_MAXLEX_SRC) {
+        float mx2[CGX_MAXLEX_SRC], ng2[CGX_MAXLEX_SRC]; bool first = true;
+        CGX_UNROLL
+        for (int j = 0; j < CGX_MAXLEX_SRC; j++) { mx2[j] = 0.0f; ng2[j] = 0.0f; }
+        for (int jj = t0; jj <= tend; jj++) {
+            bool outside = kind == 2 || ((jj < g1s || jj > g1e) && (kind == 0 || jj < g2s || jj > g2e));
+            if (!outside) continue;
+            const int32_t tw = tstr[jj];
+            float mx1 = 0.0f, ng1 = 0.0f;
+            float q[4];
+            if (cgx_lex_get(t, -1, tw, q) && q[0] > mx1) { mx1 = q[0]; ng1 = q[2]; }
+        CGX_UNROLL
+            for (int j = 0; j < CGX_MAXLEX_SRC; j++) {
+                if (j >= nsrc) break;
+                if (first && cgx_lex_get(t, src[j], -1, q) && q[1] > mx2[j]) { mx2[j] = q[1]; ng2[j] = q[3]; }
+                if (cgx_lex_get(t, src[j], tw, q)) {
+                    if (q[0] > mx1) { mx1 = q[0]; ng1 = q[2]; }
+                    if (q[1] > mx2[j]) { mx2[j] = q[1]; ng2[j] = q[3]; }
+                }
+            }
+            first = false;
+            egivenf += (nsrc > 0 && mx1 > 0.0f) ? ng1 : CGX_MAXSCORE;
+        }
+        CGX_UNROLL
+        for (int j = 0; j < CGX_MAXLEX_SRC; j++) if (j < nsrc) fgivene += mx2[j] > 0.0f ? ng2[j] : CGX_MAXSCORE;
+        *fe = fgivene; *ef = egivenf;
+        return;
+    }
     for (int j = 0; j < nsrc; j++) {
         float mx = 0.0f, neg = 0.0f; bool first = true;
         for (int jj = t0; jj <= tend; jj++) {
