@@ -66,6 +66,7 @@ struct cgx_ctx {
     uint32_t *d_qb_off = nullptr, *d_qb_ids = nullptr, *d_qo_off = nullptr, *d_qo_ids = nullptr, *d_qt_off = nullptr, *d_qt_ids = nullptr;
     char *d_text[2] = {nullptr, nullptr}; size_t text_cap[2] = {0, 0}; uint64_t text_bytes[2] = {0, 0}; uint64_t *d_qtext[2] = {nullptr, nullptr}; int32_t text_nq[2] = {0, 0}; int text_sel = 0;
     hipStream_t copy_streams[CGX_COPY_STREAMS] = {nullptr};   // few, so that they do not share a hardware queue with `stream`
+    hipEvent_t sync_ev = nullptr;                             // blocking-sync event for host waits on `stream`
     hipEvent_t copy_done[CGX_MAX_READERS] = {nullptr};        // one per reader: its last enqueued copy
     const void *vocab_owner = nullptr;
     bool device_format = true;          // lay the grammar text out on the GPU (host formatter kept as the fallback)

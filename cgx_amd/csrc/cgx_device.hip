@@ -72,9 +72,15 @@ static void dfree_bytes(void *p) { if (p) g_pool.put(p); }
 static inline unsigned nblocks(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
 static int bits_for(uint64_t maxval) { int b = 1; while (b < 64 && (maxval >> b)) b++; return b; }
 
+// Host waits sleep instead of spinning (blocking-sync event): the process's CPU share belongs to the writer threads.
+static hipError_t stream_wait(cgx_ctx *ctx) {
+    if (!ctx->sync_ev) return hipStreamSynchronize(ctx->stream);
+    hipError_t e = hipEventRecord(ctx->sync_ev, ctx->stream);
+    return e != hipSuccess ? e : hipEventSynchronize(ctx->sync_ev);
+}
 struct Timer {
     hipEvent_t a, b; hipStream_t s;
-    Timer(hipStream_t st) : s(st) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, s); }
+    Timer(hipStream_t st) : s(st) { (void)hipEventCreate(&a); (void)hipEventCreateWithFlags(&b, hipEventBlockingSync); (void)hipEventRecord(a, s); }
     double stop() { (void)hipEventRecord(b, s); (void)hipEventSynchronize(b); float ms = 0; (void)hipEventElapsedTime(&ms, a, b); (void)hipEventDestroy(a); (void)hipEventDestroy(b); return ms; }
 };
 
@@ -121,12 +127,12 @@ static int incl_scan(cgx_ctx *ctx, const In *in, Out *out, size_t n) {
 }
 template <class T> static int d2h(cgx_ctx *ctx, T *dst, const T *src, size_t count) {
     HIPCHK(hipMemcpyAsync(dst, src, count * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(stream_wait(ctx));
     return CGX_OK;
 }
 template <class T> static int h2d(cgx_ctx *ctx, T *dst, const T *src, size_t count) {
     HIPCHK(hipMemcpyAsync(dst, src, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(stream_wait(ctx));
     return CGX_OK;
 }
 
@@ -213,7 +219,7 @@ static int sort128(cgx_ctx *ctx, uint64_t *&hi, uint64_t *&lo, size_t n, unsigne
     k_gather<<<nblocks(n, 256), 256, 0, ctx->stream>>>(hi, p1, k2, n);      // k2 = hi in lo-order
     TRY(sort_pairs(ctx, k2, hi, p1, p0, n, 0, hi_bits));                    // hi = sorted hi, p0 = final permutation
     k_gather<<<nblocks(n, 256), 256, 0, ctx->stream>>>(lo, p0, k1, n);      // k1 = lo in final order
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(stream_wait(ctx));
     dfree(lo); lo = k1; dfree(k2); dfree(p1);
     if (perm_out) *perm_out = p0; else dfree(p0);
     return CGX_OK;
@@ -235,6 +241,7 @@ extern "C" cgx_ctx *cgx_create(int device) {
         int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
         if (hipStreamCreateWithPriority(&c->stream, hipStreamDefault, hi) != hipSuccess) { (void)hipGetLastError(); if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return nullptr; } }
     }
+    if (hipEventCreateWithFlags(&c->sync_ev, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) { (void)hipGetLastError(); c->sync_ev = nullptr; }
     return c;
 }
 static void free_batch(cgx_ctx *c) {
@@ -261,6 +268,7 @@ extern "C" void cgx_destroy(cgx_ctx *c) {
     for (int a = 0; a < 2; a++) if (c->arena[a]) { (void)hipHostFree(c->arena[a]); c->arena[a] = nullptr; }
     for (int a = 0; a < 2; a++) { dfree(c->d_text[a]); dfree(c->d_qtext[a]); }
     dfree(c->d_spool); dfree(c->d_soff); dfree(c->d_tpool); dfree(c->d_toff); dfree(c->d_aa); dfree(c->d_bb); dfree(c->d_fs);
+    if (c->sync_ev) (void)hipEventDestroy(c->sync_ev);
     for (int r = 0; r < CGX_COPY_STREAMS; r++) if (c->copy_streams[r]) (void)hipStreamDestroy(c->copy_streams[r]);
     for (int r = 0; r < CGX_MAX_READERS; r++) if (c->copy_done[r]) (void)hipEventDestroy(c->copy_done[r]);
     (void)hipStreamSynchronize(c->stream);
@@ -361,7 +369,7 @@ static int build_lex_hash(cgx_ctx *ctx) {
     TRY(dalloc(ctx, &ctx->d_lexslot, cap)); TRY(dalloc(ctx, &ctx->d_lexnullv, (size_t)ctx->lex_ntgt + 1));
     k_lexslot_fill<<<nblocks(cap, 256), 256, 0, ctx->stream>>>(ctx->d_lexhkey, ctx->d_lexhidx, (size_t)cap, ctx->d_lexv1, ctx->d_lexv2, ctx->d_lexn1, ctx->d_lexn2, ctx->d_lexslot);
     if (ctx->lex_ntgt) k_lexnull_fill<<<nblocks(ctx->lex_ntgt, 256), 256, 0, ctx->stream>>>(ctx->d_lexnullt, ctx->lex_ntgt, ctx->d_lexv1, ctx->d_lexn1, ctx->d_lexnullv);
-    HIPCHK(hipStreamSynchronize(ctx->stream)); HIPCHK(hipGetLastError());
+    HIPCHK(stream_wait(ctx)); HIPCHK(hipGetLastError());
     return CGX_OK;
 }
 static cgx_lexview lex_view(const cgx_ctx *ctx) {
@@ -462,7 +470,7 @@ extern "C" int cgx_build_sa(cgx_ctx *ctx) {
         if (h > n) { snprintf(ctx->err, sizeof ctx->err, "suffix array did not converge"); return CGX_ERR_STATE; }
     }
     HIPCHK(hipMemcpyAsync(ctx->d_sa, sa, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(stream_wait(ctx));
     dfree(rank); dfree(val); dfree(sa); dfree(flags); dfree(key); dfree(keys);
     ctx->have_sa = true;
     ctx->ms["build_sa"] = tm.stop(); ctx->ms["build_sa_rounds"] = rounds;
@@ -546,7 +554,7 @@ extern "C" int cgx_precompute(cgx_ctx *ctx) {
     for (int i = 0; i < CGX_TOP * CGX_TOP; i++) { empty[2 * i] = 1; empty[2 * i + 1] = 0; }        // empty pair = {1,0} (SuffixArray.cu:1306)
     TRY(h2d(ctx, ctx->d_pidx, empty.data(), empty.size()));
     if (cnt) k_precomp_unpack<<<nblocks(cnt, 256), 256, 0, ctx->stream>>>(skeys, cnt, ctx->d_phit_start, ctx->d_phit_len, ctx->d_pidx);
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(stream_wait(ctx));
     dfree(keys); dfree(skeys); dfree(counter);
     ctx->nphits = cnt; ctx->have_pre = true;
     ctx->ms["precompute"] = tm.stop();
@@ -603,7 +611,7 @@ static int build_bigrams(cgx_ctx *ctx) {
     TRY(dalloc(ctx, &ctx->d_bg_key, cap)); TRY(dalloc(ctx, &ctx->d_bg_lo, cap)); TRY(dalloc(ctx, &ctx->d_bg_hi, cap));
     HIPCHK(hipMemsetAsync(ctx->d_bg_key, 0, cap * 8, ctx->stream));
     k_bigram_fill<<<nblocks(ctx->n, 256), 256, 0, ctx->stream>>>(ctx->d_str, ctx->d_sa, ctx->n, (unsigned long long *)ctx->d_bg_key, ctx->d_bg_lo, ctx->d_bg_hi, (uint32_t)(cap - 1), ctx->bg_shift);
-    HIPCHK(hipStreamSynchronize(ctx->stream)); HIPCHK(hipGetLastError());
+    HIPCHK(stream_wait(ctx)); HIPCHK(hipGetLastError());
     ctx->ms["bigrams_distinct"] = distinct;
     return CGX_OK;
 }
@@ -669,7 +677,7 @@ extern "C" int cgx_index_d2d(cgx_ctx *ctx, int i, void *dptr, int dir) {
     if (b[i].bytes == 0) return CGX_OK;
     if (dir == 0) HIPCHK(hipMemcpyAsync(dptr, *b[i].ptr, b[i].bytes, hipMemcpyDeviceToDevice, ctx->stream));
     else HIPCHK(hipMemcpyAsync(*b[i].ptr, dptr, b[i].bytes, hipMemcpyDeviceToDevice, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(stream_wait(ctx));
     return CGX_OK;
 }
 extern "C" int cgx_index_finalize(cgx_ctx *ctx) {
@@ -701,7 +709,7 @@ extern "C" int cgx_broadcast_index(cgx_ctx *ctx, void *nccl_comm, int root, int 
     if (gstart() != 0) return fail(ctx, CGX_ERR_HIP, "ncclGroupStart", hipSuccess);
     for (auto &b : bufs) if (b.bytes && bcast(*b.ptr, *b.ptr, (size_t)b.bytes, /*ncclUint8*/ 1, root, nccl_comm, ctx->stream) != 0) return fail(ctx, CGX_ERR_HIP, "ncclBroadcast", hipSuccess);
     if (gend() != 0) return fail(ctx, CGX_ERR_HIP, "ncclGroupEnd", hipSuccess);
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(stream_wait(ctx));
     if (rank != root) return cgx_index_finalize(ctx);
     return CGX_OK;
 }
@@ -1148,7 +1156,7 @@ static int dvec_reserve(cgx_ctx *ctx, dvec64 &v, size_t need) {
     size_t nc = v.cap ? v.cap : 1024; while (nc < need) nc *= 2;
     uint64_t *np = nullptr; TRY(dalloc(ctx, &np, nc));
     if (v.n) HIPCHK(hipMemcpyAsync(np, v.p, v.n * 8, hipMemcpyDeviceToDevice, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(stream_wait(ctx));
     dfree(v.p); v.p = np; v.cap = nc;
     return CGX_OK;
 }
@@ -1166,7 +1174,7 @@ static int append_pass(cgx_ctx *ctx, uint64_t units, uint64_t chunk, uint64_t W,
     for (int attempt = 0; ; attempt++) {
         if (want > out.cap) { size_t keep = out.n; uint64_t *np = nullptr; TRY(dalloc(ctx, &np, want));
             if (keep) HIPCHK(hipMemcpyAsync(np, out.p, keep * 8, hipMemcpyDeviceToDevice, ctx->stream));
-            HIPCHK(hipStreamSynchronize(ctx->stream)); dfree(out.p); out.p = np; out.cap = want; }
+            HIPCHK(stream_wait(ctx)); dfree(out.p); out.p = np; out.cap = want; }
         unsigned long long init = n0; TRY(h2d(ctx, total, &init, 1));
         appender ap{out.p, out.cap, total};
         for (uint64_t w0 = 0; w0 < units; w0 += chunk) {
@@ -1403,7 +1411,7 @@ extern "C" int cgx_gappy_search(cgx_ctx *ctx) {
         TRY(d2h(ctx, &D1, p1 + (E1 - 1), 1));
         TRY(dalloc(ctx, &ctx->d_s1, D1));
         k_make_s1<<<nblocks(E1, 256), 256, 0, st>>>(ctx->d_g1, flags, p1, E1, ctx->d_pid1, ctx->d_s1);
-        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(stream_wait(ctx));
         dfree(hi); dfree(lo); dfree(shi); dfree(slo); dfree(p0); dfree(p1); dfree(flags);
     }
     dfree(g_raw); dfree(p_raw);
@@ -1474,7 +1482,7 @@ extern "C" int cgx_gappy_search(cgx_ctx *ctx) {
             uint64_t *sk = nullptr; TRY(dalloc(ctx, &sk, H1));
             TRY(sort_keys(ctx, keys.p, sk, H1, 0, 64));                               // thrust::sort(oneGapSACompare) + canonical tie order
             k_unpack_hits1<<<nblocks(H1, 256), 256, 0, st>>>(sk, H1, ctx->d_hits1, ctx->d_s1);
-            HIPCHK(hipStreamSynchronize(st));
+            HIPCHK(stream_wait(ctx));
             dfree(sk);
         }
         dfree(keys.p); dfree(reckey); dfree(sreckey); dfree(markkey); dfree(recpid); dfree(srecpid); dfree(ctr);
@@ -1508,7 +1516,7 @@ extern "C" int cgx_gappy_search(cgx_ctx *ctx) {
             TRY(d2h(ctx, &D2, p0 + (E2 - 1), 1));
             TRY(dalloc(ctx, &ctx->d_s2, D2));
             k_make_s2<<<nblocks(E2, 256), 256, 0, st>>>(ctx->d_g2, flags, p0, E2, ctx->d_pid2, ctx->d_s2);
-            HIPCHK(hipStreamSynchronize(st));
+            HIPCHK(stream_wait(ctx));
             dfree(key); dfree(skey); dfree(p0); dfree(p1); dfree(flags);
         }
         dfree(g2raw); dfree(c2raw);
@@ -1578,10 +1586,10 @@ extern "C" int cgx_gappy_search(cgx_ctx *ctx) {
                 TRY(sort_pairs(ctx, recs.p, sv, wid, sk, accn, 0, 40));
                 TRY(sort_pairs(ctx, sk, sk2, sv, sv2, accn, 0, idbits));
                 k_unpack_hits2<true><<<nblocks(accn, 256), 256, 0, st>>>(sk2, sv2, (uint32_t)accn, ctx->d_hits2, ctx->d_s2);
-                HIPCHK(hipStreamSynchronize(st));
+                HIPCHK(stream_wait(ctx));
                 dfree(sk); dfree(sk2); dfree(sv2);
             }
-            HIPCHK(hipStreamSynchronize(st));
+            HIPCHK(stream_wait(ctx));
             dfree(sv);
         }
         ctx->h2 = (uint32_t)accn;
@@ -1591,7 +1599,7 @@ extern "C" int cgx_gappy_search(cgx_ctx *ctx) {
     TRY(dalloc(ctx, &ctx->d_p1d, D1)); TRY(dalloc(ctx, &ctx->d_c2d, D2)); TRY(dalloc(ctx, &ctx->d_one2, D2));
     if (D1) k_compact1<<<nblocks(D1, 256), 256, 0, st>>>(ctx->d_s1, ctx->d_p1, D1, ctx->d_p1d);
     if (D2) k_compact2<<<nblocks(D2, 256), 256, 0, st>>>(ctx->d_s2, ctx->d_c2, D2, ctx->d_c2d, ctx->d_one2);
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(stream_wait(ctx));
     HIPCHK(hipGetLastError());
     ctx->ms["gappy"] = tm.stop();
     return CGX_OK;
@@ -1802,7 +1810,7 @@ extern "C" int cgx_extract(cgx_ctx *ctx) {
     if (a2.n) k_pack_r2<<<nblocks(a2.n, 256), 256, 0, st>>>(a2.hi, a2.lo, a2.n, ctx->d_r2);
     if (b2.n) k_pack_r2<<<nblocks(b2.n, 256), 256, 0, st>>>(b2.hi, b2.lo, b2.n, ctx->d_r2 + a2.n);
     if (c2.n) k_pack_r2<<<nblocks(c2.n, 256), 256, 0, st>>>(c2.hi, c2.lo, c2.n, ctx->d_r2 + a2.n + b2.n);
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(stream_wait(ctx));
     unsigned int gx = 0; TRY(d2h(ctx, &gx, guard, 1)); ctx->guard_exits = gx;
     keyset_free(a0); keyset_free(a1); keyset_free(a2); keyset_free(b2); keyset_free(c1); keyset_free(c2);
     dfree(wA); dfree(oA); dfree(wB); dfree(oB); dfree(wC); dfree(oC); dfree(guard);
@@ -2004,7 +2012,7 @@ static int lexicon_kind(cgx_ctx *ctx, const lexsrc &L, const cgx_lexview &T, int
     dfree(*out); TRY(dalloc(ctx, out, nent));
     k_lex_finish<<<nblocks(nent, 128), 128, 0, st>>>(L, T, kind, ctx->d_r0, ctx->d_r1, ctx->d_r2, n, sfirst, seid, runstart, nent, nent, gincl, gstart, ng, *out);
     k_lex_ranges<<<nblocks(nent, 256), 256, 0, st>>>(*out, nent, *rng);
-    HIPCHK(hipStreamSynchronize(st)); HIPCHK(hipGetLastError());
+    HIPCHK(stream_wait(ctx)); HIPCHK(hipGetLastError());
     *nout = nent;
     dfree(hi); dfree(lo); dfree(perm); dfree(flags); dfree(incl); dfree(coll); dfree(first); dfree(runstart); dfree(sfirst); dfree(eid); dfree(seid); dfree(gstart);
     return CGX_OK;
@@ -2095,7 +2103,7 @@ extern "C" int64_t cgx_fetch(cgx_ctx *ctx, const char *name, void *dst, int64_t 
     if (bytes && !src) { snprintf(ctx->err, sizeof ctx->err, "%s not computed yet", name); return CGX_ERR_STATE; }
     if (bytes) {
         if (hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return CGX_ERR_HIP;
-        if (hipStreamSynchronize(ctx->stream) != hipSuccess) return CGX_ERR_HIP;
+        if (stream_wait(ctx) != hipSuccess) return CGX_ERR_HIP;
     }
     return bytes;
 }

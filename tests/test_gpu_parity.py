@@ -17,6 +17,10 @@ ROOT = op.ROOT
 
 @pytest.fixture(scope="module")
 def cgx():
+    # torch first, as in bench.py: its bundled HIP runtime must be the one that initialises the device,
+    # the replica test uses a torch tensor as the staging buffer
+    import torch
+    torch.zeros(1, device="cuda:0")
     import cgx_amd
     cgx_amd.load_library()
     return cgx_amd
@@ -163,6 +167,27 @@ def test_lookup_output_sizing_paths(opts, cgx, fixtures_dir, tmp_path):
     ex, corpus, n = run_product(cgx, fx, str(tmp_path / "a"), **opts)
     assert op.sha_dir(str(tmp_path / "a"), 7) == META["toy"]["grammar"]
     ex.close(); corpus.close()
+
+
+def test_index_replica_gives_the_same_files(cgx, fixtures_dir, tmp_path):
+    """Multi-GPU layout on one card: a second context receives the index buffer by buffer (what bench.py does over
+    RCCL and cgx_broadcast_index does in C), rebuilds the derived tables in cgx_index_finalize and must produce the
+    same grammar files as the context that built the index."""
+    import torch
+    fx = make_fixture("toy", fixtures_dir); files = op.fixture_args(fx)
+    root = cgx.Extractor(0); corpus = cgx.Corpus.load(files[0], files[2], files[3], files[4]); root.upload_corpus(corpus)
+    rep = cgx.Extractor(0); rep.index_alloc(root.index_shape())
+    for i, (name, nbytes) in enumerate(root.index_buffers()):
+        if nbytes == 0:
+            continue
+        stage = torch.empty(nbytes, dtype=torch.uint8, device="cuda:0")
+        root.index_d2d(i, stage.data_ptr(), 0); torch.cuda.synchronize()
+        rep.index_d2d(i, stage.data_ptr(), 1); torch.cuda.synchronize()
+    rep.index_finalize()
+    os.makedirs(str(tmp_path / "r"))
+    rep.extract_grammars(corpus, files[1], str(tmp_path / "r"))
+    assert op.sha_dir(str(tmp_path / "r"), 7) == META["toy"]["grammar"]
+    rep.close(); root.close(); corpus.close()
 
 
 def test_bigram_table_does_not_change_intervals(cgx, oracle_bin, fixtures_dir, tmp_path):
