@@ -1,0 +1,137 @@
+"""Full-size GPU checks (BASELINE configs[2]: 10 M sentence pairs, 2.6e8 source tokens).  The oracle cannot run at
+this size, so the HIP path is checked through properties that do not depend on size: the suffix array is a sorted
+permutation, every reported interval is exactly the set of suffixes that start with the phrase, and the grammar
+files do not depend on how the batch is split or scheduled."""
+import hashlib
+import os
+import shutil
+import tempfile
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+PAIRS = int(os.environ.get("CGX_FULLSIZE_PAIRS", "10000000"))
+
+
+@pytest.fixture(scope="module")
+def world():
+    import torch
+    torch.zeros(1, device="cuda:0")
+    import cgx_amd
+    from cgx_amd import synth
+    cgx_amd.load_library()
+    corpus = synth.make_corpus(PAIRS, 200000, 1)
+    host = cgx_amd.Corpus.from_ids(corpus["str"], corpus["sentind"], corpus["tstr"], corpus["tsentind"], corpus["lsrc"], corpus["rsrc"],
+                                   corpus["ltar"], corpus["rtar"], corpus["lexk"], corpus["lexv"])
+    ex = cgx_amd.Extractor(0)
+    ex.upload_corpus(host)
+    yield cgx_amd, synth, corpus, host, ex
+    ex.close(); host.close()
+
+
+def _window(s, pos, w):
+    """tokens s[pos + k], k < w, zero beyond the end"""
+    idx = pos[:, None].astype(np.int64) + np.arange(w)[None, :]
+    ok = idx < len(s)
+    return np.where(ok, s[np.minimum(idx, len(s) - 1)], 0)
+
+
+def test_suffix_array_is_a_sorted_permutation(world):
+    cgx, synth, corpus, host, ex = world
+    s = corpus["str"]; n = len(s)
+    sa = ex.fetch("sa")
+    assert len(sa) == n
+    assert np.array_equal(np.bincount(sa, minlength=n), np.ones(n, np.int64))
+    rng = np.random.default_rng(7)
+    i = rng.integers(0, n - 1, 300000)
+    W = 24
+    a = _window(s, sa[i], W); b = _window(s, sa[i + 1], W)
+    diff = a != b
+    first = np.where(diff.any(1), diff.argmax(1), W)
+    decided = first < W
+    assert decided.mean() > 0.99                              # 24 tokens separate almost every adjacent pair
+    k = first[decided]
+    assert np.all(a[decided, k] < b[decided, k])
+
+
+def test_intervals_are_exactly_the_matching_suffixes(world):
+    cgx, synth, corpus, host, ex = world
+    s = corpus["str"]; n = len(s)
+    sa = ex.fetch("sa")
+    qoff, qtok = synth.make_queries(corpus, 2000, 11)
+    ex.upload_queries(qoff, qtok); ex.sa_lookup()
+    lm, up, down = ex.fetch("lm"), ex.fetch("up").reshape(-1, 5), ex.fetch("down").reshape(-1, 5)
+    T = len(qtok)
+    qend = np.concatenate((qoff[1:], [T]))
+    tok2end = np.repeat(qend, qend - qoff)
+    rng = np.random.default_rng(3)
+    t = rng.integers(0, T, 60000); t = t[lm[t] > 0]
+    l = 1 + rng.integers(0, 5, len(t)) % lm[t]
+    u = up[t, l - 1].astype(np.int64); d = down[t, l - 1].astype(np.int64)
+    assert np.all(u <= d)
+    want = _window(qtok, t, 5)
+    mask = np.arange(5)[None, :] < l[:, None]
+    def matches(pos, sel=slice(None)):
+        return np.all((_window(s, pos, 5) == want[sel]) | ~mask[sel], axis=1)
+    mid = u + ((d - u) * rng.random(len(t))).astype(np.int64)
+    assert matches(sa[u]).all() and matches(sa[d]).all() and matches(sa[mid]).all()
+    lo = u > 0; hi = d < n - 1                                # the neighbours just outside the interval do not match
+    assert not matches(sa[u[lo] - 1], lo).any()
+    assert not matches(sa[d[hi] + 1], hi).any()
+    # lm is maximal: the next longer phrase (if the query has one and l < 5) does not occur
+    room = (t + lm[t] < tok2end[t]) & (lm[t] < 5)
+    tt = t[room]; ll = lm[tt]
+    uu = up[tt, ll - 1].astype(np.int64); dd = down[tt, ll - 1].astype(np.int64)
+    small = (dd - uu) < 64                                    # check exhaustively where the interval is short
+    tt, ll, uu, dd = tt[small], ll[small], uu[small], dd[small]
+    nxt = qtok[tt + ll]
+    for k in range(64):
+        pos = np.minimum(uu + k, dd)
+        assert not np.any(s[np.minimum(sa[pos] + ll, n - 1)] == nxt)
+
+
+def _sha_dir(d, nq):
+    h = hashlib.sha256()
+    for q in range(nq):
+        with open(os.path.join(d, "grammar.%d.s" % q), "rb") as f:
+            while True:
+                b = f.read(1 << 24)
+                if not b:
+                    break
+                h.update(b)
+        h.update(b"\0")
+    return h.hexdigest()
+
+
+def test_grammar_files_do_not_depend_on_batching(world):
+    cgx, synth, corpus, host, ex = world
+    nq = 600
+    qoff, qtok = synth.make_queries(corpus, nq, 5)
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    out = tempfile.mkdtemp(prefix="cgx_full_", dir=base)
+    try:
+        dirs = [os.path.join(out, x) for x in "abc"]
+        for d in dirs:
+            os.mkdir(d)
+        n_all = ex.extract_grammars_ids(host, qoff, qtok, dirs[0], 0)
+        lines = 0
+        for q in range(nq):
+            with open(os.path.join(dirs[0], "grammar.%d.s" % q), "rb") as f:
+                lines += sum(b.count(b"\n") for b in iter(lambda: f.read(1 << 24), b""))
+        assert lines == n_all and n_all > 0
+        ref = _sha_dir(dirs[0], nq)
+        # two halves, asynchronous writer
+        ex.set_option("async_write", 1)
+        cut = nq // 3; tcut = int(qoff[cut])
+        n1 = ex.extract_grammars_ids(host, qoff[:cut], qtok[:tcut], dirs[1], 0)
+        n2 = ex.extract_grammars_ids(host, qoff[cut:] - tcut, qtok[tcut:], dirs[1], cut)
+        ex.flush(); ex.set_option("async_write", 0)
+        assert n1 + n2 == n_all and _sha_dir(dirs[1], nq) == ref
+        # internal sub-batches and small lookup launches
+        ex.set_option("sub_batch", 250); ex.set_option("chunk_items", 1 << 20)
+        n3 = ex.extract_grammars_ids(host, qoff, qtok, dirs[2], 0)
+        ex.set_option("sub_batch", 0); ex.set_option("chunk_items", 1 << 26)
+        assert n3 == n_all and _sha_dir(dirs[2], nq) == ref
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
