@@ -173,7 +173,7 @@ def main():
     for _ in range(args.warmup):
         step()
     ex.flush()
-    kernel_ms = []; stage = {k: 0.0 for k in ("sa_lookup", "gappy", "extract", "lexicon", "format", "fmt_lists", "fmt_count", "fmt_alloc", "fmt_write")}; hoststage = {k: 0.0 for k in ("blocks", "lists", "lexicon", "write", "write_wait_d2h", "write_file", "total", "t_upload_sa", "t_fetch_lm", "t_blocks", "t_qblocks", "t_gappy", "t_extract", "t_lexicon", "t_format", "t_offsets", "t_flush_wait")}
+    kernel_ms = []; stage = {k: 0.0 for k in ("sa_lookup", "gappy", "extract", "lexicon", "format", "fmt_lists", "fmt_count", "fmt_alloc", "fmt_write", "look1_kernel", "look2_kernel")}; hoststage = {k: 0.0 for k in ("blocks", "lists", "lexicon", "write", "write_wait_d2h", "write_file", "total", "t_upload_sa", "t_fetch_lm", "t_blocks", "t_qblocks", "t_gappy", "t_extract", "t_lexicon", "t_format", "t_offsets", "t_flush_wait")}
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -206,6 +206,17 @@ def main():
         except Exception:
             traffic = None
         ach = abytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+        # the two kernels that take the most time per batch, priced the same way: bytes the algorithm must touch per
+        # occurrence (SA entry 4 + text window 64 + alignment window 64 + sentence offset 4 [+ the 9-byte hit record
+        # for look2]) + 8 per hit written, over the stage's event time (includes the launch sizing round trip)
+        w1, w2 = ex.stage_ms("look1_items"), ex.stage_ms("look2_items")
+        k1, k2 = stage["look1_kernel"] / args.steps, stage["look2_kernel"] / args.steps
+        by_time = []
+        for name, w, per, hits, ms in (("k_look1 (one-gap corpus lookups)", w1, 136, c["h1"], k1), ("k_look2 (two-gap corpus lookups)", w2, 145, c["h2"], k2)):
+            if w > 0 and ms > 0:
+                ab = w * per + hits * 8
+                by_time.append({"kernel": name, "bound": "hbm", "occurrences_per_step": int(w), "algorithmic_bytes_per_step": int(ab), "ms_per_step": round(ms, 3),
+                                "achieved": round(ab / (ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ab / (ms * 1e-3) / 1e9 / 8000.0, 4)})
         line = {
             "metric": "query sentences/sec", "value": round(total_q / dt, 3), "unit": "query sentences/s",
             "rules_per_s": round(total_rules / dt, 1), "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -220,6 +231,7 @@ def main():
                          "frac": round(ach / 8000.0, 4), "traffic": traffic, "algorithmic_bytes_per_launch": int(abytes), "lookups_per_launch": int(lookups),
                          "kernel_ms": round(kms, 4), "pmc_GBps": (round(traffic / (kms * 1e-3) / 1e9, 1) if traffic and kms > 0 else None),
                          "note": "achieved prices every lookup at the reference's full-depth binary search (SURVEY 8d); this kernel replaces l=1,2 by table probes, so achieved can exceed the peak while pmc_GBps is the traffic it really moves"},
+            "roofline_largest_per_batch_kernels": by_time,
             "stages_ms_per_step": {k: round(v / args.steps, 3) for k, v in {**stage, **{"host_" + k: v for k, v in hoststage.items()}}.items()},
             "index": {"build_sa_ms": round(ex.stage_ms("build_sa"), 1), "precompute_ms": round(ex.stage_ms("precompute"), 1),
                       "broadcast_s": round(t_bcast, 3), "total_s": round(t_index, 2), "corpus_gen_s": round(t_gen, 2), "frequent_pair_hits": c["nphits"]},
