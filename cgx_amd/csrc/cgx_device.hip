@@ -165,7 +165,7 @@ __device__ __forceinline__ uint32_t wave_append(unsigned int *counter, bool vali
 // past `cap`, so the host learns the exact size needed when a launch overflows and can rerun
 // it; nothing is written beyond `cap`.
 #define POOL_N 2048
-struct appender { uint64_t *out; uint64_t cap; unsigned long long *total; };
+struct appender { uint64_t *out; uint64_t cap; unsigned long long *total; uint32_t pool_n; };   // pool_n <= POOL_N: pool entries in use (test hook)
 struct pool_t { uint64_t buf[POOL_N]; unsigned int n, snap; unsigned long long base; };
 __device__ __forceinline__ uint64_t lanes_reserve(unsigned long long *ctr) {        // callable from divergent code
     unsigned long long m = __ballot(1);
@@ -177,7 +177,7 @@ __device__ __forceinline__ uint64_t lanes_reserve(unsigned long long *ctr) {    
 }
 __device__ __forceinline__ void pool_put(pool_t &P, const appender &ap, uint64_t rec) {
     unsigned int slot = atomicAdd(&P.n, 1u);
-    if (slot < POOL_N) P.buf[slot] = rec;
+    if (slot < ap.pool_n) P.buf[slot] = rec;
     else { uint64_t g = lanes_reserve(ap.total); if (g < ap.cap) ap.out[g] = rec; }
 }
 // block-uniform: every thread of the block must call it.  Drains when the pool is at least
@@ -188,7 +188,7 @@ __device__ __forceinline__ void pool_drain(pool_t &P, const appender &ap, unsign
     __syncthreads();
     unsigned int cnt = P.snap;
     if (cnt < threshold || cnt == 0) return;
-    if (cnt > POOL_N) cnt = POOL_N;
+    if (cnt > ap.pool_n) cnt = ap.pool_n;
     if (threadIdx.x == 0) P.base = atomicAdd(ap.total, (unsigned long long)cnt);
     __syncthreads();
     const unsigned long long base = P.base;
@@ -227,7 +227,7 @@ static int append_pass(cgx_ctx *ctx, uint64_t units, uint64_t chunk, uint64_t W,
             HIPCHK(stream_wait(ctx)); dfree(out.p); out.p = np; out.cap = want; }
         unsigned long long init = n0; TRY(h2d(ctx, total, &init, 1));
         reset();
-        appender ap{out.p, out.cap, total};
+        appender ap{out.p, out.cap, total, ctx->pool_cap < POOL_N ? (ctx->pool_cap ? ctx->pool_cap : 1u) : POOL_N};
         for (uint64_t w0 = 0; w0 < units; w0 += chunk) {
             uint64_t nw = units - w0 < chunk ? units - w0 : chunk;
             launch(w0, nw, ap);
@@ -334,6 +334,7 @@ extern "C" int cgx_set_option(cgx_ctx *c, const char *name, int64_t value) {
     if (!strcmp(name, "use_bigrams")) { c->use_bigrams = value != 0; return CGX_OK; }
     if (!strcmp(name, "use_lex_hash")) { c->use_lex_hash = value != 0; return CGX_OK; }
     if (!strcmp(name, "wide_hits2")) { c->wide_hits2 = value != 0; return CGX_OK; }
+    if (!strcmp(name, "pool_cap")) { if (value < 1) return CGX_ERR_ARG; c->pool_cap = (uint32_t)(value > POOL_N ? POOL_N : value); return CGX_OK; }
     if (!strcmp(name, "look_rec_cap")) { if (value < 0) return CGX_ERR_ARG; c->look_rec_cap = (uint32_t)(value > 65535 ? 65535 : value); return CGX_OK; }
     if (!strcmp(name, "sub_batch")) { if (value < 0) return CGX_ERR_ARG; c->sub_batch = value; return CGX_OK; }
     if (!strcmp(name, "append_slack")) { if (value < 0) return CGX_ERR_ARG; c->append_slack = (uint64_t)value; return CGX_OK; }
@@ -389,6 +390,7 @@ __global__ void k_lexhash_fill(const uint64_t *key, uint32_t n, unsigned long lo
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const unsigned long long k = key[i];
+    if (k == 0) return;                                          // a (NULL, NULL) row: never looked up, and 0 marks an empty slot
     uint32_t slot = (uint32_t)((k * 0x9E3779B97F4A7C15ull) >> shift) & mask;
     for (;;) { unsigned long long prev = atomicCAS(&hkey[slot], 0ull, k); if (prev == 0ull || prev == k) break; slot = (slot + 1) & mask; }
     atomicMin(&hidx[slot], i);
@@ -558,7 +560,7 @@ __global__ __launch_bounds__(256) void k_precomp(cgx_view v, const int8_t *tokra
                 else atomicAdd(&hist[pair], 1);
             }
         }
-        pool_drain(pool, ap, POOL_N / 2);
+        pool_drain(pool, ap, ap.pool_n / 2);
     }
     pool_drain(pool, ap, 0);
     for (int k = threadIdx.x; k < CGX_TOP * CGX_TOP; k += 256) if (hist[k]) atomicAdd(&miss[k], hist[k]);
@@ -1193,7 +1195,7 @@ __global__ __launch_bounds__(256) void k_look1(cgx_view v, const int32_t *sa, co
                 }
             }
         }
-        pool_drain(pool, ap, it + 1 < L1_TILE / 256 ? POOL_N / 2 : 0);
+        pool_drain(pool, ap, it + 1 < L1_TILE / 256 ? ap.pool_n / 2 : 0);
     }
 }
 __global__ void k_tiles(const uint64_t *work, uint32_t ng, uint32_t tile, uint64_t *tiles) {
@@ -1356,7 +1358,7 @@ __global__ __launch_bounds__(256) void k_look2(cgx_view v, const cgx_twogapsearc
                 }
             }
         }
-        if (!WIDE) pool_drain(pool, ap, it + 1 < L2_TILE / 256 ? POOL_N / 2 : 0);
+        if (!WIDE) pool_drain(pool, ap, it + 1 < L2_TILE / 256 ? ap.pool_n / 2 : 0);
     }
 }
 __global__ void k_s2c(const cgx_twogapsearch *s2, const int32_t *c2, uint32_t d2, int32_t *s2c) {
@@ -1582,7 +1584,7 @@ extern "C" int cgx_gappy_search(cgx_ctx *ctx) {
             // ids travel in a parallel array, so capacity is fixed before launching: count first with cap 0
             for (int pass = 0; pass < 2; pass++) {
                 unsigned long long *total = nullptr; TRY(dalloc(ctx, &total, 1)); HIPCHK(hipMemsetAsync(total, 0, 8, st));
-                appender ap{recs.p, recs.cap, total};
+                appender ap{recs.p, recs.cap, total, POOL_N};
                 for (uint64_t t0 = 0; t0 < NT; t0 += tile_chunk) {
                     uint64_t nt = NT - t0 < tile_chunk ? NT - t0 : tile_chunk;
                     k_look2<true><<<(unsigned)nt, 256, 0, st>>>(v, ctx->d_s2, s2c, ctx->d_s1, groups, toff, work, NG, t0, ctx->d_hits1, ctx->d_pidx, ctx->d_phit_start, ctx->d_phit_len, H2, ap, wid, ctx->look_rec_cap < L2_REC ? ctx->look_rec_cap : L2_REC);
