@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; nccl (= RCCL over xGMI) for real runs, gloo only to rehearse N>1 on a one-GPU box")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--sub-batch", type=int, default=0, help="queries per internal batch inside one step (0 = the whole step at once)")
+    ap.add_argument("--no-numa-pin", action="store_true", help="do not bind the writer threads to the GPU's NUMA node")
     ap.add_argument("--sync-write", action="store_true", help="write each step's files before starting the next step")
     ap.add_argument("--no-write", action="store_true", help="format nothing, write no files (kernel-side study only; not the headline)")
     args = ap.parse_args()
@@ -113,6 +114,8 @@ def main():
     ex = cgx_amd.Extractor(local)
     if args.sub_batch:
         ex.set_option("sub_batch", args.sub_batch)
+    if args.no_numa_pin:
+        ex.set_option("numa_pin", 0)
     if not args.sync_write:
         ex.set_option("async_write", 1)       # files of step k are written by host threads while the GPU runs step k+1; flushed inside the timed region
 

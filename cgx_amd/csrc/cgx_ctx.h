@@ -37,6 +37,7 @@ struct cgx_ctx {
     uint32_t *d_pidx = nullptr; int32_t *d_miss = nullptr; uint32_t *d_phit_start = nullptr; uint8_t *d_phit_len = nullptr;
     uint64_t *d_bg_key = nullptr; uint32_t *d_bg_lo = nullptr, *d_bg_hi = nullptr; uint32_t bg_cap = 0; unsigned bg_shift = 0;   // bigram -> SA interval
     bool use_bigrams = true;
+    bool numa_pin = true;               // writer threads run on the CPUs of the GPU's NUMA node
     bool use_lex_hash = true;           // MaxLex pair lookups through the pair hash (0: binary search in the source word's row)
     int64_t sub_batch = 0;              // queries per internal batch of cgx_extract_grammars* (0 = all at once)
     uint32_t pool_cap = 1u << 30;       // test hook: entries of the per-block append pool in use (clamped to POOL_N)

@@ -332,6 +332,7 @@ extern "C" int cgx_set_option(cgx_ctx *c, const char *name, int64_t value) {
     if (!strcmp(name, "k1_limit")) { c->k1_limit = (int)value; return CGX_OK; }
     if (!strcmp(name, "device_format")) { c->device_format = value != 0; return CGX_OK; }
     if (!strcmp(name, "use_bigrams")) { c->use_bigrams = value != 0; return CGX_OK; }
+    if (!strcmp(name, "numa_pin")) { c->numa_pin = value != 0; return CGX_OK; }
     if (!strcmp(name, "use_lex_hash")) { c->use_lex_hash = value != 0; return CGX_OK; }
     if (!strcmp(name, "wide_hits2")) { c->wide_hits2 = value != 0; return CGX_OK; }
     if (!strcmp(name, "pool_cap")) { if (value < 1) return CGX_ERR_ARG; c->pool_cap = (uint32_t)(value > POOL_N ? POOL_N : value); return CGX_OK; }
@@ -350,7 +351,22 @@ extern "C" int64_t cgx__option(cgx_ctx *c, const char *name) {
     if (!strcmp(name, "async_write")) return (int64_t)c->async_write;
     if (!strcmp(name, "device_format")) return (int64_t)c->device_format;
     if (!strcmp(name, "sub_batch")) return c->sub_batch;
+    if (!strcmp(name, "numa_pin")) return (int64_t)c->numa_pin;
     return 0;
+}
+// "local_cpulist" of the GPU's PCI function (the CPUs of its NUMA node), or an empty string
+extern "C" void cgx__device_cpulist(cgx_ctx *c, char *buf, size_t cap) {
+    if (!buf || !cap) return;
+    buf[0] = 0;
+    if (!c) return;
+    char bdf[64] = {0};
+    if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, c->device) != hipSuccess) { (void)hipGetLastError(); return; }
+    for (char *p = bdf; *p; p++) if (*p >= 'A' && *p <= 'F') *p = (char)(*p - 'A' + 'a');
+    char path[160]; snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/local_cpulist", bdf);
+    FILE *f = fopen(path, "r");
+    if (!f) return;
+    if (!fgets(buf, (int)cap, f)) buf[0] = 0;
+    fclose(f);
 }
 extern "C" const void *cgx__get_vocab_owner(cgx_ctx *c) { return c ? c->vocab_owner : nullptr; }
 extern "C" void cgx__set_vocab_owner(cgx_ctx *c, const void *p) { if (c) c->vocab_owner = p; }

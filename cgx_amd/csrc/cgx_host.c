@@ -28,6 +28,7 @@
 #include <string.h>
 #include <time.h>
 #include <pthread.h>
+#include <sched.h>
 #include <unistd.h>
 #include <fcntl.h>
 #include <sys/types.h>
@@ -798,8 +799,25 @@ static int write_piece(devjob *w, int64_t pc, const char *src) {
     }
     return CGX_OK;
 }
+/* Writer threads copy 30+ GB per batch between the page-locked staging buffers and the page cache: keep them on
+ * the CPUs of the GPU's NUMA node, where the DMA lands.  Best effort (the list comes from sysfs). */
+static void pin_to_device_node(cgx_ctx *ctx) {
+    if (!cgx__option(ctx, "numa_pin")) return;
+    char list[1024]; cgx__device_cpulist(ctx, list, sizeof list);
+    cpu_set_t set; CPU_ZERO(&set); int any = 0;
+    for (char *p = list; *p;) {
+        char *e; long a = strtol(p, &e, 10), b = a;
+        if (e == p) break;
+        if (*e == '-') { p = e + 1; b = strtol(p, &e, 10); if (e == p) break; }
+        for (long c = a; c <= b && c < CPU_SETSIZE; c++) { if (c >= 0) { CPU_SET((int)c, &set); any = 1; } }
+        p = *e == ',' ? e + 1 : e;
+        if (*e != ',') break;
+    }
+    if (any) (void)pthread_setaffinity_np(pthread_self(), sizeof set, &set);
+}
 static void *dev_write_worker(void *arg) {
-    devjob *w = arg; w->rc = CGX_OK; w->wait_ms = w->write_ms = 0;
+    devjob *w = arg; w->rc = CGX_OK;
+    if (w->tid > 0) pin_to_device_node(w->ctx);               /* thread 0 may be the caller's own thread: left alone */ w->wait_ms = w->write_ms = 0;
     for (int k = 0; k < PIN_RING; k++) { if (!g_pin[w->tid][k]) g_pin[w->tid][k] = cgx_pinned_alloc(PIN_BYTES); if (!g_pin[w->tid][k]) { w->rc = CGX_ERR_NOMEM; return NULL; } }
     const uint64_t total = w->qtext[w->nq];
     int64_t ring[PIN_RING]; int head = 0, count = 0, more = 1;
@@ -868,6 +886,7 @@ typedef struct { batch *b; char *outdir; int32_t first; pthread_t th; int active
                  cgx_ctx *ctx; int dev, slot; uint64_t *qtext; int32_t nq; } pending;
 static void *pending_main(void *arg) {
     pending *pw = arg; double t = now_ms();
+    if (pw->dev) pin_to_device_node(pw->ctx);                 /* this background thread doubles as writer 0 */
     pw->rc = pw->dev ? write_from_device(pw->ctx, pw->slot, pw->qtext, pw->nq, pw->outdir, pw->first, &pw->wait_ms, &pw->file_ms) : write_grammars(pw->b, pw->outdir, pw->first, &pw->lines);
     pw->ms = now_ms() - t;
     return NULL;

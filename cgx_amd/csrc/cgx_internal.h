@@ -11,7 +11,8 @@ void cgx__set_host_state(cgx_ctx *ctx, void *p);              /* per-context hos
 void *cgx__get_host_state(cgx_ctx *ctx);
 void cgx__host_release(cgx_ctx *ctx);
 const void *cgx__get_vocab_owner(cgx_ctx *ctx);               /* corpus whose spellings / score tables are on the device */
-void cgx__set_vocab_owner(cgx_ctx *ctx, const void *corpus);                         /* implemented by the host TU, called from cgx_destroy */
+void cgx__set_vocab_owner(cgx_ctx *ctx, const void *corpus);
+void cgx__device_cpulist(cgx_ctx *ctx, char *buf, size_t cap);  /* sysfs local_cpulist of the GPU ("0-63,128-191"), "" if unknown */                         /* implemented by the host TU, called from cgx_destroy */
 #ifdef __cplusplus
 }
 #endif

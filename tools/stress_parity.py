@@ -62,11 +62,22 @@ def run_case(cgx_amd, shape, verbose=True):
 
 def main():
     ap = argparse.ArgumentParser(); ap.add_argument("--only", type=int, default=-1)
+    ap.add_argument("--fuzz", type=int, default=0, help="instead of the fixed shapes: this many random shapes and option sets")
+    ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--opt", action="append", default=[], help="name=value, overrides the case's options")
     args = ap.parse_args()
     import torch; torch.zeros(1, device="cuda:0")
     import cgx_amd; cgx_amd.load_library()
     shapes = SHAPES if args.only < 0 else [SHAPES[args.only]]
+    if args.fuzz:
+        import random
+        r = random.Random(args.seed); shapes = []
+        menu = {"pool_cap": [1, 7, 64], "look_rec_cap": [0, 1, 5, 40], "sub_batch": [1, 13, 50], "async_write": [1], "chunk_items": [1024, 4096, 1 << 16],
+                "use_lex_hash": [0], "append_guess_milli": [1, 300], "append_slack": [0, 5], "wide_hits2": [1], "device_format": [0], "use_bigrams": [0], "k1_limit": [128]}
+        for i in range(args.fuzz):
+            lo = r.choice([1, 2, 4, 8, 15]); hi = lo + r.choice([3, 10, 25, 60])
+            opts = {k: r.choice(v) for k, v in menu.items() if r.random() < 0.25}
+            shapes.append((r.choice([1500, 4000, 9000, 25000]), r.choice([101, 105, 130, 250, 900, 5000]), r.choice([20, 60, 130]), 1000 * args.seed + i, lo, hi, opts))
     if args.opt: shapes = [s_[:6] + (dict(o.split("=") for o in args.opt),) for s_ in shapes]
     bad = 0
     for shape in shapes:
