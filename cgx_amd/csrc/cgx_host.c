@@ -163,8 +163,9 @@ static int load_alignment(cgx_corpus *c, const char *path, char *err, size_t err
             if (p >= e) break;
             size_t t = p; while (t < e && buf[t] != ' ' && buf[t] != '-') t++;
             if (isspace((unsigned char)buf[p])) break;
-            char tmp[32]; size_t L = t - p < sizeof tmp - 1 ? t - p : sizeof tmp - 1; memcpy(tmp, buf + p, L); tmp[L] = 0;
-            int val = atoi(tmp); p = t;
+            int val = 0;                                  /* atoi() of the token: optional '+', leading digits, anything else ends it */
+            { size_t k = p; if (k < t && buf[k] == '+') k++; for (; k < t && buf[k] >= '0' && buf[k] <= '9'; k++) if (val < 100000000) val = val * 10 + (buf[k] - '0'); }
+            p = t;
             if (!have_s) { s = val; have_s = 1; continue; }
             have_s = 0;
             if (s >= 255 || val >= 255 || s < 0 || val < 0) { snprintf(err, errcap, "Not possible, too long sentence"); rc = CGX_ERR_ALIGN_RANGE; break; }
@@ -226,17 +227,43 @@ void cgx_corpus_free(cgx_corpus *c) {
     free(c->lexk); free(c->lexv); free(c);
 }
 
+typedef struct { cgx_corpus *c; const char *path; int what; int rc; char *err; size_t errcap; int32_t nsent; } loadjob;
+static void *load_side_job(void *arg) {
+    loadjob *j = arg; cgx_corpus *c = j->c;
+    if (j->what == 0) j->rc = load_side(j->path, &c->str, &c->n, &c->P, &c->sentind, &c->nsent, &c->svocab, &c->nsvocab, &c->smap);
+    else if (j->what == 1) j->rc = load_side(j->path, &c->tstr, &c->nt, NULL, &c->tsentind, &j->nsent, &c->tvocab, &c->ntvocab, &c->tmap);
+    else if (j->what == 2) j->rc = load_lex(c, j->path, j->err, j->errcap);
+    else j->rc = load_alignment(c, j->path, j->err, j->errcap);
+    return NULL;
+}
 cgx_corpus *cgx_corpus_load(const char *src, const char *tgt, const char *align, const char *lex, char *err, size_t errcap) {
     char dummy[8]; if (!err) { err = dummy; errcap = sizeof dummy; }
     err[0] = 0;
     cgx_corpus *c = calloc(1, sizeof *c);
     if (!c) return NULL;
-    int32_t tn;
-    if (load_side(src, &c->str, &c->n, &c->P, &c->sentind, &c->nsent, &c->svocab, &c->nsvocab, &c->smap)) { snprintf(err, errcap, "Can not open reference file \"%s\"", src); goto bad; }
-    if (load_side(tgt, &c->tstr, &c->nt, NULL, &c->tsentind, &tn, &c->tvocab, &c->ntvocab, &c->tmap)) { snprintf(err, errcap, "Can not open reference file \"%s\"", tgt); goto bad; }
+    /* the two sides of the bitext are parsed concurrently, then the lexical table and the alignment (both only
+     * read what the first pair produced) */
+    int32_t tn = 0; const int trace = getenv("CGX_TRACE") != NULL; double t0 = now_ms();
+    loadjob js = {c, src, 0, 0, err, errcap, 0}, jt = {c, tgt, 1, 0, NULL, 0, 0};
+    pthread_t th; int threaded = !pthread_create(&th, NULL, load_side_job, &jt);
+    load_side_job(&js);
+    if (threaded) pthread_join(th, NULL); else load_side_job(&jt);
+    if (js.rc) { snprintf(err, errcap, "Can not open reference file \"%s\"", src); goto bad; }
+    if (jt.rc) { snprintf(err, errcap, "Can not open reference file \"%s\"", tgt); goto bad; }
+    tn = jt.nsent;
+    if (trace) fprintf(stderr, "cgx: bitext parsed in %.0f ms (%u + %u tokens)\n", now_ms() - t0, c->n, c->nt);
+    t0 = now_ms();
     if (tn != c->nsent) { snprintf(err, errcap, "source has %d lines, target %d", c->nsent, tn); goto bad; }
-    if (load_lex(c, lex, err, errcap) != CGX_OK) goto bad;
-    if (load_alignment(c, align, err, errcap) != CGX_OK) goto bad;
+    {
+        char err2[512]; err2[0] = 0;
+        loadjob jl = {c, lex, 2, 0, err, errcap, 0}, ja = {c, align, 3, 0, err2, sizeof err2, 0};
+        threaded = !pthread_create(&th, NULL, load_side_job, &ja);
+        load_side_job(&jl);
+        if (threaded) pthread_join(th, NULL); else load_side_job(&ja);
+        if (jl.rc != CGX_OK) goto bad;                       /* same precedence as the sequential loader: lexical table first */
+        if (ja.rc != CGX_OK) { snprintf(err, errcap, "%s", err2); goto bad; }
+    }
+    if (trace) fprintf(stderr, "cgx: lexical table + alignment parsed in %.0f ms\n", now_ms() - t0);
     c->svlen = calloc((size_t)c->nsvocab + 1, 4); c->tvlen = calloc((size_t)c->ntvocab + 1, 4); c->maxword = 16;
     if (!c->svlen || !c->tvlen) goto bad;
     for (int32_t i = 2; i < c->nsvocab; i++) { c->svlen[i] = (uint32_t)strlen(c->svocab[i]); if (c->svlen[i] > c->maxword) c->maxword = c->svlen[i]; }
@@ -817,7 +844,8 @@ static void pin_to_device_node(cgx_ctx *ctx) {
 }
 static void *dev_write_worker(void *arg) {
     devjob *w = arg; w->rc = CGX_OK;
-    if (w->tid > 0) pin_to_device_node(w->ctx);               /* thread 0 may be the caller's own thread: left alone */ w->wait_ms = w->write_ms = 0;
+    w->wait_ms = w->write_ms = 0;
+    if (w->tid > 0) pin_to_device_node(w->ctx);               /* thread 0 may be the caller's own thread: left alone */
     for (int k = 0; k < PIN_RING; k++) { if (!g_pin[w->tid][k]) g_pin[w->tid][k] = cgx_pinned_alloc(PIN_BYTES); if (!g_pin[w->tid][k]) { w->rc = CGX_ERR_NOMEM; return NULL; } }
     const uint64_t total = w->qtext[w->nq];
     int64_t ring[PIN_RING]; int head = 0, count = 0, more = 1;
