@@ -176,7 +176,7 @@ def main():
     for _ in range(args.warmup):
         step()
     ex.flush()
-    kernel_ms = []; stage = {k: 0.0 for k in ("sa_lookup", "gappy", "extract", "lexicon", "format", "fmt_lists", "fmt_count", "fmt_alloc", "fmt_write", "look1_kernel", "look2_kernel")}; hoststage = {k: 0.0 for k in ("blocks", "lists", "lexicon", "write", "write_wait_d2h", "write_file", "total", "t_upload_sa", "t_fetch_lm", "t_blocks", "t_qblocks", "t_gappy", "t_extract", "t_lexicon", "t_format", "t_offsets", "t_flush_wait")}
+    kernel_ms = []; stage = {k: 0.0 for k in ("sa_lookup", "blocks", "gappy", "extract", "lexicon", "format", "fmt_lists", "fmt_count", "fmt_alloc", "fmt_write", "look1_kernel", "look2_kernel")}; hoststage = {k: 0.0 for k in ("lists", "lexicon", "write", "write_wait_d2h", "write_file", "total", "t_upload_sa", "t_fetch_lm", "t_blocks", "t_qblocks", "t_gappy", "t_extract", "t_lexicon", "t_format", "t_offsets", "t_flush_wait")}
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

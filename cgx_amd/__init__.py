@@ -41,6 +41,7 @@ FETCH_DTYPES = {
     "s1": GAPSEARCH, "hits1": HIT1, "g2": TWOGAPPY, "c2": np.int32, "pid2": np.uint32, "s2": TWOGAPSEARCH, "hits2": HIT2,
     "r0": RULE0, "r1": RULE1, "r2": RULE2, "counts": np.uint32, "p1d": GAPPAT, "c2d": np.int32, "one2": np.uint32,
     "lex0": LEXENT, "lex1": LEXENT, "lex2": LEXENT, "rng0": np.int32, "rng1": np.int32, "rng2": np.int32,
+    "blocks": BLOCK, "qb_off": np.uint32, "qb_ids": np.uint32,
 }
 COUNT_NAMES = ["e1", "d1", "h1", "e2", "d2", "h2", "g", "n0", "n1", "n2", "sep1", "sep2a", "sep2b", "nphits", "guard_exits", "last"]
 
@@ -48,7 +49,7 @@ COUNT_NAMES = ["e1", "d1", "h1", "e2", "d2", "h2", "g", "n0", "n1", "n2", "sep1"
 ABI = [
     "cgx_create", "cgx_destroy", "cgx_last_error", "cgx_set_option", "cgx_upload_index", "cgx_build_sa", "cgx_precompute",
     "cgx_index_shape", "cgx_index_alloc", "cgx_index_nbuffers", "cgx_index_buffer", "cgx_index_d2d", "cgx_index_finalize", "cgx_broadcast_index",
-    "cgx_upload_queries", "cgx_sa_lookup", "cgx_gappy_search", "cgx_set_blocks", "cgx_extract", "cgx_lexicon", "cgx_lex_features", "cgx_fetch",
+    "cgx_upload_queries", "cgx_sa_lookup", "cgx_gappy_search", "cgx_make_blocks", "cgx_set_blocks", "cgx_extract", "cgx_lexicon", "cgx_lex_features", "cgx_fetch",
     "cgx_stage_ms", "cgx_corpus_load", "cgx_corpus_free", "cgx_corpus_upload", "cgx_extract_grammars", "cgx_extract_grammars_ids",
     "cgx_corpus_from_ids", "cgx_host_ms", "cgx_flush", "cgx_fetch_pinned", "cgx_pinned_next_batch", "cgx_upload_vocab", "cgx_upload_score_tables", "cgx_set_query_blocks",
     "cgx_format", "cgx_text_offsets", "cgx_text_read", "cgx_text_read_begin", "cgx_text_read_wait", "cgx_pinned_alloc", "cgx_pinned_free",
@@ -81,7 +82,7 @@ def load_library():
     lib.cgx_last_error.restype = C.c_char_p; lib.cgx_last_error.argtypes = [C.c_void_p]
     lib.cgx_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
     lib.cgx_upload_index.argtypes = [C.c_void_p, C.POINTER(IndexHost)]
-    for f in ("cgx_flush", "cgx_build_sa", "cgx_precompute", "cgx_sa_lookup", "cgx_gappy_search", "cgx_extract", "cgx_lexicon", "cgx_index_finalize", "cgx_index_nbuffers"):
+    for f in ("cgx_flush", "cgx_build_sa", "cgx_precompute", "cgx_sa_lookup", "cgx_make_blocks", "cgx_gappy_search", "cgx_extract", "cgx_lexicon", "cgx_index_finalize", "cgx_index_nbuffers"):
         getattr(lib, f).argtypes = [C.c_void_p]
     lib.cgx_index_alloc.argtypes = [C.c_void_p, C.c_void_p]
     lib.cgx_index_shape.argtypes = [C.c_void_p, C.c_void_p]
@@ -229,6 +230,9 @@ class Extractor:
 
     def gappy_search(self):
         self._chk(self.lib.cgx_gappy_search(self.h), "cgx_gappy_search")
+
+    def make_blocks(self):
+        self._chk(self.lib.cgx_make_blocks(self.h), "cgx_make_blocks")
 
     def set_blocks(self, blocks):
         blocks = _c(blocks, BLOCK)

@@ -65,6 +65,7 @@ struct cgx_ctx {
     // ---- device text formatter ----
     char *d_spool = nullptr, *d_tpool = nullptr; uint32_t *d_soff = nullptr, *d_toff = nullptr; uint32_t vocab_ns = 0, vocab_nt = 0;
     float *d_aa = nullptr, *d_bb = nullptr, *d_fs = nullptr;
+    uint32_t nqb = 0;                                         // entries of d_qb_ids
     uint32_t *d_qb_off = nullptr, *d_qb_ids = nullptr, *d_qo_off = nullptr, *d_qo_ids = nullptr, *d_qt_off = nullptr, *d_qt_ids = nullptr;
     char *d_text[2] = {nullptr, nullptr}; size_t text_cap[2] = {0, 0}; uint64_t text_bytes[2] = {0, 0}; uint64_t *d_qtext[2] = {nullptr, nullptr}; int32_t text_nq[2] = {0, 0}; int text_sel = 0;
     hipStream_t copy_streams[CGX_COPY_STREAMS] = {nullptr};   // few, so that they do not share a hardware queue with `stream`

@@ -1774,6 +1774,117 @@ extern "C" int cgx_set_blocks(cgx_ctx *ctx, cgx_block *blocks, uint32_t g) {
     return CGX_OK;
 }
 
+// ------------------------------------------------------------------------------------
+// GenerateBlocks (ExtractPair.cu:2740-2830 / Start.cu:585): the distinct contiguous phrases of the
+// batch = distinct (SA interval start, length) over every query token t and length ct <= lm[t],
+// numbered in first-seen order of the scan (query, token, length), plus per query the list of
+// its distinct phrases in first-seen order.  The host version walked 1.2 M items through a hash
+// map (40 ms per 10 k queries); here it is four small radix sorts:
+//   (key, ordinal) sorted by key      -> groups, first ordinal of each group
+//   groups sorted by first ordinal    -> block id = rank
+//   (query, block, ordinal) sorted    -> first ordinal of each (query, block)
+//   those sorted by ordinal           -> per-query lists in first-seen order
+// ------------------------------------------------------------------------------------
+#define BLK_INVALID (1ull << 36)
+__global__ void k_blk_keys(const int32_t *lm, const int32_t *up, uint32_t m, uint64_t *key, uint32_t *ord) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const uint32_t t = i / 5, ct = i % 5 + 1;
+    key[i] = (int32_t)ct <= lm[t] ? (((uint64_t)(uint32_t)up[i] << 3) | ct) : BLK_INVALID;
+    ord[i] = i;
+}
+__global__ void k_blk_heads(const uint64_t *skey, uint32_t m, uint32_t *flags) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) flags[i] = (skey[i] != BLK_INVALID && (i == 0 || skey[i] != skey[i - 1])) ? 1u : 0u;
+}
+__global__ void k_blk_headord(const uint32_t *flags, const uint32_t *incl, const uint32_t *sord, uint32_t m, uint32_t *ho, uint32_t *giota) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m && flags[i]) { ho[incl[i] - 1] = sord[i]; giota[incl[i] - 1] = incl[i] - 1; }
+}
+__global__ void k_blk_make(const uint32_t *ho_sorted, const uint32_t *g_sorted, uint32_t g, const int32_t *up, const int32_t *down, const int32_t *sa, cgx_block *blocks, uint32_t *rank_of_group) {
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= g) return;
+    const uint32_t o = ho_sorted[r];
+    cgx_block b; b.start = up[o]; b.end = down[o]; b.matchlen = (int32_t)(o % 5 + 1); b.string_start = sa[b.start];
+    blocks[r] = b; rank_of_group[g_sorted[r]] = r;
+}
+__global__ void k_blk_qkeys(const uint64_t *skey, const uint32_t *sord, const uint32_t *incl, const uint32_t *rank_of_group, const int32_t *tok2q, uint32_t m, uint64_t *qkey, uint32_t *qord) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    if (skey[i] == BLK_INVALID) { qkey[i] = ~0ull; qord[i] = 0; return; }
+    const uint32_t o = sord[i];
+    qkey[i] = ((uint64_t)(uint32_t)tok2q[o / 5] << 32) | rank_of_group[incl[i] - 1];
+    qord[i] = o;
+}
+__global__ void k_blk_qheads(const uint64_t *sqkey, uint32_t m, uint32_t *flags) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) flags[i] = (sqkey[i] != ~0ull && (i == 0 || sqkey[i] != sqkey[i - 1])) ? 1u : 0u;
+}
+__global__ void k_blk_qcompact(const uint64_t *sqkey, const uint32_t *sqord, const uint32_t *flags, const uint32_t *incl, uint32_t m, uint32_t *ord_out, uint32_t *id_out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m && flags[i]) { ord_out[incl[i] - 1] = sqord[i]; id_out[incl[i] - 1] = (uint32_t)sqkey[i]; }
+}
+__global__ void k_blk_qof(const uint32_t *ord_sorted, uint32_t n, const int32_t *tok2q, uint32_t *q_out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) q_out[i] = (uint32_t)tok2q[ord_sorted[i] / 5];
+}
+__global__ void k_csr_offsets(const uint32_t *q_sorted, uint32_t n, int32_t nq, uint32_t *off) {   // off[q] = first index with q_sorted >= q, q = 0..nq
+    int32_t q = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (q > nq) return;
+    uint32_t a = 0, z = n;
+    while (a < z) { uint32_t mid = (a + z) >> 1; if (q_sorted[mid] < (uint32_t)q) a = mid + 1; else z = mid; }
+    off[q] = a;
+}
+extern "C" int cgx_make_blocks(cgx_ctx *ctx) {
+    if (!ctx || !ctx->d_lm || !ctx->have_sa) return CGX_ERR_STATE;
+    HIPCHK(hipSetDevice(ctx->device));
+    Timer tm(ctx->stream);
+    hipStream_t st = ctx->stream; const int32_t nq = ctx->nq; const uint32_t T = (uint32_t)ctx->ntok;
+    dfree(ctx->d_blocks); dfree(ctx->d_qb_off); dfree(ctx->d_qb_ids); ctx->g = 0;
+    TRY(dalloc(ctx, &ctx->d_qb_off, (size_t)nq + 2));
+    HIPCHK(hipMemsetAsync(ctx->d_qb_off, 0, ((size_t)nq + 2) * 4, st));
+    if ((uint64_t)T * 5 > 0x7FFFFFF0ull) { snprintf(ctx->err, sizeof ctx->err, "too many query tokens for one batch"); return CGX_ERR_NOMEM; }
+    const uint32_t M = T * 5;
+    if (M == 0) { TRY(dalloc(ctx, &ctx->d_blocks, 1)); TRY(dalloc(ctx, &ctx->d_qb_ids, 1)); ctx->ms["blocks"] = tm.stop(); return CGX_OK; }
+    uint64_t *key = nullptr, *skey = nullptr; uint32_t *ord = nullptr, *sord = nullptr, *flags = nullptr, *incl = nullptr;
+    TRY(dalloc(ctx, &key, M)); TRY(dalloc(ctx, &skey, M)); TRY(dalloc(ctx, &ord, M)); TRY(dalloc(ctx, &sord, M)); TRY(dalloc(ctx, &flags, M)); TRY(dalloc(ctx, &incl, M));
+    k_blk_keys<<<nblocks(M, 256), 256, 0, st>>>(ctx->d_lm, ctx->d_up, M, key, ord);
+    TRY(sort_pairs(ctx, key, skey, ord, sord, M, 0, 37));                              // stable: ordinals ascend inside a group
+    k_blk_heads<<<nblocks(M, 256), 256, 0, st>>>(skey, M, flags);
+    TRY(incl_scan(ctx, flags, incl, M));
+    uint32_t G = 0; TRY(d2h(ctx, &G, incl + (M - 1), 1));
+    TRY(dalloc(ctx, &ctx->d_blocks, (size_t)G + 1));
+    uint32_t nlist = 0;
+    if (G) {
+        uint32_t *ho = nullptr, *gi = nullptr, *hos = nullptr, *gis = nullptr, *rank = nullptr;
+        TRY(dalloc(ctx, &ho, G)); TRY(dalloc(ctx, &gi, G)); TRY(dalloc(ctx, &hos, G)); TRY(dalloc(ctx, &gis, G)); TRY(dalloc(ctx, &rank, G));
+        k_blk_headord<<<nblocks(M, 256), 256, 0, st>>>(flags, incl, sord, M, ho, gi);
+        TRY(sort_pairs(ctx, ho, hos, gi, gis, G, 0, (unsigned)bits_for(M)));
+        k_blk_make<<<nblocks(G, 256), 256, 0, st>>>(hos, gis, G, ctx->d_up, ctx->d_down, ctx->d_sa, ctx->d_blocks, rank);
+        // per-query lists
+        uint64_t *qkey = nullptr, *sqkey = nullptr; uint32_t *qord = nullptr, *sqord = nullptr;
+        TRY(dalloc(ctx, &qkey, M)); TRY(dalloc(ctx, &sqkey, M)); TRY(dalloc(ctx, &qord, M)); TRY(dalloc(ctx, &sqord, M));
+        k_blk_qkeys<<<nblocks(M, 256), 256, 0, st>>>(skey, sord, incl, rank, ctx->d_tok2q, M, qkey, qord);
+        TRY(sort_pairs(ctx, qkey, sqkey, qord, sqord, M, 0, 64));
+        k_blk_qheads<<<nblocks(M, 256), 256, 0, st>>>(sqkey, M, flags);
+        TRY(incl_scan(ctx, flags, incl, M));
+        TRY(d2h(ctx, &nlist, incl + (M - 1), 1));
+        uint32_t *lo = nullptr, *lid = nullptr, *los = nullptr, *lq = nullptr;
+        TRY(dalloc(ctx, &lo, (size_t)nlist + 1)); TRY(dalloc(ctx, &lid, (size_t)nlist + 1)); TRY(dalloc(ctx, &los, (size_t)nlist + 1)); TRY(dalloc(ctx, &lq, (size_t)nlist + 1));
+        TRY(dalloc(ctx, &ctx->d_qb_ids, (size_t)nlist + 1));
+        k_blk_qcompact<<<nblocks(M, 256), 256, 0, st>>>(sqkey, sqord, flags, incl, M, lo, lid);
+        TRY(sort_pairs(ctx, lo, los, lid, ctx->d_qb_ids, nlist, 0, (unsigned)bits_for(M)));
+        k_blk_qof<<<nblocks(nlist, 256), 256, 0, st>>>(los, nlist, ctx->d_tok2q, lq);
+        k_csr_offsets<<<nblocks((size_t)nq + 1, 256), 256, 0, st>>>(lq, nlist, nq, ctx->d_qb_off);
+        HIPCHK(stream_wait(ctx)); HIPCHK(hipGetLastError());
+        dfree(ho); dfree(gi); dfree(hos); dfree(gis); dfree(rank); dfree(qkey); dfree(sqkey); dfree(qord); dfree(sqord); dfree(lo); dfree(lid); dfree(los); dfree(lq);
+    } else { TRY(dalloc(ctx, &ctx->d_qb_ids, 1)); }
+    dfree(key); dfree(skey); dfree(ord); dfree(sord); dfree(flags); dfree(incl);
+    ctx->g = G; ctx->nqb = nlist;
+    ctx->ms["blocks"] = tm.stop();
+    return CGX_OK;
+}
+
 // one launch family: scan the per-unit sample counts, run the kernel in chunks, sort the keys
 struct keyset { uint64_t *hi = nullptr, *lo = nullptr; unsigned int *count = nullptr; size_t cap = 0; uint32_t n = 0; };
 static int keyset_alloc(cgx_ctx *ctx, keyset &k, size_t cap) {
@@ -2135,6 +2246,7 @@ extern "C" int64_t cgx_fetch(cgx_ctx *ctx, const char *name, void *dst, int64_t 
     ENT("rng2", ctx->d_rng2, ctx->d_rng2 ? 2 * ((size_t)ctx->g + 2 * (size_t)ctx->d1 + ctx->d2) : 0, int32_t)
     ENT("lex0", ctx->d_lex0, ctx->nl0, cgx_lexent) ENT("lex1", ctx->d_lex1, ctx->nl1, cgx_lexent) ENT("lex2", ctx->d_lex2, ctx->nl2, cgx_lexent)
     ENT("r0", ctx->d_r0, ctx->n0, cgx_rule0) ENT("r1", ctx->d_r1, ctx->n1, cgx_rule1) ENT("r2", ctx->d_r2, ctx->n2, cgx_rule2)
+    ENT("blocks", ctx->d_blocks, ctx->g, cgx_block) ENT("qb_off", ctx->d_qb_off, ctx->d_qb_off ? (size_t)ctx->nq + 1 : 0, uint32_t) ENT("qb_ids", ctx->d_qb_ids, ctx->nqb, uint32_t)
 #undef ENT
     if (s == "counts") { bytes = sizeof counts; if (!dst) return bytes; if (cap < bytes) return CGX_ERR_ARG; memcpy(dst, counts, sizeof counts); return bytes; }
     if (bytes < 0) { snprintf(ctx->err, sizeof ctx->err, "unknown result %s", name); return CGX_ERR_ARG; }

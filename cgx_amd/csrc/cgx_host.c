@@ -367,43 +367,20 @@ static int fetch_alloc(cgx_ctx *ctx, const char *name, void **out, size_t elem, 
     return CGX_OK;
 }
 
-/* GenerateBlocks: distinct (SA interval, length) in first-seen order; per-query lists without repeats */
-typedef struct { uint64_t *key; uint32_t *val; size_t cap, n; } u64map;
-static int u64map_get_or_add(u64map *m, uint64_t k, uint32_t newid, uint32_t *id, int *added) {
-    if ((m->n + 1) * 2 > m->cap) {
-        size_t oc = m->cap; uint64_t *ok = m->key; uint32_t *ov = m->val;
-        m->cap = oc ? oc * 2 : 4096; m->key = malloc(m->cap * 8); m->val = malloc(m->cap * 4);
-        if (!m->key || !m->val) return -1;
-        memset(m->key, 0xFF, m->cap * 8);
-        for (size_t j = 0; j < oc; j++) if (ok[j] != UINT64_MAX) { size_t i = (size_t)(ok[j] * 0x9E3779B97F4A7C15ull >> 17) & (m->cap - 1); while (m->key[i] != UINT64_MAX) i = (i + 1) & (m->cap - 1); m->key[i] = ok[j]; m->val[i] = ov[j]; }
-        free(ok); free(ov);
-    }
-    size_t i = (size_t)(k * 0x9E3779B97F4A7C15ull >> 17) & (m->cap - 1);
-    while (m->key[i] != UINT64_MAX) { if (m->key[i] == k) { *id = m->val[i]; *added = 0; return 0; } i = (i + 1) & (m->cap - 1); }
-    m->key[i] = k; m->val[i] = newid; m->n++; *id = newid; *added = 1;
-    return 0;
-}
-static int make_blocks(cgx_ctx *ctx, batch *b) {
-    uint32_t cap = 0, g = 0; u64map m; memset(&m, 0, sizeof m);
-    int32_t *lastq = NULL; size_t lqcap = 0;
-    int32_t *sa_first = NULL;       /* string_start = sa[up]: fetched in one gather below */
-    b->qblocks = calloc((size_t)b->nq + 1, sizeof *b->qblocks);
-    if (!b->qblocks) return CGX_ERR_NOMEM;
-    for (int32_t q = 0; q < b->nq; q++) for (int32_t j = b->qoff[q]; j < b->qoff[q + 1]; j++)
-        for (int ct = 1; ct <= b->lm[j] && ct <= LONGEST_SRC; ct++) {
-            int32_t up = b->up[(size_t)j * 5 + ct - 1], down = b->down[(size_t)j * 5 + ct - 1];
-            uint32_t id; int added;
-            if (u64map_get_or_add(&m, ((uint64_t)(uint32_t)up << 3) | (uint64_t)ct, g, &id, &added)) return CGX_ERR_NOMEM;
-            if (added) {
-                if (g == cap) { cap = cap ? cap * 2 : 1024; b->blocks = realloc(b->blocks, (size_t)cap * sizeof *b->blocks); if (!b->blocks) return CGX_ERR_NOMEM; }
-                b->blocks[g].start = up; b->blocks[g].end = down; b->blocks[g].matchlen = ct; b->blocks[g].string_start = -1; g++;
-            }
-            if ((size_t)g > lqcap) { size_t nc = lqcap ? lqcap * 2 : 1024; while (nc < g) nc *= 2; lastq = realloc(lastq, nc * 4); if (!lastq) return CGX_ERR_NOMEM; memset(lastq + lqcap, 0xFF, (nc - lqcap) * 4); lqcap = nc; }
-            if (lastq[id] != q) { lastq[id] = q; if (idlist_push(&b->qblocks[q], id)) return CGX_ERR_NOMEM; }
-        }
-    free(m.key); free(m.val); free(lastq); (void)sa_first;
+/* the blocks and per-query block lists made by cgx_make_blocks, for the host formatter / host lexicon */
+static int fetch_host_blocks(cgx_ctx *ctx, batch *b) {
+    int rc; uint32_t g = 0, noff = 0, nids = 0; uint32_t *off = NULL, *ids = NULL;
+    free(b->blocks); b->blocks = NULL;
+    if ((rc = fetch_alloc(ctx, "blocks", (void **)&b->blocks, sizeof *b->blocks, &g)) != CGX_OK) return rc;
     b->g = g;
-    return CGX_OK;
+    if ((rc = fetch_alloc(ctx, "qb_off", (void **)&off, 4, &noff)) != CGX_OK) return rc;
+    if ((rc = fetch_alloc(ctx, "qb_ids", (void **)&ids, 4, &nids)) != CGX_OK) { free(off); return rc; }
+    b->qblocks = calloc((size_t)b->nq + 1, sizeof *b->qblocks);
+    if (!b->qblocks || noff < (uint32_t)b->nq + 1) { free(off); free(ids); return CGX_ERR_NOMEM; }
+    for (int32_t q = 0; q < b->nq && rc == CGX_OK; q++)
+        for (uint32_t k = off[q]; k < off[q + 1] && k < nids; k++) if (idlist_push(&b->qblocks[q], ids[k])) { rc = CGX_ERR_NOMEM; break; }
+    free(off); free(ids);
+    return rc;
 }
 
 /* per-query lists of distinct pattern ids, ascending (checkDup loops, SuffixArray.cu:1707-1718, 2085-2096) */
@@ -927,27 +904,16 @@ static int run_batch(cgx_ctx *ctx, const cgx_corpus *c, batch *b, const char *ou
     if ((rc = cgx_upload_queries(ctx, b->qoff, b->nq, b->qtok, b->ntok)) != CGX_OK) return rc;
     if ((rc = cgx_sa_lookup(ctx)) != CGX_OK) return rc;
     LAP("upload_sa");
-    if ((rc = fetch_alloc(ctx, "lm", (void **)&b->lm, 4, NULL)) || (rc = fetch_alloc(ctx, "up", (void **)&b->up, 4, NULL)) || (rc = fetch_alloc(ctx, "down", (void **)&b->down, 4, NULL))) return rc;
-    LAP("fetch_lm");
-    t = now_ms();
-    if ((rc = make_blocks(ctx, b)) != CGX_OK) return rc;
-    cgx__set_host_ms(ctx, "blocks", now_ms() - t);
-    if ((rc = cgx_set_blocks(ctx, b->blocks, b->g)) != CGX_OK) return rc;   /* also fills string_start = sa[start] (ExtractPair.cu:2798) */
+    /* GenerateBlocks on the device: distinct contiguous phrases + per-query lists (kept there for the formatter) */
+    if ((rc = cgx_make_blocks(ctx)) != CGX_OK) return rc;
+    {
+        uint32_t counts0[16];
+        if (cgx_fetch(ctx, "counts", counts0, sizeof counts0) < 0) return CGX_ERR_HIP;
+        b->g = counts0[6];
+    }
     LAP("blocks");
     const int devfmt = outdir && cgx__option(ctx, "device_format");
-    if (devfmt) {                                             /* per-query block lists as CSR for the device formatter */
-        uint32_t *off = malloc(((size_t)b->nq + 1) * 4); size_t tot = 0;
-        if (!off) return CGX_ERR_NOMEM;
-        for (int32_t q = 0; q < b->nq; q++) { off[q] = (uint32_t)tot; tot += b->qblocks[q].n; }
-        off[b->nq] = (uint32_t)tot;
-        uint32_t *ids = malloc((tot + 1) * 4);
-        if (!ids) { free(off); return CGX_ERR_NOMEM; }
-        for (int32_t q = 0; q < b->nq; q++) if (b->qblocks[q].n) memcpy(ids + off[q], b->qblocks[q].v, (size_t)b->qblocks[q].n * 4);
-        rc = cgx_set_query_blocks(ctx, off, ids);
-        free(off); free(ids);
-        if (rc == CGX_OK) rc = ensure_vocab(ctx, c);
-        if (rc != CGX_OK) return rc;
-    }
+    if (devfmt && (rc = ensure_vocab(ctx, c)) != CGX_OK) return rc;
     LAP("qblocks");
     if ((rc = cgx_gappy_search(ctx)) != CGX_OK) return rc;
     LAP("gappy");
@@ -993,6 +959,7 @@ static int run_batch(cgx_ctx *ctx, const cgx_corpus *c, batch *b, const char *ou
         if (rc != CGX_ERR_STATE) return rc;                   /* CGX_ERR_STATE: a line the device cannot represent -> host formatter below */
     }
     /* device results needed by the host stages */
+    if ((rc = fetch_host_blocks(ctx, b)) != CGX_OK) return rc;
     uint32_t *pid1 = NULL, *pid2 = NULL; cgx_gappy *g1 = NULL; cgx_twogappy *g2 = NULL; uint32_t counts[16];
     if (cgx_fetch(ctx, "counts", counts, sizeof counts) < 0) return CGX_ERR_HIP;
     b->d1 = counts[1]; b->d2 = counts[4]; b->sep1 = counts[10]; b->sep2a = counts[11]; b->sep2b = counts[12];

@@ -95,7 +95,8 @@ int cgx_broadcast_index(cgx_ctx *ctx, void *nccl_comm, int root, int rank);
 int cgx_upload_queries(cgx_ctx *ctx, const int32_t *qoff, int32_t nq, const int32_t *qtok, int32_t ntok); /* constructQryIndex output (Start.cu:50-132) */
 int cgx_sa_lookup(cgx_ctx *ctx);        /* K1 + K2: SuffixArray.cu:402-767, 109-400 */
 int cgx_gappy_search(cgx_ctx *ctx);     /* enumeration, sorts, lookups: SuffixArray.cu:1530-2256, GappyLook.cu:128-737 */
-int cgx_set_blocks(cgx_ctx *ctx, cgx_block *blocks, uint32_t g);   /* distinct contiguous phrases (GenerateBlocks, ExtractPair.cu:2742-2903); fills blocks[i].string_start = sa[start] */
+int cgx_make_blocks(cgx_ctx *ctx);      /* GenerateBlocks (ExtractPair.cu:2742-2903) on the device, after cgx_sa_lookup: distinct contiguous phrases in first-seen order ("blocks") and the per-query lists ("qb_off", "qb_ids") */
+int cgx_set_blocks(cgx_ctx *ctx, cgx_block *blocks, uint32_t g);   /* the same, with a block list made by the caller's own GenerateBlocks; fills blocks[i].string_start = sa[start] */
 int cgx_extract(cgx_ctx *ctx);          /* three extraction launches + sorts: ExtractPair.cu:3336-3670 */
 int cgx_lexicon(cgx_ctx *ctx);          /* device lexicon + MaxLex: createLexicon*Fast (ExtractPair.c:515-1276) + lexicalTaskMaxEF; results "lex1" "lex2" "lex0" */
 int cgx_lex_features(cgx_ctx *ctx, const cgx_lextask *tasks, uint32_t ntask, uint32_t n_onegap, uint32_t n_twogap,

@@ -82,6 +82,23 @@ def test_every_stage_matches_the_oracle(name, cgx, oracle_bin, fixtures_dir, tmp
     lm5 = np.minimum(d["lm"], 5)
     assert np.array_equal(ex.fetch("lm"), lm5)
     assert np.array_equal(ex.fetch("up"), d["up"]) and np.array_equal(ex.fetch("down"), d["down"])
+    # GenerateBlocks on the device: same blocks in the same (first-seen) order, and per-query lists that equal a
+    # plain restatement of the host loop (distinct ids per query, in the order the scan meets them)
+    ex.make_blocks()
+    got = ex.fetch("blocks")
+    for f in ("start", "end", "matchlen", "string_start"):
+        assert np.array_equal(got[f], d["blocks"][f]), f
+    ids = {(int(b["start"]), int(b["matchlen"])): i for i, b in enumerate(d["blocks"])}
+    up5 = d["up"].reshape(-1, 5); qoff = d["qoff"]; want_off = [0]; want_ids = []
+    for q in range(len(qoff) - 1):
+        seen = []
+        for t in range(qoff[q], qoff[q + 1]):
+            for ct in range(1, int(lm5[t]) + 1):
+                i = ids[(int(up5[t, ct - 1]), ct)]
+                if i not in seen:
+                    seen.append(i)
+        want_ids += seen; want_off.append(len(want_ids))
+    assert np.array_equal(ex.fetch("qb_off"), np.array(want_off, np.uint32)) and np.array_equal(ex.fetch("qb_ids"), np.array(want_ids, np.uint32))
     blocks = ex.set_blocks(d["blocks"])
     assert np.array_equal(blocks["string_start"], d["blocks"]["string_start"])
     ex.gappy_search()
