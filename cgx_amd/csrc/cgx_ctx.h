@@ -39,6 +39,7 @@ struct cgx_ctx {
     bool use_bigrams = true;
     bool numa_pin = true;               // writer threads run on the CPUs of the GPU's NUMA node
     bool use_lex_hash = true;           // MaxLex pair lookups through the pair hash (0: binary search in the source word's row)
+    int64_t auto_batch_tokens = 300000; // with sub_batch == 0: query tokens per internal batch (bounds device memory per call)
     int64_t sub_batch = 0;              // queries per internal batch of cgx_extract_grammars* (0 = all at once)
     uint32_t pool_cap = 1u << 30;       // test hook: entries of the per-block append pool in use (clamped to POOL_N)
     uint32_t look_rec_cap = 65535;      // test hook: groups with more records than this read them from global memory

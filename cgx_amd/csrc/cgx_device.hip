@@ -338,6 +338,7 @@ extern "C" int cgx_set_option(cgx_ctx *c, const char *name, int64_t value) {
     if (!strcmp(name, "pool_cap")) { if (value < 1) return CGX_ERR_ARG; c->pool_cap = (uint32_t)(value > POOL_N ? POOL_N : value); return CGX_OK; }
     if (!strcmp(name, "look_rec_cap")) { if (value < 0) return CGX_ERR_ARG; c->look_rec_cap = (uint32_t)(value > 65535 ? 65535 : value); return CGX_OK; }
     if (!strcmp(name, "sub_batch")) { if (value < 0) return CGX_ERR_ARG; c->sub_batch = value; return CGX_OK; }
+    if (!strcmp(name, "auto_batch_tokens")) { if (value < 1) return CGX_ERR_ARG; c->auto_batch_tokens = value; return CGX_OK; }
     if (!strcmp(name, "append_slack")) { if (value < 0) return CGX_ERR_ARG; c->append_slack = (uint64_t)value; return CGX_OK; }
     if (!strcmp(name, "append_guess_milli")) { if (value < 0) return CGX_ERR_ARG; c->look1_per_item = c->look2_per_item = (double)value / 1000.0; return CGX_OK; }
     if (!strcmp(name, "async_write")) { c->async_write = value != 0; return CGX_OK; }
@@ -351,6 +352,7 @@ extern "C" int64_t cgx__option(cgx_ctx *c, const char *name) {
     if (!strcmp(name, "async_write")) return (int64_t)c->async_write;
     if (!strcmp(name, "device_format")) return (int64_t)c->device_format;
     if (!strcmp(name, "sub_batch")) return c->sub_batch;
+    if (!strcmp(name, "auto_batch_tokens")) return c->auto_batch_tokens;
     if (!strcmp(name, "numa_pin")) return (int64_t)c->numa_pin;
     return 0;
 }

@@ -1087,15 +1087,21 @@ static int extract_ids_once(cgx_ctx *ctx, const cgx_corpus *c, const int32_t *qo
 int cgx_extract_grammars_ids(cgx_ctx *ctx, const cgx_corpus *c, const int32_t *qoff, int32_t nq, const int32_t *qtok, int32_t ntok,
                              const char *outdir, int32_t first, uint64_t *nrules) {
     if (!ctx || !c || nq < 0 || ntok < 0 || (nq && !qoff) || (ntok && !qtok) || (ntok && !nq)) return CGX_ERR_ARG;
-    const int64_t sub = cgx__option(ctx, "sub_batch");
-    if (sub <= 0 || sub >= nq) return extract_ids_once(ctx, c, qoff, nq, qtok, ntok, outdir, first, nrules);
+    /* Internal batches: `sub_batch` queries each if set; otherwise as many queries as fit AUTO_BATCH_TOKENS query
+     * tokens (option "auto_batch_tokens", default 300 000 = about 12 k sentences), which bounds the device memory of a call whatever the size of the query file
+     * (the text of 10 k queries alone is 30-40 GB, kept twice).  Queries are independent: any split gives the same files. */
+    const int64_t sub = cgx__option(ctx, "sub_batch"), AUTO_BATCH_TOKENS = cgx__option(ctx, "auto_batch_tokens");
+    if ((sub <= 0 || sub >= nq) && ntok <= AUTO_BATCH_TOKENS) return extract_ids_once(ctx, c, qoff, nq, qtok, ntok, outdir, first, nrules);
     uint64_t total = 0;
-    for (int32_t q0 = 0; q0 < nq; q0 += (int32_t)sub) {      /* queries are independent: any split gives the same files */
-        int32_t q1 = q0 + (int32_t)sub < nq ? q0 + (int32_t)sub : nq; uint64_t n = 0;
+    for (int32_t q0 = 0; q0 < nq;) {
+        int32_t q1 = q0;
+        if (sub > 0) q1 = q0 + (int32_t)sub < nq ? q0 + (int32_t)sub : nq;
+        else { while (q1 < nq && ((q1 + 1 < nq ? qoff[q1 + 1] : ntok) - qoff[q0] <= AUTO_BATCH_TOKENS || q1 == q0)) q1++; }
+        uint64_t n = 0;
         int32_t t1 = q1 < nq ? qoff[q1] : ntok;
         int rc = extract_ids_once(ctx, c, qoff + q0, q1 - q0, qtok, t1 - qoff[q0], outdir, first + q0, &n);
         if (rc != CGX_OK) return rc;
-        total += n;
+        total += n; q0 = q1;
     }
     if (nrules) *nrules = total;
     return CGX_OK;
