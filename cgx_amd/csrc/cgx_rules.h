@@ -67,6 +67,28 @@ CGX_HD int cgx_sentence(const cgx_view &v, int k, uint32_t w, int *src0) {
 // target words inside the span are ignored (ExtractPair.cu:103-133).
 CGX_HD bool cgx_tight(const cgx_view &v, int ts, int te, int s_chk, int e_chk, int src0) {
     int lo = 255, hi = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // Every caller has already rejected target spans of 15 words or more, so [ts,te] fits 16 bytes: on the device
+    // both byte tables are read with five aligned dword loads each (they are padded) instead of a byte load per
+    // word -- the extraction kernels were bound by the number of L1 requests, most of them issued here.
+    if (te - ts < 16) {
+        const uint32_t *pl = (const uint32_t *)(v.ltar + (ts & ~3)), *pr = (const uint32_t *)(v.rtar + (ts & ~3));
+        uint32_t a[5], b[5];
+        CGX_UNROLL
+        for (int i = 0; i < 5; i++) { a[i] = pl[i]; b[i] = pr[i]; }
+        const unsigned sh = (unsigned)ts & 3u; const int last = te - ts;
+        CGX_UNROLL
+        for (int i = 0; i < 4; i++) {
+            const uint32_t l4 = __builtin_amdgcn_alignbyte(a[i + 1], a[i], sh), r4 = __builtin_amdgcn_alignbyte(b[i + 1], b[i], sh);
+            CGX_UNROLL
+            for (int k = 0; k < 4; k++) {
+                const int L = (int)((l4 >> (8 * k)) & 0xFF), R = (int)((r4 >> (8 * k)) & 0xFF);
+                if (4 * i + k <= last && L != 255 && R != 255) { if (lo > L) lo = L; if (hi < R) hi = R; }
+            }
+        }
+        return src0 + lo == s_chk && src0 + hi == e_chk;
+    }
+#endif
     for (int k = ts; k <= te; k++) {
         int L = v.ltar[k], R = v.rtar[k];
         if (L == 255 || R == 255) continue;
