@@ -195,6 +195,7 @@ def main():
     total_rules = shard.sum_over_ranks(rules, dist if world > 1 else None)
 
     out_bytes = sum(e.stat().st_size for e in os.scandir(outdir)) if outdir else 0
+    free_b, total_b = torch.cuda.mem_get_info()                # after the timed steps: index + cached batch buffers + both text slots
 
     if rank == 0:
         lm = ex.fetch("lm"); c = ex.counts()
@@ -238,6 +239,7 @@ def main():
             "stages_ms_per_step": {k: round(v / args.steps, 3) for k, v in {**stage, **{"host_" + k: v for k, v in hoststage.items()}}.items()},
             "index": {"build_sa_ms": round(ex.stage_ms("build_sa"), 1), "precompute_ms": round(ex.stage_ms("precompute"), 1),
                       "broadcast_s": round(t_bcast, 3), "total_s": round(t_index, 2), "corpus_gen_s": round(t_gen, 2), "frequent_pair_hits": c["nphits"]},
+            "hbm_in_use_gb": round((total_b - free_b) / 1e9, 1),
             "counts": {k: c[k] for k in ("d1", "d2", "h1", "h2", "g", "n0", "n1", "n2", "guard_exits")},
         }
         if not args.no_cpu_baseline and world == 1:

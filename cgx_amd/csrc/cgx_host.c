@@ -91,17 +91,44 @@ static char *slurp(const char *path, size_t *len) {
 #define GROW(arr, cnt, cap) do { if ((cnt) == (cap)) { (cap) = (cap) ? (cap) * 2 : 1024; (arr) = realloc((arr), (cap) * sizeof *(arr)); if (!(arr)) return -1; } } while (0)
 
 /* One side of the bitext.  Lines end at '\n'; words are separated by single blanks only
- * (strtok(" ")); a word that starts with other white space ends the line (Start.cu:280). */
-static int load_side(const char *path, int32_t **str_out, uint32_t *n_out, uint8_t **P_out, int32_t **sent_out, int32_t *nsent_out,
-                     char ***vocab_out, int32_t *nvocab_out, wordmap *map) {
-    size_t len; char *buf = slurp(path, &len);
-    if (!buf) return -1;
-    int32_t *str = NULL; uint8_t *P = NULL; int32_t *sent = NULL; char **voc = NULL;
-    size_t ns = 0, cs = 0, np = 0, cp = 0, nl = 0, cl = 0, nv = 0, cv = 0;
-    if (wordmap_init(map, 1 << 16)) return -1;
-    GROW(voc, nv, cv); voc[nv++] = NULL; GROW(voc, nv, cv); voc[nv++] = NULL;
-    GROW(sent, nl, cl); sent[nl++] = 0;
-    int32_t last = -1; size_t i = 0;
+ * (strtok(" ")); a word that starts with other white space ends the line (Start.cu:280).
+ * Ids are handed out in order of first appearance (2, 3, ...), exactly as a sequential reader would,
+ * but the file is tokenised by several threads: each parses a run of whole lines against a private
+ * dictionary, the private dictionaries are merged in file order (which reproduces the sequential
+ * numbering), then the threads rewrite their private ids and copy their piece into place. */
+typedef struct { const char **key; uint32_t *klen; int32_t *val; size_t cap, n; } spanmap;   /* words as (pointer, length) into the file buffer */
+static int spanmap_id(spanmap *m, const char *s, uint32_t len, int *added) {
+    if ((m->n + 1) * 2 > m->cap) {
+        size_t oc = m->cap, nc = oc ? oc * 2 : 4096;
+        const char **ok = m->key; uint32_t *ol = m->klen; int32_t *ov = m->val;
+        m->key = calloc(nc, sizeof *m->key); m->klen = malloc(nc * sizeof *m->klen); m->val = malloc(nc * sizeof *m->val);
+        if (!m->key || !m->klen || !m->val) return -1;
+        m->cap = nc;
+        for (size_t j = 0; j < oc; j++) if (ok[j]) { size_t i = hash_bytes(ok[j], ol[j]) & (nc - 1); while (m->key[i]) i = (i + 1) & (nc - 1); m->key[i] = ok[j]; m->klen[i] = ol[j]; m->val[i] = ov[j]; }
+        free(ok); free(ol); free(ov);
+    }
+    size_t i = hash_bytes(s, len) & (m->cap - 1);
+    while (m->key[i]) { if (m->klen[i] == len && !memcmp(m->key[i], s, len)) { *added = 0; return m->val[i]; } i = (i + 1) & (m->cap - 1); }
+    m->key[i] = s; m->klen[i] = len; m->val[i] = (int32_t)m->n + 2; m->n++; *added = 1;
+    return m->val[i];
+}
+typedef struct {
+    const char *buf; size_t begin, end; int want_P, rc;
+    int32_t *tok; uint8_t *P; size_t ntok, ctok;              /* private ids (>= 2), 1 closes a line */
+    int32_t *sent; size_t nsent, csent;                       /* tokens of this piece up to the end of each of its lines */
+    spanmap map; const char **wkey; uint32_t *wlen; size_t nw, cw;   /* its new words in order of first appearance */
+    int32_t *l2g;                                             /* private id -> final id (filled by the merge) */
+    int32_t *str_out; uint8_t *P_out; int32_t *sent_out; size_t tok_off, sent_off;
+} sidepiece;
+static int piece_room(sidepiece *pc) {                      /* room for one more token */
+    if (pc->ntok < pc->ctok) return 0;
+    pc->ctok = pc->ctok ? pc->ctok * 2 : 1 << 16;
+    pc->tok = realloc(pc->tok, pc->ctok * sizeof *pc->tok);
+    if (pc->want_P) pc->P = realloc(pc->P, pc->ctok);
+    return !pc->tok || (pc->want_P && !pc->P) ? -1 : 0;
+}
+static int piece_parse(sidepiece *pc) {
+    const char *buf = pc->buf; size_t i = pc->begin; const size_t len = pc->end;
     while (i < len) {
         size_t e = i; while (e < len && buf[e] != '\n') e++;
         uint8_t local = 0; size_t p = i;
@@ -110,29 +137,104 @@ static int load_side(const char *path, int32_t **str_out, uint32_t *n_out, uint8
             if (p >= e) break;
             size_t q = p; while (q < e && buf[q] != ' ') q++;
             if (isspace((unsigned char)buf[p])) break;
-            int32_t id = wordmap_get(map, buf + p, q - p);
-            if (id < 0) {
-                id = (int32_t)map->n + 2; last = id;
-                char *w = malloc(q - p + 1); if (!w) return -1; memcpy(w, buf + p, q - p); w[q - p] = 0;
-                if (wordmap_put(map, w, id)) return -1;
-                GROW(voc, nv, cv); voc[nv++] = w;
+            int added; int32_t id = spanmap_id(&pc->map, buf + p, (uint32_t)(q - p), &added);
+            if (id < 0) return -1;
+            if (added) {
+                if (pc->nw == pc->cw) {
+                    pc->cw = pc->cw ? pc->cw * 2 : 1024;
+                    pc->wkey = realloc(pc->wkey, pc->cw * sizeof *pc->wkey); pc->wlen = realloc(pc->wlen, pc->cw * sizeof *pc->wlen);
+                    if (!pc->wkey || !pc->wlen) return -1;
+                }
+                pc->wkey[pc->nw] = buf + p; pc->wlen[pc->nw] = (uint32_t)(q - p); pc->nw++;
             }
-            GROW(str, ns, cs); str[ns++] = id;
-            if (P_out) { GROW(P, np, cp); P[np++] = local; }
+            if (piece_room(pc)) return -1;
+            pc->tok[pc->ntok] = id; if (pc->want_P) pc->P[pc->ntok] = local; pc->ntok++;
             local++; p = q;
         }
-        GROW(str, ns, cs); str[ns++] = 1;
-        if (P_out) { GROW(P, np, cp); P[np++] = 0; }
-        GROW(sent, nl, cl); sent[nl++] = (int32_t)ns;
+        if (piece_room(pc)) return -1;
+        pc->tok[pc->ntok] = 1; if (pc->want_P) pc->P[pc->ntok] = 0; pc->ntok++;
+        GROW(pc->sent, pc->nsent, pc->csent); pc->sent[pc->nsent++] = (int32_t)pc->ntok;
         i = e + 1;
     }
-    free(buf);
-    GROW(str, ns, cs); str[ns++] = 1; if (P_out) { GROW(P, np, cp); P[np++] = 0; }
-    last++;
-    GROW(str, ns, cs); str[ns++] = last; if (P_out) { GROW(P, np, cp); P[np++] = 0; }
-    *str_out = str; *n_out = (uint32_t)ns; if (P_out) *P_out = P;
-    *sent_out = sent; *nsent_out = (int32_t)nl - 1; *vocab_out = voc; *nvocab_out = (int32_t)nv;
     return 0;
+}
+static void *piece_parse_job(void *arg) { sidepiece *pc = arg; pc->rc = piece_parse(pc); return NULL; }
+static void *piece_place_job(void *arg) {
+    sidepiece *pc = arg;
+    for (size_t k = 0; k < pc->ntok; k++) pc->str_out[pc->tok_off + k] = pc->tok[k] == 1 ? 1 : pc->l2g[pc->tok[k]];
+    if (pc->want_P) memcpy(pc->P_out + pc->tok_off, pc->P, pc->ntok);
+    for (size_t k = 0; k < pc->nsent; k++) pc->sent_out[pc->sent_off + k] = (int32_t)(pc->tok_off + (size_t)pc->sent[k]);
+    return NULL;
+}
+static void piece_free(sidepiece *pc) { free(pc->tok); free(pc->P); free(pc->sent); free(pc->map.key); free(pc->map.klen); free(pc->map.val); free(pc->wkey); free(pc->wlen); free(pc->l2g); }
+static int nthreads_host(void);
+#define SIDE_MAX_PIECES 32
+static int load_side(const char *path, int32_t **str_out, uint32_t *n_out, uint8_t **P_out, int32_t **sent_out, int32_t *nsent_out,
+                     char ***vocab_out, int32_t *nvocab_out, wordmap *map) {
+    double tr0 = now_ms(); const int trace = getenv("CGX_TRACE") != NULL;
+    size_t len; char *buf = slurp(path, &len);
+    if (!buf) return -1;
+    double tr1 = now_ms();
+    int np = nthreads_host() / 2; if (np > SIDE_MAX_PIECES) np = SIDE_MAX_PIECES; if (len < (4u << 20) || np < 1) np = 1;   /* two sides load at once */
+    sidepiece pc[SIDE_MAX_PIECES]; memset(pc, 0, sizeof pc);
+    size_t cut = 0;
+    for (int k = 0; k < np; k++) {                            /* pieces start at line starts */
+        pc[k].buf = buf; pc[k].want_P = P_out != NULL; pc[k].begin = cut;
+        size_t e = k + 1 == np ? len : len / (size_t)np * (size_t)(k + 1);
+        if (e < cut) e = cut;
+        while (e < len && buf[e] != '\n') e++;
+        if (e < len) e++;
+        pc[k].end = cut = e;
+    }
+    pthread_t th[SIDE_MAX_PIECES]; int started[SIDE_MAX_PIECES] = {0}; int rc = 0;
+    for (int k = 1; k < np; k++) started[k] = !pthread_create(&th[k], NULL, piece_parse_job, &pc[k]);
+    piece_parse_job(&pc[0]);
+    for (int k = 1; k < np; k++) { if (started[k]) pthread_join(th[k], NULL); else piece_parse_job(&pc[k]); }
+    for (int k = 0; k < np; k++) if (pc[k].rc) rc = -1;
+    double tr2 = now_ms();
+    /* merge the dictionaries in file order: the id of a word is 2 + the number of distinct words seen before it */
+    char **voc = NULL; size_t nv = 0, cv = 0; int32_t *str = NULL, *sent = NULL; uint8_t *P = NULL;
+    if (!rc && wordmap_init(map, 1 << 16)) rc = -1;
+    if (!rc) { GROW(voc, nv, cv); voc[nv++] = NULL; GROW(voc, nv, cv); voc[nv++] = NULL; }
+    for (int k = 0; k < np && !rc; k++) {
+        pc[k].l2g = malloc((pc[k].nw + 2) * sizeof *pc[k].l2g);
+        if (!pc[k].l2g) { rc = -1; break; }
+        for (size_t j = 0; j < pc[k].nw; j++) {
+            int32_t id = wordmap_get(map, pc[k].wkey[j], pc[k].wlen[j]);
+            if (id < 0) {
+                id = (int32_t)map->n + 2;
+                char *w = malloc((size_t)pc[k].wlen[j] + 1);
+                if (!w) { rc = -1; break; }
+                memcpy(w, pc[k].wkey[j], pc[k].wlen[j]); w[pc[k].wlen[j]] = 0;
+                if (wordmap_put(map, w, id)) { rc = -1; break; }
+                if (nv == cv) { cv = cv ? cv * 2 : 1024; voc = realloc(voc, cv * sizeof *voc); if (!voc) { rc = -1; break; } }
+                voc[nv++] = w;
+            }
+            pc[k].l2g[j + 2] = id;
+        }
+    }
+    double tr3 = now_ms();
+    size_t ns = 0, nl = 0;
+    for (int k = 0; k < np; k++) { pc[k].tok_off = ns; pc[k].sent_off = nl + 1; ns += pc[k].ntok; nl += pc[k].nsent; }
+    if (!rc) {
+        str = malloc((ns + 2) * sizeof *str); sent = malloc((nl + 1) * sizeof *sent); if (P_out) P = malloc(ns + 2);
+        if (!str || !sent || (P_out && !P)) rc = -1;
+    }
+    if (!rc) {
+        sent[0] = 0;
+        for (int k = 0; k < np; k++) { pc[k].str_out = str; pc[k].P_out = P; pc[k].sent_out = sent; }
+        for (int k = 1; k < np; k++) started[k] = !pthread_create(&th[k], NULL, piece_place_job, &pc[k]);
+        piece_place_job(&pc[0]);
+        for (int k = 1; k < np; k++) { if (started[k]) pthread_join(th[k], NULL); else piece_place_job(&pc[k]); }
+        int32_t last = map->n ? (int32_t)map->n + 1 : -1;     /* id of the newest word, then one past it (Start.cu:300-312) */
+        str[ns] = 1; str[ns + 1] = last + 1; if (P) { P[ns] = 0; P[ns + 1] = 0; }
+        *str_out = str; *n_out = (uint32_t)(ns + 2); if (P_out) *P_out = P;
+        *sent_out = sent; *nsent_out = (int32_t)nl; *vocab_out = voc; *nvocab_out = (int32_t)nv;
+    } else { free(str); free(sent); free(P); for (size_t j = 2; j < nv; j++) free(voc[j]); free(voc); }
+    if (trace) fprintf(stderr, "cgx: %s: read %.0f ms, tokenise (%d threads) %.0f ms, merge %.0f ms, place %.0f ms\n", path, tr1 - tr0, np, tr2 - tr1, tr3 - tr2, now_ms() - tr3);
+    for (int k = 0; k < np; k++) piece_free(&pc[k]);
+    free(buf);
+    return rc;
 }
 
 static int pack_alignment(cgx_corpus *c, const uint8_t *Ls, const uint8_t *Rs) {
@@ -145,18 +247,16 @@ static int pack_alignment(cgx_corpus *c, const uint8_t *Ls, const uint8_t *Rs) {
     }
     return 0;
 }
-static int load_alignment(cgx_corpus *c, const char *path, char *err, size_t errcap) {
-    size_t len; char *buf = slurp(path, &len);
-    if (!buf) { snprintf(err, errcap, "Can not open reference file \"%s\"", path); return CGX_ERR_IO; }
-    uint8_t *Ls = malloc(c->n), *Rs = malloc(c->n);
-    c->ltar = malloc((size_t)c->nt + 1); c->rtar = malloc((size_t)c->nt + 1);
-    if (!Ls || !Rs || !c->ltar || !c->rtar) return CGX_ERR_NOMEM;
-    memset(Ls, 255, c->n); memset(Rs, 255, c->n); memset(c->ltar, 255, c->nt); memset(c->rtar, 255, c->nt);
-    size_t i = 0; int q = -1; int rc = CGX_OK;
+/* Alignment lines are independent once their line number is known, and line q only touches the tokens of
+ * sentence pair q: pieces of whole lines are parsed by several threads; the error of the earliest piece wins. */
+typedef struct { cgx_corpus *c; const char *buf; size_t begin, end; int q0, rc; uint8_t *Ls, *Rs; char err[160]; } alignpiece;
+static void *align_piece_job(void *arg) {
+    alignpiece *a = arg; cgx_corpus *c = a->c; const char *buf = a->buf; uint8_t *Ls = a->Ls, *Rs = a->Rs;
+    size_t i = a->begin; const size_t len = a->end; int q = a->q0 - 1; int rc = CGX_OK;
     while (i < len && rc == CGX_OK) {
         size_t e = i; while (e < len && buf[e] != '\n') e++;
         q++;
-        if (q >= c->nsent) { snprintf(err, errcap, "alignment file has more lines than the corpus"); rc = CGX_ERR_ARG; break; }
+        if (q >= c->nsent) { snprintf(a->err, sizeof a->err, "alignment file has more lines than the corpus"); rc = CGX_ERR_ARG; break; }
         size_t p = i; int have_s = 0, s = 0;
         for (;;) {                                      /* tokens separated by blanks and '-' (ExtractPair.cu:2657) */
             while (p < e && (buf[p] == ' ' || buf[p] == '-')) p++;
@@ -168,15 +268,43 @@ static int load_alignment(cgx_corpus *c, const char *path, char *err, size_t err
             p = t;
             if (!have_s) { s = val; have_s = 1; continue; }
             have_s = 0;
-            if (s >= 255 || val >= 255 || s < 0 || val < 0) { snprintf(err, errcap, "Not possible, too long sentence"); rc = CGX_ERR_ALIGN_RANGE; break; }
+            if (s >= 255 || val >= 255 || s < 0 || val < 0) { snprintf(a->err, sizeof a->err, "Not possible, too long sentence"); rc = CGX_ERR_ALIGN_RANGE; break; }
             uint32_t si = (uint32_t)(c->sentind[q] + s), ti = (uint32_t)(c->tsentind[q] + val);
-            if (si >= c->n || ti >= c->nt) { snprintf(err, errcap, "alignment link outside the corpus on line %d", q + 1); rc = CGX_ERR_ARG; break; }
+            if (si >= (uint32_t)c->sentind[q + 1] || ti >= (uint32_t)c->tsentind[q + 1]) { snprintf(a->err, sizeof a->err, "alignment link outside its sentence pair on line %d", q + 1); rc = CGX_ERR_ARG; break; }
             if (Ls[si] == 255 || Rs[si] == 255) Ls[si] = Rs[si] = (uint8_t)val; else if (val > Rs[si]) Rs[si] = (uint8_t)val; else if (val < Ls[si]) Ls[si] = (uint8_t)val;
             if (c->ltar[ti] == 255 || c->rtar[ti] == 255) c->ltar[ti] = c->rtar[ti] = (uint8_t)s; else if (s > c->rtar[ti]) c->rtar[ti] = (uint8_t)s; else if (s < c->ltar[ti]) c->ltar[ti] = (uint8_t)s;
         }
-        if (rc == CGX_OK && have_s) { snprintf(err, errcap, "Not possible!"); rc = CGX_ERR_ALIGN_PAIR; }
+        if (rc == CGX_OK && have_s) { snprintf(a->err, sizeof a->err, "Not possible!"); rc = CGX_ERR_ALIGN_PAIR; }
         i = e + 1;
     }
+    a->rc = rc;
+    return NULL;
+}
+static int load_alignment(cgx_corpus *c, const char *path, char *err, size_t errcap) {
+    size_t len; char *buf = slurp(path, &len);
+    if (!buf) { snprintf(err, errcap, "Can not open reference file \"%s\"", path); return CGX_ERR_IO; }
+    uint8_t *Ls = malloc(c->n), *Rs = malloc(c->n);
+    c->ltar = malloc((size_t)c->nt + 1); c->rtar = malloc((size_t)c->nt + 1);
+    if (!Ls || !Rs || !c->ltar || !c->rtar) return CGX_ERR_NOMEM;
+    memset(Ls, 255, c->n); memset(Rs, 255, c->n); memset(c->ltar, 255, c->nt); memset(c->rtar, 255, c->nt);
+    int np = nthreads_host() / 2; if (np > SIDE_MAX_PIECES) np = SIDE_MAX_PIECES; if (len < (4u << 20) || np < 1) np = 1;   /* the lexical table loads at the same time */
+    alignpiece pc[SIDE_MAX_PIECES]; size_t cut = 0; int line = 0;
+    for (int k = 0; k < np; k++) {
+        pc[k].c = c; pc[k].buf = buf; pc[k].Ls = Ls; pc[k].Rs = Rs; pc[k].rc = CGX_OK; pc[k].err[0] = 0; pc[k].begin = cut; pc[k].q0 = line;
+        size_t e = k + 1 == np ? len : len / (size_t)np * (size_t)(k + 1);
+        if (e < cut) e = cut;
+        while (e < len && buf[e] != '\n') e++;
+        if (e < len) e++;
+        for (const char *p = buf + cut; (p = memchr(p, '\n', (size_t)(buf + e - p))) != NULL; p++) line++;
+        if (e == len && e > cut && buf[e - 1] != '\n') line++;      /* last line without a newline */
+        pc[k].end = cut = e;
+    }
+    pthread_t th[SIDE_MAX_PIECES]; int started[SIDE_MAX_PIECES] = {0};
+    for (int k = 1; k < np; k++) started[k] = !pthread_create(&th[k], NULL, align_piece_job, &pc[k]);
+    align_piece_job(&pc[0]);
+    for (int k = 1; k < np; k++) { if (started[k]) pthread_join(th[k], NULL); else align_piece_job(&pc[k]); }
+    int rc = CGX_OK;
+    for (int k = 0; k < np && rc == CGX_OK; k++) if (pc[k].rc != CGX_OK) { rc = pc[k].rc; snprintf(err, errcap, "%s", pc[k].err); }
     free(buf);
     if (rc == CGX_OK && pack_alignment(c, Ls, Rs)) rc = CGX_ERR_NOMEM;
     free(Ls); free(Rs);
