@@ -50,7 +50,7 @@ ABI = [
     "cgx_create", "cgx_destroy", "cgx_last_error", "cgx_set_option", "cgx_upload_index", "cgx_build_sa", "cgx_precompute",
     "cgx_index_shape", "cgx_index_alloc", "cgx_index_nbuffers", "cgx_index_buffer", "cgx_index_d2d", "cgx_index_finalize", "cgx_broadcast_index",
     "cgx_upload_queries", "cgx_sa_lookup", "cgx_gappy_search", "cgx_make_blocks", "cgx_set_blocks", "cgx_extract", "cgx_lexicon", "cgx_lex_features", "cgx_fetch",
-    "cgx_stage_ms", "cgx_corpus_load", "cgx_corpus_free", "cgx_corpus_upload", "cgx_extract_grammars", "cgx_extract_grammars_ids",
+    "cgx_stage_ms", "cgx_corpus_load", "cgx_corpus_free", "cgx_corpus_checksum", "cgx_corpus_upload", "cgx_extract_grammars", "cgx_extract_grammars_ids",
     "cgx_corpus_from_ids", "cgx_host_ms", "cgx_flush", "cgx_fetch_pinned", "cgx_pinned_next_batch", "cgx_upload_vocab", "cgx_upload_score_tables", "cgx_set_query_blocks",
     "cgx_format", "cgx_text_offsets", "cgx_text_read", "cgx_text_read_begin", "cgx_text_read_wait", "cgx_pinned_alloc", "cgx_pinned_free",
 ]
@@ -97,6 +97,7 @@ def load_library():
     lib.cgx_host_ms.restype = C.c_double; lib.cgx_host_ms.argtypes = [C.c_void_p, C.c_char_p]
     lib.cgx_corpus_load.restype = C.c_void_p; lib.cgx_corpus_load.argtypes = [C.c_char_p] * 4 + [C.c_char_p, C.c_size_t]
     lib.cgx_corpus_free.restype = None; lib.cgx_corpus_free.argtypes = [C.c_void_p]
+    lib.cgx_corpus_checksum.restype = C.c_uint64; lib.cgx_corpus_checksum.argtypes = [C.c_void_p]
     lib.cgx_corpus_upload.argtypes = [C.c_void_p, C.c_void_p]
     lib.cgx_extract_grammars.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_uint64)]
     lib.cgx_extract_grammars_ids.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_char_p, C.c_int32, C.POINTER(C.c_uint64)]
@@ -140,6 +141,9 @@ class Corpus:
         if not h:
             raise CgxError("cgx_corpus_from_ids failed")
         return cls(h)
+
+    def checksum(self):
+        return int(load_library().cgx_corpus_checksum(self.h))
 
     def close(self):
         if self.h:

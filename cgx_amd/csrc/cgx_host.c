@@ -169,13 +169,15 @@ static void *piece_place_job(void *arg) {
 static void piece_free(sidepiece *pc) { free(pc->tok); free(pc->P); free(pc->sent); free(pc->map.key); free(pc->map.klen); free(pc->map.val); free(pc->wkey); free(pc->wlen); free(pc->l2g); }
 static int nthreads_host(void);
 #define SIDE_MAX_PIECES 32
+/* files smaller than this are parsed by one thread (CGX_LOAD_PIECE_MIN overrides it: tests force the multi-piece path on small fixtures) */
+static size_t piece_min_bytes(void) { const char *e = getenv("CGX_LOAD_PIECE_MIN"); long v = e ? atol(e) : 0; return v > 0 ? (size_t)v : (size_t)4 << 20; }
 static int load_side(const char *path, int32_t **str_out, uint32_t *n_out, uint8_t **P_out, int32_t **sent_out, int32_t *nsent_out,
                      char ***vocab_out, int32_t *nvocab_out, wordmap *map) {
     double tr0 = now_ms(); const int trace = getenv("CGX_TRACE") != NULL;
     size_t len; char *buf = slurp(path, &len);
     if (!buf) return -1;
     double tr1 = now_ms();
-    int np = nthreads_host() / 2; if (np > SIDE_MAX_PIECES) np = SIDE_MAX_PIECES; if (len < (4u << 20) || np < 1) np = 1;   /* two sides load at once */
+    int np = nthreads_host() / 2; if (np > SIDE_MAX_PIECES) np = SIDE_MAX_PIECES; if (len < piece_min_bytes() || np < 1) np = 1;   /* two sides load at once */
     sidepiece pc[SIDE_MAX_PIECES]; memset(pc, 0, sizeof pc);
     size_t cut = 0;
     for (int k = 0; k < np; k++) {                            /* pieces start at line starts */
@@ -287,7 +289,7 @@ static int load_alignment(cgx_corpus *c, const char *path, char *err, size_t err
     c->ltar = malloc((size_t)c->nt + 1); c->rtar = malloc((size_t)c->nt + 1);
     if (!Ls || !Rs || !c->ltar || !c->rtar) return CGX_ERR_NOMEM;
     memset(Ls, 255, c->n); memset(Rs, 255, c->n); memset(c->ltar, 255, c->nt); memset(c->rtar, 255, c->nt);
-    int np = nthreads_host() / 2; if (np > SIDE_MAX_PIECES) np = SIDE_MAX_PIECES; if (len < (4u << 20) || np < 1) np = 1;   /* the lexical table loads at the same time */
+    int np = nthreads_host() / 2; if (np > SIDE_MAX_PIECES) np = SIDE_MAX_PIECES; if (len < piece_min_bytes() || np < 1) np = 1;   /* the lexical table loads at the same time */
     alignpiece pc[SIDE_MAX_PIECES]; size_t cut = 0; int line = 0;
     for (int k = 0; k < np; k++) {
         pc[k].c = c; pc[k].buf = buf; pc[k].Ls = Ls; pc[k].Rs = Rs; pc[k].rc = CGX_OK; pc[k].err[0] = 0; pc[k].begin = cut; pc[k].q0 = line;
@@ -345,6 +347,22 @@ static int build_word_slots(cgx_corpus *c) {
     for (int32_t i = 0; i < c->nsvocab; i++) { uint32_t L = c->svocab[i] ? c->svlen[i] : 0; if (c->svocab[i] && L <= 15) { c->svslot[i].len = (uint8_t)L; memcpy(c->svslot[i].s, c->svocab[i], L); } else c->svslot[i].len = 255; }
     for (int32_t i = 0; i < c->ntvocab; i++) { uint32_t L = c->tvocab[i] ? c->tvlen[i] : 0; if (c->tvocab[i] && L <= 15) { c->tvslot[i].len = (uint8_t)L; memcpy(c->tvslot[i].s, c->tvocab[i], L); } else c->tvslot[i].len = 255; }
     return 0;
+}
+/* FNV-1a over every array of the corpus and the spellings: equal corpora have equal checksums whatever the number of
+ * loader threads (tests), and a caller can tell whether two files produced the same index input */
+static uint64_t fnv_more(uint64_t h, const void *p, size_t n) { const unsigned char *b = p; for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 0x100000001b3ull; } return h; }
+uint64_t cgx_corpus_checksum(const cgx_corpus *c) {
+    if (!c) return 0;
+    uint64_t h = 0xcbf29ce484222325ull;
+    h = fnv_more(h, &c->n, 4); h = fnv_more(h, &c->nt, 4); h = fnv_more(h, &c->nsent, 4); h = fnv_more(h, &c->nlex, 4);
+    h = fnv_more(h, c->str, (size_t)c->n * 4); h = fnv_more(h, c->tstr, (size_t)c->nt * 4);
+    h = fnv_more(h, c->sentind, ((size_t)c->nsent + 1) * 4); h = fnv_more(h, c->tsentind, ((size_t)c->nsent + 1) * 4);
+    if (c->rlp) h = fnv_more(h, c->rlp, (size_t)c->n * 4);
+    if (c->ltar) h = fnv_more(h, c->ltar, c->nt); if (c->rtar) h = fnv_more(h, c->rtar, c->nt);
+    if (c->lexk) h = fnv_more(h, c->lexk, (size_t)c->nlex * sizeof *c->lexk); if (c->lexv) h = fnv_more(h, c->lexv, (size_t)c->nlex * sizeof *c->lexv);
+    for (int32_t i = 2; c->svocab && i < c->nsvocab; i++) if (c->svocab[i]) h = fnv_more(h, c->svocab[i], strlen(c->svocab[i]) + 1);
+    for (int32_t i = 2; c->tvocab && i < c->ntvocab; i++) if (c->tvocab[i]) h = fnv_more(h, c->tvocab[i], strlen(c->tvocab[i]) + 1);
+    return h;
 }
 void cgx_corpus_free(cgx_corpus *c) {
     if (!c) return;

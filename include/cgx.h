@@ -134,6 +134,7 @@ double cgx_stage_ms(cgx_ctx *ctx, const char *name);
 typedef struct cgx_corpus cgx_corpus;
 cgx_corpus *cgx_corpus_load(const char *src, const char *tgt, const char *align, const char *lex, char *err, size_t errcap);
 void cgx_corpus_free(cgx_corpus *c);
+uint64_t cgx_corpus_checksum(const cgx_corpus *c);               /* FNV-1a over every array and spelling of the loaded corpus */
 int cgx_corpus_upload(cgx_ctx *ctx, const cgx_corpus *c);
 /* runs lookup -> gappy search -> extraction -> features for the query file and writes
  * <outdir>/grammar.<q>.s; queries [q_begin, q_end) only (q_end < 0: all) for query sharding */

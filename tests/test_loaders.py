@@ -1,0 +1,56 @@
+"""Host loaders (no GPU): the multi-threaded readers must build exactly the corpus a single thread builds --
+same first-appearance word ids, same arrays, same alignment bytes -- and report the same errors."""
+import os
+import shutil
+
+import pytest
+
+import oracle_py as op
+from test_oracle import make_fixture
+
+
+@pytest.fixture(scope="module")
+def cgx():
+    import cgx_amd
+    cgx_amd.load_library()
+    return cgx_amd
+
+
+def _load(cgx, fx, threads, piece_min):
+    old = {k: os.environ.get(k) for k in ("CGX_THREADS", "CGX_LOAD_PIECE_MIN")}
+    os.environ["CGX_THREADS"] = str(threads); os.environ["CGX_LOAD_PIECE_MIN"] = str(piece_min)
+    try:
+        f = op.fixture_args(fx)
+        c = cgx.Corpus.load(f[0], f[2], f[3], f[4])
+        s = c.checksum(); c.close()
+        return s
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("name", ["tiny", "toy", "mid"])
+def test_piecewise_loading_builds_the_same_corpus(name, cgx, fixtures_dir):
+    fx = make_fixture(name, fixtures_dir)
+    one = _load(cgx, fx, 1, 1 << 30)
+    assert one != 0
+    for threads in (2, 4, 7, 16, 64):
+        assert _load(cgx, fx, threads, 1) == one, threads
+
+
+def test_error_of_the_earliest_line_wins(cgx, fixtures_dir, tmp_path):
+    fx = make_fixture("toy", fixtures_dir); d = tmp_path / "fx"
+    shutil.copytree(fx, d)
+    lines = (d / "corpus.a").read_text().split("\n")
+    lines[len(lines) // 4] += " 3"                      # unpaired number early in the file
+    lines[3 * len(lines) // 4] = "300-1"                # out-of-range position later
+    (d / "corpus.a").write_text("\n".join(lines))
+    msgs = []
+    for threads, pm in ((1, 1 << 30), (8, 1)):
+        with pytest.raises(cgx.CgxError) as e:
+            _load(cgx, str(d), threads, pm)
+        msgs.append(str(e.value))
+    assert msgs[0] == msgs[1] and "Not possible!" in msgs[0]
