@@ -70,9 +70,9 @@ int main(int argc, char **argv) {
     uint64_t nrules = 0;
     rc = cgx_extract_grammars(ctx, corpus, qry, out, qb, nshard == 1 ? -1 : qe, &nrules);
     if (rc != CGX_OK) { fprintf(stderr, "strmatchcuda: %s (%d)\n", cgx_last_error(ctx), rc); return rc == CGX_ERR_IO ? 0 : 2; }
-    fprintf(stderr, "strmatchcuda: %llu rules | index build %.1f ms, precompute %.1f ms | lookup %.3f ms, gappy %.3f ms, extract %.3f ms, features %.3f ms | host: blocks %.1f lists %.1f lexicon %.1f write %.1f ms\n",
-            (unsigned long long)nrules, cgx_stage_ms(ctx, "build_sa"), cgx_stage_ms(ctx, "precompute"), cgx_stage_ms(ctx, "sa_lookup"), cgx_stage_ms(ctx, "gappy"),
-            cgx_stage_ms(ctx, "extract"), cgx_stage_ms(ctx, "lex"), cgx_host_ms(ctx, "blocks"), cgx_host_ms(ctx, "lists"), cgx_host_ms(ctx, "lexicon"), cgx_host_ms(ctx, "write"));
+    fprintf(stderr, "strmatchcuda: %llu rules | index: suffix array %.1f ms, frequent pairs %.1f ms | last batch: lookup %.3f, blocks %.3f, gappy %.3f, extract %.3f, lexicon %.3f, text layout %.3f ms | files written in %.1f ms\n",
+            (unsigned long long)nrules, cgx_stage_ms(ctx, "build_sa"), cgx_stage_ms(ctx, "precompute"), cgx_stage_ms(ctx, "sa_lookup"), cgx_stage_ms(ctx, "blocks"),
+            cgx_stage_ms(ctx, "gappy"), cgx_stage_ms(ctx, "extract"), cgx_stage_ms(ctx, "lexicon"), cgx_stage_ms(ctx, "format"), cgx_host_ms(ctx, "write"));
     cgx_destroy(ctx); cgx_corpus_free(corpus); free(av);
     return 0;
 }
