@@ -68,7 +68,9 @@ int main(int argc, char **argv) {
     if (rc != CGX_OK) { fprintf(stderr, "strmatchcuda: %s\n", cgx_last_error(ctx)); return 2; }
     int32_t qb = (int32_t)((int64_t)nlines * shard / nshard), qe = (int32_t)((int64_t)nlines * (shard + 1) / nshard);
     uint64_t nrules = 0;
+    (void)cgx_set_option(ctx, "async_write", 1);             /* large query files run as several internal batches: write batch k while batch k+1 is on the GPU */
     rc = cgx_extract_grammars(ctx, corpus, qry, out, qb, nshard == 1 ? -1 : qe, &nrules);
+    if (rc == CGX_OK) rc = cgx_flush(ctx);                   /* every file is on disk (or its error reported) before the summary */
     if (rc != CGX_OK) { fprintf(stderr, "strmatchcuda: %s (%d)\n", cgx_last_error(ctx), rc); return rc == CGX_ERR_IO ? 0 : 2; }
     fprintf(stderr, "strmatchcuda: %llu rules | index: suffix array %.1f ms, frequent pairs %.1f ms | last batch: lookup %.3f, blocks %.3f, gappy %.3f, extract %.3f, lexicon %.3f, text layout %.3f ms | files written in %.1f ms\n",
             (unsigned long long)nrules, cgx_stage_ms(ctx, "build_sa"), cgx_stage_ms(ctx, "precompute"), cgx_stage_ms(ctx, "sa_lookup"), cgx_stage_ms(ctx, "blocks"),
