@@ -922,7 +922,8 @@ static int ensure_vocab(cgx_ctx *ctx, const cgx_corpus *c) {
     return rc;
 }
 typedef struct { cgx_ctx *ctx; int slot; const uint64_t *qtext; int32_t nq, first; const char *outdir; int64_t *next; int64_t npieces; int tid, rc; double wait_ms, write_ms; } devjob;
-#define PIN_BYTES (16u << 20)
+static uint64_t g_pin_bytes;                              /* piece size: fixed at the first batch (CGX_PIN_MB, default 16) */
+#define PIN_BYTES g_pin_bytes
 #define PIN_RING 3                                        /* copies in flight per writer thread: keeps PCIe busy while the thread sits in pwrite() */
 #define MAX_WRITERS (CGX_MAX_READERS / PIN_RING)
 static void *g_pin[MAX_WRITERS][PIN_RING];                /* page-locked staging buffers, kept for the life of the process */
@@ -1008,6 +1009,7 @@ static int write_from_device(cgx_ctx *ctx, int slot, const uint64_t *qtext, int3
     if (rc != CGX_OK) return rc;
     *wait_ms = *file_ms = 0;
     const uint64_t total = qtext[nq];
+    if (!g_pin_bytes) { const char *e = getenv("CGX_PIN_MB"); long mb = e ? atol(e) : 0; g_pin_bytes = (uint64_t)(mb >= 1 && mb <= 256 ? mb : 16) << 20; }
     int64_t npieces = (int64_t)((total + PIN_BYTES - 1) / PIN_BYTES), next = 0;
     if (!npieces) return CGX_OK;
     int nt = nthreads_host(); if (nt > MAX_WRITERS) nt = MAX_WRITERS; if (nt > npieces) nt = (int)npieces;
