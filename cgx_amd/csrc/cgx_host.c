@@ -312,33 +312,85 @@ static int load_alignment(cgx_corpus *c, const char *path, char *err, size_t err
     free(Ls); free(Rs);
     return rc;
 }
-static int load_lex(cgx_corpus *c, const char *path, char *err, size_t errcap) {
-    size_t len; char *buf = slurp(path, &len);
-    if (!buf) { snprintf(err, errcap, "The Word Possibility File is not Found!"); return CGX_ERR_IO; }
-    size_t cap = 0, n = 0, p = 0;
+/* Lexical table: four white-space separated fields per entry, like `file >> a >> b >> v1 >> v2` (entries, not lines:
+ * a piece boundary must fall between entries, so pieces are cut at line ends and a piece whose field count is not a
+ * multiple of four makes the loader fall back to one piece).  Rows keep file order; the "Not Available" notices of
+ * the reference are printed in file order after the pieces are joined. */
+typedef struct { const cgx_corpus *c; const char *buf; size_t begin, end; cgx_lexkey *k; cgx_lexval *v; size_t n, cap; char *msg; size_t nmsg, cmsg; size_t fields; int rc; } lexpiece;
+static int lexpiece_note(lexpiece *lp, const char *what, const char *w, size_t wl) {
+    size_t need = strlen(what) + wl + 2;
+    if (lp->nmsg + need + 1 > lp->cmsg) { size_t nc = lp->cmsg ? lp->cmsg * 2 : 4096; while (nc < lp->nmsg + need + 1) nc *= 2; lp->msg = realloc(lp->msg, nc); if (!lp->msg) return -1; lp->cmsg = nc; }
+    lp->nmsg += (size_t)sprintf(lp->msg + lp->nmsg, "%s%.*s\n", what, (int)wl, w);
+    return 0;
+}
+static void *lex_piece_job(void *arg) {
+    lexpiece *lp = arg; const cgx_corpus *c = lp->c; const char *buf = lp->buf; size_t p = lp->begin; const size_t len = lp->end;
     const char *w[4]; size_t wl[4];
     for (;;) {
         int k = 0;
-        while (k < 4) {                                  /* four white-space separated fields, like `file >> a >> b >> v1 >> v2` */
+        while (k < 4) {
             while (p < len && isspace((unsigned char)buf[p])) p++;
             if (p >= len) break;
             w[k] = buf + p; size_t q = p; while (q < len && !isspace((unsigned char)buf[q])) q++;
             wl[k] = q - p; p = q; k++;
         }
+        lp->fields += (size_t)k;
         if (k < 4) break;
         int32_t s = wordmap_get(&c->smap, w[0], wl[0]), t = wordmap_get(&c->tmap, w[1], wl[1]);
         int snull = wl[0] == 4 && !strncmp(w[0], "NULL", 4), tnull = wl[1] == 4 && !strncmp(w[1], "NULL", 4);
-        if (s < 0 && !snull) { printf("Ch Not Available!!! %.*s\n", (int)wl[0], w[0]); continue; }
-        if (t < 0 && !tnull) { printf("En Not Available!!! %.*s\n", (int)wl[1], w[1]); continue; }
+        if (s < 0 && !snull) { if (lexpiece_note(lp, "Ch Not Available!!! ", w[0], wl[0])) { lp->rc = CGX_ERR_NOMEM; return NULL; } continue; }
+        if (t < 0 && !tnull) { if (lexpiece_note(lp, "En Not Available!!! ", w[1], wl[1])) { lp->rc = CGX_ERR_NOMEM; return NULL; } continue; }
         char f1[64], f2[64]; size_t a = wl[2] < 63 ? wl[2] : 63, b = wl[3] < 63 ? wl[3] : 63;
         memcpy(f1, w[2], a); f1[a] = 0; memcpy(f2, w[3], b); f2[b] = 0;
-        if (n == cap) { cap = cap ? cap * 2 : 4096; c->lexk = realloc(c->lexk, cap * sizeof *c->lexk); c->lexv = realloc(c->lexv, cap * sizeof *c->lexv); if (!c->lexk || !c->lexv) return CGX_ERR_NOMEM; }
-        c->lexk[n].src = s < 0 ? -1 : s; c->lexk[n].tgt = t < 0 ? -1 : t;
-        c->lexv[n].v1 = strtof(f1, NULL); c->lexv[n].v2 = strtof(f2, NULL); n++;
+        if (lp->n == lp->cap) { lp->cap = lp->cap ? lp->cap * 2 : 4096; lp->k = realloc(lp->k, lp->cap * sizeof *lp->k); lp->v = realloc(lp->v, lp->cap * sizeof *lp->v); if (!lp->k || !lp->v) { lp->rc = CGX_ERR_NOMEM; return NULL; } }
+        lp->k[lp->n].src = s < 0 ? -1 : s; lp->k[lp->n].tgt = t < 0 ? -1 : t;
+        lp->v[lp->n].v1 = strtof(f1, NULL); lp->v[lp->n].v2 = strtof(f2, NULL); lp->n++;
+    }
+    return NULL;
+}
+static int load_lex(cgx_corpus *c, const char *path, char *err, size_t errcap) {
+    size_t len; char *buf = slurp(path, &len);
+    if (!buf) { snprintf(err, errcap, "The Word Possibility File is not Found!"); return CGX_ERR_IO; }
+    int np = nthreads_host() / 2; if (np > SIDE_MAX_PIECES) np = SIDE_MAX_PIECES; if (len < piece_min_bytes() || np < 1) np = 1;   /* the alignment loads at the same time */
+    lexpiece pc[SIDE_MAX_PIECES]; pthread_t th[SIDE_MAX_PIECES]; int started[SIDE_MAX_PIECES]; int rc = CGX_OK;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        memset(pc, 0, sizeof pc); memset(started, 0, sizeof started);
+        size_t cut = 0;
+        for (int k = 0; k < np; k++) {
+            pc[k].c = c; pc[k].buf = buf; pc[k].begin = cut;
+            size_t e = k + 1 == np ? len : len / (size_t)np * (size_t)(k + 1);
+            if (e < cut) e = cut;
+            while (e < len && buf[e] != '\n') e++;
+            if (e < len) e++;
+            pc[k].end = cut = e;
+        }
+        for (int k = 1; k < np; k++) started[k] = !pthread_create(&th[k], NULL, lex_piece_job, &pc[k]);
+        lex_piece_job(&pc[0]);
+        for (int k = 1; k < np; k++) { if (started[k]) pthread_join(th[k], NULL); else lex_piece_job(&pc[k]); }
+        int ragged = 0;
+        for (int k = 0; k + 1 < np; k++) if (pc[k].fields % 4) ragged = 1;     /* an entry straddles a line end: only a sequential read parses it like `>>` */
+        for (int k = 0; k < np; k++) if (pc[k].rc != CGX_OK) rc = pc[k].rc;
+        if (!ragged || np == 1 || rc != CGX_OK) break;
+        for (int k = 0; k < np; k++) { free(pc[k].k); free(pc[k].v); free(pc[k].msg); }
+        np = 1;
+    }
+    size_t n = 0;
+    for (int k = 0; k < np; k++) n += pc[k].n;
+    if (rc == CGX_OK) {
+        c->lexk = malloc((n + 1) * sizeof *c->lexk); c->lexv = malloc((n + 1) * sizeof *c->lexv);
+        if (!c->lexk || !c->lexv) rc = CGX_ERR_NOMEM;
+    }
+    size_t at = 0;
+    for (int k = 0; k < np; k++) {
+        if (rc == CGX_OK) {
+            if (pc[k].nmsg) fwrite(pc[k].msg, 1, pc[k].nmsg, stdout);
+            if (pc[k].n) { memcpy(c->lexk + at, pc[k].k, pc[k].n * sizeof *c->lexk); memcpy(c->lexv + at, pc[k].v, pc[k].n * sizeof *c->lexv); at += pc[k].n; }
+        }
+        free(pc[k].k); free(pc[k].v); free(pc[k].msg);
     }
     free(buf);
-    c->nlex = (uint32_t)n;
-    return CGX_OK;
+    if (rc == CGX_OK) c->nlex = (uint32_t)n;
+    return rc;
 }
 
 static int build_word_slots(cgx_corpus *c) {
@@ -358,8 +410,10 @@ uint64_t cgx_corpus_checksum(const cgx_corpus *c) {
     h = fnv_more(h, c->str, (size_t)c->n * 4); h = fnv_more(h, c->tstr, (size_t)c->nt * 4);
     h = fnv_more(h, c->sentind, ((size_t)c->nsent + 1) * 4); h = fnv_more(h, c->tsentind, ((size_t)c->nsent + 1) * 4);
     if (c->rlp) h = fnv_more(h, c->rlp, (size_t)c->n * 4);
-    if (c->ltar) h = fnv_more(h, c->ltar, c->nt); if (c->rtar) h = fnv_more(h, c->rtar, c->nt);
-    if (c->lexk) h = fnv_more(h, c->lexk, (size_t)c->nlex * sizeof *c->lexk); if (c->lexv) h = fnv_more(h, c->lexv, (size_t)c->nlex * sizeof *c->lexv);
+    if (c->ltar) h = fnv_more(h, c->ltar, c->nt);
+    if (c->rtar) h = fnv_more(h, c->rtar, c->nt);
+    if (c->lexk) h = fnv_more(h, c->lexk, (size_t)c->nlex * sizeof *c->lexk);
+    if (c->lexv) h = fnv_more(h, c->lexv, (size_t)c->nlex * sizeof *c->lexv);
     for (int32_t i = 2; c->svocab && i < c->nsvocab; i++) if (c->svocab[i]) h = fnv_more(h, c->svocab[i], strlen(c->svocab[i]) + 1);
     for (int32_t i = 2; c->tvocab && i < c->ntvocab; i++) if (c->tvocab[i]) h = fnv_more(h, c->tvocab[i], strlen(c->tvocab[i]) + 1);
     return h;
@@ -725,6 +779,8 @@ static int build_lexicons(batch *b) {
 typedef struct { char *p; size_t n, cap; } sbuf;
 static int sb_need(sbuf *s, size_t extra) { if (s->n + extra + 1 > s->cap) { size_t nc = s->cap ? s->cap : 1 << 16; while (nc < s->n + extra + 1) nc *= 2; s->p = realloc(s->p, nc); if (!s->p) return -1; s->cap = nc; } return 0; }
 /* The formatter below appends through a raw cursor; the caller reserves line_max() bytes per line first. */
+/* used by tests/cpu_sim/f6test.c, which includes this file to check put_f6 against printf */
+static int sb_f6(sbuf *s, float x) __attribute__((unused));
 static size_t line_max(const cgx_corpus *c) { return 512 + 32 * ((size_t)c->maxword + 8); }
 #define PUT_LIT(p, lit) do { memcpy((p), (lit), sizeof(lit) - 1); (p) += sizeof(lit) - 1; } while (0)
 static const char DIG2[201] = "00010203040506070809101112131415161718192021222324252627282930313233343536373839404142434445464748495051525354555657585960616263646566676869707172737475767778798081828384858687888990919293949596979899";
@@ -792,6 +848,7 @@ static float g_aa[TABN][TABN], g_bb[TABN], g_fs[TABN]; static int g_tab_ready;
 static char g_aa_s[TABN][TABN][12], g_bb_s[TABN][12], g_fs_s[TABN][12];      /* the same values already formatted with %f */
 static uint8_t g_aa_l[TABN][TABN], g_bb_l[TABN], g_fs_l[TABN];
 static inline char *put_f6(char *p, float x);
+static int sb_f6(sbuf *s, float x) { if (sb_need(s, 64)) return -1; s->n = (size_t)(put_f6(s->p + s->n, x) - s->p); return 0; }
 static void score_tables(void) {
     if (g_tab_ready) return;
     for (int p = 0; p < TABN; p++) {
@@ -815,7 +872,6 @@ static inline char *put_f6(char *p, float x) {
     memcpy(p, DIG2 + 2 * (fp / 10000u), 2); memcpy(p + 2, DIG2 + 2 * (fp / 100u % 100u), 2); memcpy(p + 4, DIG2 + 2 * (fp % 100u), 2);
     return p + 6;
 }
-static int sb_f6(sbuf *s, float x) { if (sb_need(s, 64)) return -1; s->n = (size_t)(put_f6(s->p + s->n, x) - s->p); return 0; }
 static int emit_range(sbuf *s, const batch *b, int kind, const cgx_lexent *lex, const range *rng, uint32_t id, uint64_t *lines) {
     if (rng[id].down == -1 || rng[id].up == -1) return 0;
     const size_t lmax = line_max(b->c);

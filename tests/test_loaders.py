@@ -54,3 +54,13 @@ def test_error_of_the_earliest_line_wins(cgx, fixtures_dir, tmp_path):
             _load(cgx, str(d), threads, pm)
         msgs.append(str(e.value))
     assert msgs[0] == msgs[1] and "Not possible!" in msgs[0]
+
+
+def test_lexical_entries_that_straddle_lines(cgx, fixtures_dir, tmp_path):
+    """`file >> a >> b >> v1 >> v2` does not care about line ends; a table whose entries are split over lines must load
+    the same way with many threads (the loader notices the ragged pieces and reads it sequentially)."""
+    fx = make_fixture("toy", fixtures_dir); d = tmp_path / "fx"
+    shutil.copytree(fx, d)
+    rows = (d / "lex.txt").read_text().split()
+    (d / "lex.txt").write_text("\n".join(" ".join(rows[i:i + 3]) for i in range(0, len(rows), 3)) + "\n")   # three fields per line
+    assert _load(cgx, str(d), 16, 1) == _load(cgx, str(d), 1, 1 << 30) == _load(cgx, fx, 1, 1 << 30)
