@@ -2105,7 +2105,7 @@ __global__ void k_group_starts(const uint32_t *flags, const uint32_t *incl, uint
     if (i < n && flags[i]) gstart[incl[i] - 1] = i;
 }
 // final pass: one lane per lexicon line (in first-occurrence order): fill the wire record and run MaxLex
-__global__ void k_lex_finish(lexsrc L, cgx_lexview T, int kind, const cgx_rule0 *r0, const cgx_rule1 *r1, const cgx_rule2 *r2, uint32_t nrules,
+__global__ __launch_bounds__(128) void k_lex_finish(lexsrc L, cgx_lexview T, int kind, const cgx_rule0 *r0, const cgx_rule1 *r1, const cgx_rule2 *r2, uint32_t nrules,
                              const uint32_t *first_rule_sorted, const uint32_t *entry_of_sorted, const uint32_t *runstart, uint32_t nent, uint32_t nruns_total,
                              const uint32_t *gidx_incl, const uint32_t *gstart, uint32_t ngroups, cgx_lexent *out) {
     uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;

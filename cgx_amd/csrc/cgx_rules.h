@@ -445,7 +445,7 @@ CGX_HD bool cgx_lex_get(const cgx_lexview &t, int32_t src, int32_t tgt, float *v
 // Each maximum still sees its candidates in the reference's order (NULL first, then ascending
 // position, strict '>'), and the two sums are still added in ascending word order, so the
 // floats are identical.
-#define CGX_MAXLEX_SRC 8
+#define CGX_MAXLEX_SRC 5
 CGX_HD void cgx_maxlex(const cgx_lexview &t, const int32_t *tstr, const int32_t *src, int nsrc, uint32_t tstart,
                        int end, int gap1, int gap1_1, int gap2, int gap2_1, int kind, float *fe, float *ef) {
     float fgivene = 0.0f, egivenf = 0.0f;
