@@ -239,17 +239,22 @@ def test_async_writer_gives_the_same_files(cgx, fixtures_dir, tmp_path):
     ex.close(); corpus.close()
 
 
-def test_id_level_batch_on_synthetic_corpus(cgx, tmp_path):
-    """bench.py's path: corpus from id arrays; suffix array property check + oracle parity through liboracle."""
+_EXTRA = [tuple(int(x) for x in os.environ["CGX_BIG_PARITY"].split(","))] if os.environ.get("CGX_BIG_PARITY") else []   # e.g. 1000000,200000,60 (minutes of oracle time)
+
+
+@pytest.mark.parametrize("pairs,vocab,nq", [(3000, 400, 12), (100000, 200000, 120)] + _EXTRA)
+def test_id_level_batch_on_synthetic_corpus(pairs, vocab, nq, cgx, tmp_path):
+    """bench.py's path: corpus from id arrays; suffix array property check + oracle parity through liboracle.  The
+    second size is the prefix bench.py times its CPU baseline on (2.6 M source tokens, the benchmark's vocabulary)."""
     import ctypes as C
     from cgx_amd import synth
-    corpus = synth.make_corpus(3000, 400, 5)
-    qoff, qtok = synth.make_queries(corpus, 12, 6)
+    corpus = synth.make_corpus(pairs, vocab, 5)
+    qoff, qtok = synth.make_queries(corpus, nq, 6)
     host = cgx.Corpus.from_ids(corpus["str"], corpus["sentind"], corpus["tstr"], corpus["tsentind"], corpus["lsrc"], corpus["rsrc"],
                                corpus["ltar"], corpus["rtar"], corpus["lexk"], corpus["lexv"])
     ex = cgx.Extractor(0); ex.upload_corpus(host)
     sa = ex.fetch("sa"); s = corpus["str"]; n = len(s)
-    assert np.array_equal(np.sort(sa), np.arange(n))
+    assert np.array_equal(np.bincount(sa, minlength=n), np.ones(n, np.int64))
     pad = np.concatenate((s, np.zeros(64, np.int32)))
     for i in np.random.default_rng(0).integers(0, n - 1, 2000):      # adjacent suffixes are in order
         a, b = int(sa[i]), int(sa[i + 1]); k = 0
@@ -270,6 +275,6 @@ def test_id_level_batch_on_synthetic_corpus(cgx, tmp_path):
     oout = tmp_path / "o"; oout.mkdir()
     b = lib.orc_batch_from_ids(p(qoff), len(qoff), p(qtok), len(qtok))
     assert lib.orc_run_all(ix, b, str(oout).encode()) == 0
-    assert op.sha_dir(str(out), 12) == op.sha_dir(str(oout), 12)
+    assert op.sha_dir(str(out), nq) == op.sha_dir(str(oout), nq)
     assert nrules == sum(sum(1 for _ in open(oout / f, "rb")) for f in os.listdir(oout))
     ex.close(); host.close()
