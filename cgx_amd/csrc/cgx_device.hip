@@ -39,6 +39,10 @@ static int fail(cgx_ctx *c, int code, const char *what, hipError_t e) {
 // and reused by later stages/batches on the same stream; cgx_destroy returns them to the driver.
 #include <unordered_map>
 #include <map>
+// Caching device allocator: multi-GB hipMalloc/hipFree calls cost up to a second each, and every batch needs the same
+// sizes again.  One pool per device (a block is only ever reused on the device it came from), one lock for all of
+// them (contexts on different devices may be driven from different threads).
+#include <mutex>
 struct DevPool {
     std::unordered_map<void *, size_t> live;
     std::multimap<size_t, void *> cached;
@@ -51,24 +55,40 @@ struct DevPool {
         live[p] = bytes;
         return p;
     }
-    void put(void *p) {
+    bool put(void *p) {
         auto it = live.find(p);
-        if (it == live.end()) { (void)hipFree(p); return; }
+        if (it == live.end()) return false;
         cached.insert({it->second, p}); cached_bytes += it->second; live.erase(it);
+        return true;
     }
     void trim() { for (auto &kv : cached) (void)hipFree(kv.second); cached.clear(); cached_bytes = 0; }
 };
-static DevPool g_pool;
+#define CGX_MAX_DEVICES 64
+static DevPool g_pools[CGX_MAX_DEVICES];
+static std::mutex g_pool_lock;
+static void *pool_get(int device, size_t bytes) {
+    std::lock_guard<std::mutex> g(g_pool_lock);
+    return g_pools[device < 0 || device >= CGX_MAX_DEVICES ? 0 : device].get(bytes);      // the caller has made `device` current
+}
+static void pool_put(void *p) {
+    std::lock_guard<std::mutex> g(g_pool_lock);
+    for (int d = 0; d < CGX_MAX_DEVICES; d++) if (g_pools[d].put(p)) return;
+    (void)hipFree(p);                                         // not ours (never happens): plain free
+}
+static void pool_trim(int device) {
+    std::lock_guard<std::mutex> g(g_pool_lock);
+    g_pools[device < 0 || device >= CGX_MAX_DEVICES ? 0 : device].trim();
+}
 template <class T> static int dalloc(cgx_ctx *ctx, T **p, size_t count) {
     size_t bytes = (count ? count : 1) * sizeof(T);
     bytes = (bytes + 255) & ~(size_t)255;
-    *p = (T *)g_pool.get(bytes);
+    *p = (T *)pool_get(ctx->device, bytes);
     if (!*p) return fail(ctx, CGX_ERR_NOMEM, "device allocation", hipErrorOutOfMemory);
     return CGX_OK;
 }
-template <class T> static void dfree(T *&p) { if (p) { g_pool.put((void *)p); p = nullptr; } }
+template <class T> static void dfree(T *&p) { if (p) { pool_put((void *)p); p = nullptr; } }
 static int dalloc_bytes(cgx_ctx *ctx, void **p, size_t bytes) { return dalloc(ctx, (char **)p, bytes); }
-static void dfree_bytes(void *p) { if (p) g_pool.put(p); }
+static void dfree_bytes(void *p) { if (p) pool_put(p); }
 static inline unsigned nblocks(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
 static int bits_for(uint64_t maxval) { int b = 1; while (b < 64 && (maxval >> b)) b++; return b; }
 
@@ -322,7 +342,7 @@ extern "C" void cgx_destroy(cgx_ctx *c) {
     for (int r = 0; r < CGX_COPY_STREAMS; r++) if (c->copy_streams[r]) (void)hipStreamDestroy(c->copy_streams[r]);
     for (int r = 0; r < CGX_MAX_READERS; r++) if (c->copy_done[r]) (void)hipEventDestroy(c->copy_done[r]);
     (void)hipStreamSynchronize(c->stream);
-    g_pool.trim();
+    pool_trim(c->device);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
