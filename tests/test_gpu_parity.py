@@ -154,6 +154,12 @@ def test_edge_case_queries(cgx, oracle_bin, tmp_path):
     ex, corpus, n = run_product(cgx, str(d), str(tmp_path / "p"))
     assert op.sha_dir(str(tmp_path / "p"), 6) == op.sha_dir(str(tmp_path / "o"), 6)
     ex.close(); corpus.close()
+    (d / "query.f").write_text("OOV1 OOV2 OOV3\nOOV4\n\n")                # nothing matches anywhere: three empty grammar files
+    op.run_oracle(oracle_bin, str(d), str(tmp_path / "o3"))
+    for fmt in (1, 0):
+        ex, corpus, n = run_product(cgx, str(d), str(tmp_path / ("p3_%d" % fmt)), device_format=fmt)
+        assert n == 0 and op.sha_dir(str(tmp_path / ("p3_%d" % fmt)), 3) == op.sha_dir(str(tmp_path / "o3"), 3)
+        ex.close(); corpus.close()
     (d / "query.f").write_text("")                                       # empty query file: nothing to do, no crash
     ex, corpus, n = run_product(cgx, str(d), str(tmp_path / "p2"))
     assert n == 0
