@@ -80,7 +80,7 @@ def cpu_baseline(corpus, args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--pairs", type=int, default=10000000, help="sentence pairs in the synthetic corpus (BASELINE configs[2]: 10M)")
     ap.add_argument("--vocab", type=int, default=200000)
