@@ -65,6 +65,7 @@ def main():
     ap = argparse.ArgumentParser(); ap.add_argument("--only", type=int, default=-1)
     ap.add_argument("--fuzz", type=int, default=0, help="instead of the fixed shapes: this many random shapes and option sets")
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--big", action="store_true", help="with --fuzz: corpora of 50-150 k sentence pairs, 100-300 queries (tens of seconds of oracle time each)")
     ap.add_argument("--opt", action="append", default=[], help="name=value, overrides the case's options")
     args = ap.parse_args()
     import torch; torch.zeros(1, device="cuda:0")
@@ -78,7 +79,8 @@ def main():
         for i in range(args.fuzz):
             lo = r.choice([1, 2, 4, 8, 15]); hi = lo + r.choice([3, 10, 25, 60])
             opts = {k: r.choice(v) for k, v in menu.items() if r.random() < 0.25}
-            shapes.append((r.choice([1500, 4000, 9000, 25000]), r.choice([101, 105, 130, 250, 900, 5000]), r.choice([20, 60, 130]), 1000 * args.seed + i, lo, hi, opts))
+            if args.big: shapes.append((r.choice([50000, 150000]), r.choice([150, 1000, 30000]), r.choice([100, 300]), 1000 * args.seed + i, lo, hi, opts))
+            else: shapes.append((r.choice([1500, 4000, 9000, 25000]), r.choice([101, 105, 130, 250, 900, 5000]), r.choice([20, 60, 130]), 1000 * args.seed + i, lo, hi, opts))
     if args.opt: shapes = [s_[:6] + (dict(o.split("=") for o in args.opt),) for s_ in shapes]
     bad = 0
     for shape in shapes:
