@@ -94,6 +94,8 @@ def main():
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--sub-batch", type=int, default=0, help="queries per internal batch inside one step (0 = the whole step at once)")
     ap.add_argument("--no-numa-pin", action="store_true", help="do not bind the writer threads to the GPU's NUMA node")
+    ap.add_argument("--no-rewrite-run", action="store_true", help="skip the informational in-place rewrite measurement")
+    ap.add_argument("--outdir-mode", choices=("auto", "fresh", "inplace"), default="auto", help="fresh: a new directory per step (default when there is room for four steps' files); inplace: every step rewrites the same files")
     ap.add_argument("--sync-write", action="store_true", help="write each step's files before starting the next step")
     ap.add_argument("--no-write", action="store_true", help="format nothing, write no files (kernel-side study only; not the headline)")
     args = ap.parse_args()
@@ -168,13 +170,49 @@ def main():
             pass
     if base is None and cands:
         base = max(cands, key=lambda d: shutil.disk_usage(d).free)
-    outdir = None if args.no_write else tempfile.mkdtemp(prefix="cgx_bench_r%d_" % rank, dir=base)
+    outroot = None if args.no_write else tempfile.mkdtemp(prefix="cgx_bench_r%d_" % rank, dir=base)
+    # Every step writes its files into a FRESH directory, as a real run does (a step that rewrites the previous step's
+    # files in place measures the page cache's second-touch behaviour instead: the first rewrite of a file set takes
+    # 4x the CPU time of either a fresh write or a later rewrite).  Directories of finished steps are unlinked by
+    # background threads while later steps run; with too little room for three live directories the steps share one
+    # directory and one extra untimed step makes sure the timed ones are not the first rewrite.
+    fresh = bool(outroot) and args.outdir_mode != "inplace" and shutil.disk_usage(base).free >= 4 * need * (world if not args.outdir else 1)
+    if args.outdir_mode == "fresh" and outroot and not fresh:
+        raise SystemExit("bench.py: not enough room under %s for --outdir-mode fresh" % base)
+    import concurrent.futures, collections
+    pool = concurrent.futures.ThreadPoolExecutor(max_workers=4)
+    deletions = []; live = collections.deque(); stepno = [0]
+
+    def unlink_many(paths):
+        for p in paths:
+            try:
+                os.unlink(p)
+            except OSError:
+                pass
+
+    def remove_dir_async(d):
+        names = [os.path.join(d, n) for n in os.listdir(d)]
+        futs = [pool.submit(unlink_many, names[i::4]) for i in range(4)]
+        deletions.append((d, futs))
 
     def step():
-        return ex.extract_grammars_ids(host, qoff, qtok, outdir, first)
+        if not outroot:
+            return ex.extract_grammars_ids(host, qoff, qtok, None, first)
+        if not fresh:
+            return ex.extract_grammars_ids(host, qoff, qtok, outroot, first)
+        d = os.path.join(outroot, "step%d" % stepno[0]); stepno[0] += 1
+        os.mkdir(d)
+        n = ex.extract_grammars_ids(host, qoff, qtok, d, first)   # returns once this step's text is laid out; the previous step's files are complete by then
+        live.append(d)
+        while len(live) > 2:                                  # the newest directory is still being written, the one before it was just completed
+            remove_dir_async(live.popleft())
+        return n
 
+    priming = 0
     for _ in range(args.warmup):
         step()
+    if outroot and not fresh and args.warmup < 2:             # in-place mode: the timed steps must not be the first rewrite of the files
+        step(); priming = 1
     ex.flush()
     kernel_ms = []; stage = {k: 0.0 for k in ("sa_lookup", "blocks", "gappy", "extract", "lexicon", "format", "fmt_lists", "fmt_count", "fmt_alloc", "fmt_write", "look1_kernel", "look2_kernel")}; hoststage = {k: 0.0 for k in ("lists", "lexicon", "write", "write_wait_d2h", "write_file", "total", "t_upload_sa", "t_fetch_lm", "t_blocks", "t_qblocks", "t_gappy", "t_extract", "t_lexicon", "t_format", "t_offsets", "t_flush_wait")}
     if world > 1:
@@ -194,7 +232,28 @@ def main():
     total_q = shard.sum_over_ranks(len(qoff) * args.steps, dist if world > 1 else None)
     total_rules = shard.sum_over_ranks(rules, dist if world > 1 else None)
 
-    out_bytes = sum(e.stat().st_size for e in os.scandir(outdir)) if outdir else 0
+    # informational second measurement (N=1 only): the same K steps rewriting ONE directory in place, after two
+    # untimed steps so that no timed step is the first rewrite.  No page allocation, no unlinking: what is left is
+    # the pipeline itself (PCIe D2H at ~55 GB/s is the limit).  Never used for `value`.
+    rewrite = None
+    if fresh and world == 1 and not args.no_rewrite_run:
+        rd = os.path.join(outroot, "rewrite"); os.mkdir(rd)
+        for _ in range(2):
+            ex.extract_grammars_ids(host, qoff, qtok, rd, first)
+        ex.flush(); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            ex.extract_grammars_ids(host, qoff, qtok, rd, first)
+        ex.flush(); torch.cuda.synchronize()
+        dt1 = time.perf_counter() - t1
+        rewrite = {"value": round(len(qoff) * args.steps / dt1, 3), "unit": "query sentences/s", "ms_per_step": round(dt1 / args.steps * 1e3, 3),
+                   "what": "same steps, one output directory rewritten in place (files and their page-cache pages already exist)"}
+    lastdir = (live[-1] if fresh else outroot) if outroot else None
+    out_bytes = sum(e.stat().st_size for e in os.scandir(lastdir) if e.is_file()) if lastdir else 0
+    for d, futs in deletions:                                  # outside the timed region: only bookkeeping is left here, the unlinks ran during the steps
+        for f in futs:
+            f.result()
+    pool.shutdown()
     free_b, total_b = torch.cuda.mem_get_info()                # after the timed steps: index + cached batch buffers + both text slots
 
     if rank == 0:
@@ -230,11 +289,13 @@ def main():
                                    % (args.pairs, args.queries),
                        "sentence_pairs": args.pairs, "source_tokens": int(len(corpus["str"])), "vocab": args.vocab,
                        "queries_per_gpu": int(len(qoff)), "query_tokens_per_gpu": int(len(qtok)), "parallelism": "query-shard x%d, index replicated" % world,
-                       "grammar_files_written": not args.no_write, "grammar_bytes_per_step": out_bytes, "writer": "sync" if args.sync_write else "async (host threads overlap the next step; flushed before the clock stops)", "outdir": os.path.dirname(outdir) if outdir else None},
+                       "grammar_files_written": not args.no_write, "grammar_bytes_per_step": out_bytes, "writer": "sync" if args.sync_write else "async (host threads overlap the next step; flushed before the clock stops)", "outdir": base if outroot else None,
+                       "outdir_mode": ("fresh directory per step, older ones unlinked in the background" if fresh else "one directory rewritten in place, %d untimed priming step(s)" % priming) if outroot else None},
             "roofline": {"bound": "hbm", "kernel": "k_sa_lookup (batched SA interval search)", "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(ach / 8000.0, 4), "traffic": traffic, "algorithmic_bytes_per_launch": int(abytes), "lookups_per_launch": int(lookups),
                          "kernel_ms": round(kms, 4), "pmc_GBps": (round(traffic / (kms * 1e-3) / 1e9, 1) if traffic and kms > 0 else None),
                          "note": "achieved prices every lookup at the reference's full-depth binary search (SURVEY 8d); this kernel replaces l=1,2 by table probes, so achieved can exceed the peak while pmc_GBps is the traffic it really moves"},
+            "rewrite_in_place": rewrite,
             "roofline_largest_per_batch_kernels": by_time,
             "stages_ms_per_step": {k: round(v / args.steps, 3) for k, v in {**stage, **{"host_" + k: v for k, v in hoststage.items()}}.items()},
             "index": {"build_sa_ms": round(ex.stage_ms("build_sa"), 1), "precompute_ms": round(ex.stage_ms("precompute"), 1),
@@ -245,8 +306,8 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(corpus, args)
         print(json.dumps(line))
-    if outdir:
-        shutil.rmtree(outdir, ignore_errors=True)
+    if outroot:
+        shutil.rmtree(outroot, ignore_errors=True)
     ex.close()
     if world > 1:
         dist.barrier(); dist.destroy_process_group()

@@ -977,7 +977,7 @@ static int ensure_vocab(cgx_ctx *ctx, const cgx_corpus *c) {
     free(sp); free(tp); free(soff); free(toff);
     return rc;
 }
-typedef struct { cgx_ctx *ctx; int slot; const uint64_t *qtext; int32_t nq, first; const char *outdir; int64_t *next; int64_t npieces; int tid, rc; double wait_ms, write_ms; } devjob;
+typedef struct { cgx_ctx *ctx; int slot; const uint64_t *qtext; int32_t nq, first; const char *outdir; int64_t *next; int64_t npieces; int tid, rc; double wait_ms, write_ms, t_start, t_first, t_end; } devjob;
 static uint64_t g_pin_bytes;                              /* piece size: fixed at the first batch (CGX_PIN_MB, default 16) */
 #define PIN_BYTES g_pin_bytes
 #define PIN_RING 3                                        /* copies in flight per writer thread: keeps PCIe busy while the thread sits in pwrite() */
@@ -1024,7 +1024,7 @@ static void pin_to_device_node(cgx_ctx *ctx) {
 }
 static void *dev_write_worker(void *arg) {
     devjob *w = arg; w->rc = CGX_OK;
-    w->wait_ms = w->write_ms = 0;
+    w->wait_ms = w->write_ms = 0; w->t_start = now_ms(); w->t_first = 0;
     if (w->tid > 0) pin_to_device_node(w->ctx);               /* thread 0 may be the caller's own thread: left alone */
     for (int k = 0; k < PIN_RING; k++) { if (!g_pin[w->tid][k]) g_pin[w->tid][k] = cgx_pinned_alloc(PIN_BYTES); if (!g_pin[w->tid][k]) { w->rc = CGX_ERR_NOMEM; return NULL; } }
     const uint64_t total = w->qtext[w->nq];
@@ -1041,12 +1041,13 @@ static void *dev_write_worker(void *arg) {
         if (!count) break;
         double t0 = now_ms();
         if (cgx_text_read_wait(w->ctx, w->tid * PIN_RING + head) != CGX_OK && w->rc == CGX_OK) w->rc = CGX_ERR_HIP;
-        double t1 = now_ms(); w->wait_ms += t1 - t0;
+        double t1 = now_ms(); w->wait_ms += t1 - t0; if (w->t_first == 0) w->t_first = t1;
         if (w->rc == CGX_OK) w->rc = write_piece(w, ring[head], g_pin[w->tid][head]);
         w->write_ms += now_ms() - t1;
         head = (head + 1) % PIN_RING; count--;
         if (w->rc != CGX_OK) more = 0;                      /* on error: stop claiming, but drain the copies in flight before the buffers go away */
     }
+    w->t_end = now_ms();
     return NULL;
 }
 /* queries without any text still get their (empty) file */
@@ -1075,6 +1076,11 @@ static int write_from_device(cgx_ctx *ctx, int slot, const uint64_t *qtext, int3
     dev_write_worker(&jobs[0]);
     for (int t = 1; t < nt; t++) pthread_join(th[t], NULL);
     double wait = 0, wr = 0;
+    if (getenv("CGX_TRACE")) {
+        double tb = jobs[0].t_start, first = 0, end_min = 1e300, end_max = 0, start_max = 0;
+        for (int t = 0; t < nt; t++) { if (jobs[t].t_start - tb > start_max) start_max = jobs[t].t_start - tb; if (jobs[t].t_first - tb > first) first = jobs[t].t_first - tb; if (jobs[t].t_end - tb < end_min) end_min = jobs[t].t_end - tb; if (jobs[t].t_end - tb > end_max) end_max = jobs[t].t_end - tb; }
+        fprintf(stderr, "cgx writer: %d threads, %lld pieces, %.1f GB: last thread started at %.1f ms, last first-piece at %.1f ms, threads ended between %.1f and %.1f ms (%.1f GB/s overall); per thread: waiting for copies %.0f ms, writing files %.0f ms\n", nt, (long long)npieces, total / 1e9, start_max, first, end_min, end_max, total / 1e6 / end_max, jobs[nt > 1 ? 1 : 0].wait_ms, jobs[nt > 1 ? 1 : 0].write_ms);
+    }
     for (int t = 0; t < nt; t++) { if (jobs[t].rc != CGX_OK) return jobs[t].rc; wait += jobs[t].wait_ms; wr += jobs[t].write_ms; }
     *wait_ms = wait / nt; *file_ms = wr / nt;                /* per-thread averages; reported by the caller's thread */
     return CGX_OK;
