@@ -179,11 +179,21 @@ def main():
     fresh = bool(outroot) and args.outdir_mode != "inplace" and shutil.disk_usage(base).free >= 4 * need * (world if not args.outdir else 1)
     if args.outdir_mode == "fresh" and outroot and not fresh:
         raise SystemExit("bench.py: not enough room under %s for --outdir-mode fresh" % base)
-    import concurrent.futures, collections
+    # Unlinking an older step's 33 GB while later steps run is bench hygiene, not workload, and it is not free (it
+    # contends with the writers inside the page cache: +13 % step time).  So finished directories are kept as long as
+    # they fit in 60 % of the scratch space (shared by all ranks) and only the excess is unlinked in the background.
+    keep_live = 2
+    if fresh:
+        keep_live = max(2, int(0.6 * shutil.disk_usage(base).free / (need * (world if not args.outdir else 1))) - 1)
+    import concurrent.futures, collections, threading
     pool = concurrent.futures.ThreadPoolExecutor(max_workers=4)
     deletions = []; live = collections.deque(); stepno = [0]
 
     def unlink_many(paths):
+        try:                                                   # lowest priority: take only the CPU time the writer threads leave idle
+            os.setpriority(os.PRIO_PROCESS, threading.get_native_id(), 19)
+        except (OSError, AttributeError):
+            pass
         for p in paths:
             try:
                 os.unlink(p)
@@ -204,7 +214,7 @@ def main():
         os.mkdir(d)
         n = ex.extract_grammars_ids(host, qoff, qtok, d, first)   # returns once this step's text is laid out; the previous step's files are complete by then
         live.append(d)
-        while len(live) > 2:                                  # the newest directory is still being written, the one before it was just completed
+        while len(live) > keep_live:                                  # the newest directory is still being written, the one before it was just completed
             remove_dir_async(live.popleft())
         return n
 
@@ -290,7 +300,7 @@ def main():
                        "sentence_pairs": args.pairs, "source_tokens": int(len(corpus["str"])), "vocab": args.vocab,
                        "queries_per_gpu": int(len(qoff)), "query_tokens_per_gpu": int(len(qtok)), "parallelism": "query-shard x%d, index replicated" % world,
                        "grammar_files_written": not args.no_write, "grammar_bytes_per_step": out_bytes, "writer": "sync" if args.sync_write else "async (host threads overlap the next step; flushed before the clock stops)", "outdir": base if outroot else None,
-                       "outdir_mode": ("fresh directory per step, older ones unlinked in the background" if fresh else "one directory rewritten in place, %d untimed priming step(s)" % priming) if outroot else None},
+                       "outdir_mode": (("fresh directory per step, up to %d finished ones kept, older ones unlinked in the background" % keep_live) if fresh else "one directory rewritten in place, %d untimed priming step(s)" % priming) if outroot else None},
             "roofline": {"bound": "hbm", "kernel": "k_sa_lookup (batched SA interval search)", "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(ach / 8000.0, 4), "traffic": traffic, "algorithmic_bytes_per_launch": int(abytes), "lookups_per_launch": int(lookups),
                          "kernel_ms": round(kms, 4), "pmc_GBps": (round(traffic / (kms * 1e-3) / 1e9, 1) if traffic and kms > 0 else None),
