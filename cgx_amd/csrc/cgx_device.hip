@@ -406,1843 +406,11 @@ extern "C" double cgx_stage_ms(cgx_ctx *c, const char *name) {
     return it == c->ms.end() ? -1.0 : it->second;
 }
 
-// ------------------------------------------------------------------------------------
-// index upload
-// ------------------------------------------------------------------------------------
-static int build_tokstart(cgx_ctx *ctx, const int32_t *str, uint32_t n) {
-    // SA bucket table: suffixes are ordered by first token, so the SA interval of token c is
-    // [tokstart[c], tokstart[c+1]).  Replaces K1's O(log N) search for 1-token phrases.
-    int32_t last = 0;
-    for (uint32_t i = 0; i < n; i++) if (str[i] > last) last = str[i];
-    ctx->last = last;
-    std::vector<int32_t> ts((size_t)last + 3, 0);
-    for (uint32_t i = 0; i < n; i++) { if (str[i] < 0) { snprintf(ctx->err, sizeof ctx->err, "negative token id at %u", i); return CGX_ERR_ARG; } ts[(size_t)str[i] + 1]++; }
-    for (size_t c = 1; c < ts.size(); c++) ts[c] += ts[c - 1];
-    dfree(ctx->d_tokstart);
-    TRY(dalloc(ctx, &ctx->d_tokstart, ts.size()));
-    TRY(h2d(ctx, ctx->d_tokstart, ts.data(), ts.size()));
-    return CGX_OK;
-}
-// pair hash over the sorted lexical table: key -> LOWEST entry index (duplicate keys resolve to the first in file order)
-__global__ void k_lexhash_fill(const uint64_t *key, uint32_t n, unsigned long long *hkey, uint32_t *hidx, uint32_t mask, unsigned shift) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const unsigned long long k = key[i];
-    if (k == 0) return;                                          // a (NULL, NULL) row: never looked up, and 0 marks an empty slot
-    uint32_t slot = (uint32_t)((k * 0x9E3779B97F4A7C15ull) >> shift) & mask;
-    for (;;) { unsigned long long prev = atomicCAS(&hkey[slot], 0ull, k); if (prev == 0ull || prev == k) break; slot = (slot + 1) & mask; }
-    atomicMin(&hidx[slot], i);
-}
-__global__ void k_lexslot_fill(const uint64_t *hkey, const uint32_t *hidx, size_t cap, const float *v1, const float *v2, const float *n1, const float *n2, cgx_lexslot *slot) {
-    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (i >= cap) return;
-    cgx_lexslot e; e.key = hkey[i]; e.pad = 0; e.v1 = e.v2 = e.n1 = e.n2 = 0.0f;
-    if (e.key) { uint32_t m = hidx[i]; e.v1 = v1[m]; e.v2 = v2[m]; e.n1 = n1[m]; e.n2 = n2[m]; }
-    slot[i] = e;
-}
-__global__ void k_lexnull_fill(const int32_t *nullt, uint32_t ntgt, const float *v1, const float *n1, cgx_lexnull *out) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= ntgt) return;
-    int32_t m = nullt[i]; cgx_lexnull e; e.v1 = -1.0f; e.n1 = 0.0f;
-    if (m >= 0) { e.v1 = v1[m]; e.n1 = n1[m]; }
-    out[i] = e;
-}
-static int build_lex_hash(cgx_ctx *ctx) {
-    dfree(ctx->d_lexhkey); dfree(ctx->d_lexhidx); dfree(ctx->d_lexslot); dfree(ctx->d_lexnullv); ctx->lex_hmask = 0;
-    if (!ctx->nlex) return CGX_OK;
-    uint64_t cap = 1024; while (cap < (uint64_t)ctx->nlex * 2) cap <<= 1;
-    if (cap > (1ull << 32)) return CGX_OK;                       // too large for 32-bit slots: lookups fall back to the row search
-    TRY(dalloc(ctx, &ctx->d_lexhkey, cap)); TRY(dalloc(ctx, &ctx->d_lexhidx, cap));
-    HIPCHK(hipMemsetAsync(ctx->d_lexhkey, 0, cap * 8, ctx->stream)); HIPCHK(hipMemsetAsync(ctx->d_lexhidx, 0xFF, cap * 4, ctx->stream));
-    ctx->lex_hmask = (uint32_t)(cap - 1); ctx->lex_hshift = 64 - (unsigned)bits_for(cap - 1);
-    k_lexhash_fill<<<nblocks(ctx->nlex, 256), 256, 0, ctx->stream>>>(ctx->d_lexkey, ctx->nlex, (unsigned long long *)ctx->d_lexhkey, ctx->d_lexhidx, ctx->lex_hmask, ctx->lex_hshift);
-    TRY(dalloc(ctx, &ctx->d_lexslot, cap)); TRY(dalloc(ctx, &ctx->d_lexnullv, (size_t)ctx->lex_ntgt + 1));
-    k_lexslot_fill<<<nblocks(cap, 256), 256, 0, ctx->stream>>>(ctx->d_lexhkey, ctx->d_lexhidx, (size_t)cap, ctx->d_lexv1, ctx->d_lexv2, ctx->d_lexn1, ctx->d_lexn2, ctx->d_lexslot);
-    if (ctx->lex_ntgt) k_lexnull_fill<<<nblocks(ctx->lex_ntgt, 256), 256, 0, ctx->stream>>>(ctx->d_lexnullt, ctx->lex_ntgt, ctx->d_lexv1, ctx->d_lexn1, ctx->d_lexnullv);
-    HIPCHK(stream_wait(ctx)); HIPCHK(hipGetLastError());
-    return CGX_OK;
-}
-static cgx_lexview lex_view(const cgx_ctx *ctx) {
-    cgx_lexview t{ctx->d_lexkey, ctx->d_lexv1, ctx->d_lexv2, ctx->d_lexn1, ctx->d_lexn2, ctx->nlex, ctx->d_lexrow, ctx->d_lexnullt, ctx->lex_nrow, ctx->lex_ntgt};
-    if (ctx->lex_hmask && ctx->use_lex_hash) { t.hkey = ctx->d_lexhkey; t.hidx = ctx->d_lexhidx; t.hmask = ctx->lex_hmask; t.hshift = ctx->lex_hshift; t.hslot = ctx->d_lexslot; t.nullv = ctx->d_lexnullv; }
-    return t;
-}
-static int upload_lex(cgx_ctx *ctx, const cgx_lexkey *k, const cgx_lexval *v, uint32_t nlex) {
-    // sort rows by (src,tgt) like thrust::sort_by_key(lexFileCompare) (ExtractPair.cu:2537) and
-    // precompute -log10f of both probabilities with the host libm (bit-exact MaxLex sums).
-    std::vector<uint32_t> ord(nlex);
-    for (uint32_t i = 0; i < nlex; i++) ord[i] = i;
-    std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) {
-        return cgx_lexkey_pack(k[a].src, k[a].tgt) < cgx_lexkey_pack(k[b].src, k[b].tgt); });
-    std::vector<uint64_t> key(nlex); std::vector<float> v1(nlex), v2(nlex), n1(nlex), n2(nlex);
-    for (uint32_t i = 0; i < nlex; i++) {
-        uint32_t o = ord[i];
-        key[i] = cgx_lexkey_pack(k[o].src, k[o].tgt); v1[i] = v[o].v1; v2[i] = v[o].v2;
-        n1[i] = -log10f(v[o].v1); n2[i] = -log10f(v[o].v2);
-    }
-    TRY(dalloc(ctx, &ctx->d_lexkey, nlex)); TRY(dalloc(ctx, &ctx->d_lexv1, nlex)); TRY(dalloc(ctx, &ctx->d_lexv2, nlex));
-    TRY(dalloc(ctx, &ctx->d_lexn1, nlex)); TRY(dalloc(ctx, &ctx->d_lexn2, nlex));
-    TRY(h2d(ctx, ctx->d_lexkey, key.data(), nlex)); TRY(h2d(ctx, ctx->d_lexv1, v1.data(), nlex)); TRY(h2d(ctx, ctx->d_lexv2, v2.data(), nlex));
-    TRY(h2d(ctx, ctx->d_lexn1, n1.data(), nlex)); TRY(h2d(ctx, ctx->d_lexn2, n2.data(), nlex));
-    // row pointers per source word and the direct (NULL, tgt) table
-    uint32_t maxs = 0, maxt = 0;
-    for (uint32_t i = 0; i < nlex; i++) { uint32_t s_ = (uint32_t)(key[i] >> 32), t_ = (uint32_t)key[i]; if (s_ > maxs) maxs = s_; if (t_ > maxt) maxt = t_; }
-    ctx->lex_nrow = maxs + 1; ctx->lex_ntgt = maxt;                   // target ids 0..maxt-1 (key stores tgt+1)
-    std::vector<uint32_t> row((size_t)ctx->lex_nrow + 2, nlex); std::vector<int32_t> nullt((size_t)ctx->lex_ntgt + 1, -1);
-    for (uint32_t i = nlex; i-- > 0;) row[(size_t)(key[i] >> 32)] = i;
-    for (size_t s_ = ctx->lex_nrow; s_-- > 0;) if (row[s_] == nlex || row[s_] > row[s_ + 1]) row[s_] = row[s_ + 1];      // empty rows point at the next row
-    for (uint32_t i = 0; i < nlex && (key[i] >> 32) == 0; i++) { uint32_t t_ = (uint32_t)key[i]; if (t_ >= 1) nullt[t_ - 1] = (int32_t)i; }
-    TRY(dalloc(ctx, &ctx->d_lexrow, row.size())); TRY(h2d(ctx, ctx->d_lexrow, row.data(), row.size()));
-    TRY(dalloc(ctx, &ctx->d_lexnullt, nullt.size())); TRY(h2d(ctx, ctx->d_lexnullt, nullt.data(), nullt.size()));
-    ctx->nlex = nlex;
-    return build_lex_hash(ctx);
-}
-#define STR_PAD 32   // zero tokens after the corpus so window scans never leave the buffer
-extern "C" int cgx_upload_index(cgx_ctx *ctx, const cgx_index_host *ix) {
-    if (!ctx || !ix || !ix->str || !ix->rlp || !ix->tstr || !ix->ltar || !ix->rtar || ix->n < 4) return CGX_ERR_ARG;
-    HIPCHK(hipSetDevice(ctx->device));
-    free_batch(ctx); free_index(ctx);
-    ctx->n = ix->n; ctx->nt = ix->nt;
-    TRY(dalloc(ctx, &ctx->d_str, (size_t)ix->n + STR_PAD)); HIPCHK(hipMemsetAsync(ctx->d_str, 0, ((size_t)ix->n + STR_PAD) * 4, ctx->stream));
-    TRY(h2d(ctx, ctx->d_str, ix->str, ix->n));
-    TRY(dalloc(ctx, &ctx->d_rlp, (size_t)ix->n + STR_PAD)); HIPCHK(hipMemsetAsync(ctx->d_rlp, 0xFF, ((size_t)ix->n + STR_PAD) * 4, ctx->stream));
-    TRY(h2d(ctx, ctx->d_rlp, ix->rlp, ix->n));
-    TRY(dalloc(ctx, &ctx->d_tstr, (size_t)ix->nt + STR_PAD)); HIPCHK(hipMemsetAsync(ctx->d_tstr, 0, ((size_t)ix->nt + STR_PAD) * 4, ctx->stream));
-    TRY(h2d(ctx, ctx->d_tstr, ix->tstr, ix->nt));
-    TRY(dalloc(ctx, &ctx->d_ltar, (size_t)ix->nt + 256)); TRY(dalloc(ctx, &ctx->d_rtar, (size_t)ix->nt + 256));
-    HIPCHK(hipMemsetAsync(ctx->d_ltar, 0xFF, (size_t)ix->nt + 256, ctx->stream)); HIPCHK(hipMemsetAsync(ctx->d_rtar, 0xFF, (size_t)ix->nt + 256, ctx->stream));
-    TRY(h2d(ctx, ctx->d_ltar, ix->ltar, ix->nt)); TRY(h2d(ctx, ctx->d_rtar, ix->rtar, ix->nt));
-    TRY(upload_lex(ctx, ix->lexk, ix->lexv, ix->nlex));
-    TRY(build_tokstart(ctx, ix->str, ix->n));
-    TRY(dalloc(ctx, &ctx->d_sa, (size_t)ix->n));
-    if (ix->sa) { TRY(h2d(ctx, ctx->d_sa, ix->sa, ix->n)); ctx->have_sa = true; }
-    return CGX_OK;
-}
-
-// ------------------------------------------------------------------------------------
-// suffix array on the device: prefix doubling with rocPRIM radix sort.
-// Replaces suffixArrayInt (DC3, SuffixArray.c:51-129); a suffix array is unique, so the
-// result is identical.  The LCP tables of buildLCPTable are not needed by this design.
-// ------------------------------------------------------------------------------------
-__global__ void k_sa_keys(const uint32_t *rank, uint64_t *key, uint32_t *val, uint32_t n, uint32_t h) {
-    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint64_t second = (i + h < n) ? (uint64_t)rank[i + h] + 1 : 0;   // a suffix that ends first sorts first
-    key[i] = ((uint64_t)rank[i] << 32) | second;
-    val[i] = (uint32_t)i;
-}
-__global__ void k_sa_rank(const uint32_t *sa, const uint32_t *incl, uint32_t *rank, uint32_t n) {
-    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (i < n) rank[sa[i]] = incl[i] - 1;
-}
-__global__ void k_copy_i32_u32(const int32_t *a, uint32_t *b, uint32_t n) { size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; if (i < n) b[i] = (uint32_t)a[i]; }
-extern "C" int cgx_build_sa(cgx_ctx *ctx) {
-    if (!ctx || !ctx->d_str) return CGX_ERR_STATE;
-    HIPCHK(hipSetDevice(ctx->device));
-    Timer tm(ctx->stream);
-    uint32_t n = ctx->n;
-    uint32_t *rank = nullptr, *val = nullptr, *sa = nullptr, *flags = nullptr; uint64_t *key = nullptr, *keys = nullptr;
-    TRY(dalloc(ctx, &rank, n)); TRY(dalloc(ctx, &val, n)); TRY(dalloc(ctx, &sa, n)); TRY(dalloc(ctx, &flags, n));
-    TRY(dalloc(ctx, &key, n)); TRY(dalloc(ctx, &keys, n));
-    k_copy_i32_u32<<<nblocks(n, 256), 256, 0, ctx->stream>>>(ctx->d_str, rank, n);
-    uint32_t maxrank = (uint32_t)ctx->last;
-    int rounds = 0;
-    for (uint32_t h = 1;; h *= 2) {
-        k_sa_keys<<<nblocks(n, 256), 256, 0, ctx->stream>>>(rank, key, val, n, h);
-        unsigned hb = 32 + (unsigned)bits_for(maxrank);
-        TRY(sort_pairs(ctx, key, keys, val, sa, n, 0, hb > 64 ? 64 : hb));
-        k_head_flags<<<nblocks(n, 256), 256, 0, ctx->stream>>>(keys, flags, n);
-        TRY(incl_scan(ctx, flags, val, n));                                   // val = dense 1-based rank of each sorted suffix
-        k_sa_rank<<<nblocks(n, 256), 256, 0, ctx->stream>>>(sa, val, rank, n);
-        uint32_t top = 0; TRY(d2h(ctx, &top, val + (n - 1), 1));
-        maxrank = top - 1; rounds++;
-        if (top == n) break;
-        if (h > n) { snprintf(ctx->err, sizeof ctx->err, "suffix array did not converge"); return CGX_ERR_STATE; }
-    }
-    HIPCHK(hipMemcpyAsync(ctx->d_sa, sa, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));
-    HIPCHK(stream_wait(ctx));
-    dfree(rank); dfree(val); dfree(sa); dfree(flags); dfree(key); dfree(keys);
-    ctx->have_sa = true;
-    ctx->ms["build_sa"] = tm.stop(); ctx->ms["build_sa_rounds"] = rounds;
-    return CGX_OK;
-}
-
-// ------------------------------------------------------------------------------------
-// frequent-pair precomputation (SuffixArray.cu:1132-1340 + precomp kernel GappyLook.cu:740-870)
-// One thread per corpus position instead of one block per (a,b) pair: a coalesced sweep of
-// str with a 14-token window; hits are appended as 64-bit keys and radix-sorted by
-// (pair, start, length), exactly the order of compareUserTotal3.
-// ------------------------------------------------------------------------------------
-// Single pass: persistent blocks sweep the corpus; hits go through the per-block LDS pool (one
-// global atomic per drain) and the per-pair counts of rejected gaps through a per-block LDS
-// histogram that is added to the global one at the end.  (The first version did one global
-// atomicAdd per hit on ONE counter: 2.3e8 same-address atomics = 2.6 s of the 3.2 s index build.)
-__global__ __launch_bounds__(256) void k_precomp(cgx_view v, const int8_t *tokrank, uint32_t n, appender ap, int32_t *miss) {
-    __shared__ pool_t pool;
-    __shared__ int hist[CGX_TOP * CGX_TOP];
-    for (int k = threadIdx.x; k < CGX_TOP * CGX_TOP; k += 256) hist[k] = 0;
-    if (threadIdx.x == 0) pool.n = 0;
-    __syncthreads();
-    for (size_t base = (size_t)blockIdx.x * 256; base < n; base += (size_t)gridDim.x * 256) {   // block-uniform trip count
-        const size_t i = base + threadIdx.x;
-        int ra = -1;
-        if (i < n) { int32_t a = v.str[i]; ra = a >= 2 ? tokrank[a] : -1; }
-        if (ra >= 0 && v.str[i + 1] >= 2) {
-            for (int d = 2; d + 1 <= CGX_MAX_SPAN; d++) {            // b sits d tokens right of a; span d+1 <= 15
-                int32_t t = v.str[i + d];
-                if (t < 2) break;
-                int rb = tokrank[t];
-                if (rb < 0) continue;
-                const uint32_t pair = (uint32_t)(ra * CGX_TOP + rb);
-                if (cgx_gap_ok(v, (uint32_t)i + 1, (uint32_t)i + d - 1)) pool_put(pool, ap, ((uint64_t)pair << 36) | ((uint64_t)(uint32_t)i << 4) | (uint64_t)d);
-                else atomicAdd(&hist[pair], 1);
-            }
-        }
-        pool_drain(pool, ap, ap.pool_n / 2);
-    }
-    pool_drain(pool, ap, 0);
-    for (int k = threadIdx.x; k < CGX_TOP * CGX_TOP; k += 256) if (hist[k]) atomicAdd(&miss[k], hist[k]);
-}
-__global__ void k_precomp_unpack(const uint64_t *keys, uint32_t cnt, uint32_t *start, uint8_t *len, uint32_t *pidx) {
-    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (i >= cnt) return;
-    uint64_t k = keys[i]; uint32_t pair = (uint32_t)(k >> 36);
-    start[i] = (uint32_t)((k >> 4) & 0xFFFFFFFFu); len[i] = (uint8_t)(k & 15);
-    if (i == 0 || (uint32_t)(keys[i - 1] >> 36) != pair) pidx[2 * pair] = (uint32_t)i;
-    if (i + 1 == cnt || (uint32_t)(keys[i + 1] >> 36) != pair) pidx[2 * pair + 1] = (uint32_t)i;
-}
-static int install_freq(cgx_ctx *ctx, const int32_t *freq) {
-    std::vector<int8_t> rank((size_t)ctx->last + 2, (int8_t)-1);
-    for (int j = 0; j < CGX_TOP; j++) rank[(size_t)freq[j]] = (int8_t)j;
-    dfree(ctx->d_tokrank); dfree(ctx->d_freq);
-    TRY(dalloc(ctx, &ctx->d_tokrank, rank.size())); TRY(h2d(ctx, ctx->d_tokrank, rank.data(), rank.size()));
-    TRY(dalloc(ctx, &ctx->d_freq, CGX_TOP)); TRY(h2d(ctx, ctx->d_freq, freq, CGX_TOP));
-    memcpy(ctx->freq, freq, sizeof ctx->freq);
-    return CGX_OK;
-}
-static int build_bigrams(cgx_ctx *ctx);
-extern "C" int cgx_precompute(cgx_ctx *ctx) {
-    if (!ctx || !ctx->d_str || !ctx->d_tokstart) return CGX_ERR_STATE;
-    HIPCHK(hipSetDevice(ctx->device));
-    Timer tm(ctx->stream);
-    // top-100 tokens by (count desc, id asc), then ordered by id (SuffixArray.cu:1175-1176)
-    size_t nts = (size_t)ctx->last + 3;
-    std::vector<int32_t> ts(nts); TRY(d2h(ctx, ts.data(), ctx->d_tokstart, nts));
-    std::vector<std::pair<int32_t, int32_t>> cand;      // (count, id) for ids >= 2 including the final sentinel
-    for (int32_t c = 2; c <= ctx->last; c++) { int32_t cnt = ts[(size_t)c + 1] - ts[c]; if (cnt > 0) cand.push_back({cnt, c}); }
-    if (cand.size() < CGX_TOP) { snprintf(ctx->err, sizeof ctx->err, "fewer than %d distinct source tokens", CGX_TOP); return CGX_ERR_ARG; }
-    std::stable_sort(cand.begin(), cand.end(), [](const std::pair<int32_t, int32_t> &a, const std::pair<int32_t, int32_t> &b) { return a.first > b.first; });
-    int32_t freq[CGX_TOP];
-    for (int j = 0; j < CGX_TOP; j++) freq[j] = cand[j].second;
-    std::sort(freq, freq + CGX_TOP);
-    TRY(install_freq(ctx, freq));
-
-    cgx_view v{ctx->d_str, ctx->d_rlp, ctx->d_ltar, ctx->d_rtar, ctx->n};
-    dfree(ctx->d_miss); TRY(dalloc(ctx, &ctx->d_miss, CGX_TOP * CGX_TOP));
-    dvec64 hits; double per_item = 1.0;                       // about 0.9 hits per corpus token on Zipf text
-    int rc_reset = CGX_OK;
-    TRY(append_pass(ctx, 1, 1, ctx->n, hits, &per_item,
-        [&](uint64_t, uint64_t, appender ap) { k_precomp<<<2 * 256, 256, 0, ctx->stream>>>(v, ctx->d_tokrank, ctx->n, ap, ctx->d_miss); },
-        [&] { if (hipMemsetAsync(ctx->d_miss, 0, sizeof(int32_t) * CGX_TOP * CGX_TOP, ctx->stream) != hipSuccess) rc_reset = CGX_ERR_HIP; }));   // a rerun starts from clean miss counts
-    if (rc_reset != CGX_OK) return rc_reset;
-    if (hits.n > 0xFFFFFFF0ull) { snprintf(ctx->err, sizeof ctx->err, "too many frequent-pair occurrences"); return CGX_ERR_NOMEM; }
-    unsigned int cnt = (unsigned int)hits.n;
-    uint64_t *keys = hits.p, *skeys = nullptr; TRY(dalloc(ctx, &skeys, cnt));
-    if (cnt) TRY(sort_keys(ctx, keys, skeys, cnt, 0, 50));
-    dfree(ctx->d_pidx); dfree(ctx->d_phit_start); dfree(ctx->d_phit_len);
-    TRY(dalloc(ctx, &ctx->d_pidx, 2 * CGX_TOP * CGX_TOP)); TRY(dalloc(ctx, &ctx->d_phit_start, cnt)); TRY(dalloc(ctx, &ctx->d_phit_len, cnt));
-    std::vector<uint32_t> empty(2 * CGX_TOP * CGX_TOP);
-    for (int i = 0; i < CGX_TOP * CGX_TOP; i++) { empty[2 * i] = 1; empty[2 * i + 1] = 0; }        // empty pair = {1,0} (SuffixArray.cu:1306)
-    TRY(h2d(ctx, ctx->d_pidx, empty.data(), empty.size()));
-    if (cnt) k_precomp_unpack<<<nblocks(cnt, 256), 256, 0, ctx->stream>>>(skeys, cnt, ctx->d_phit_start, ctx->d_phit_len, ctx->d_pidx);
-    HIPCHK(stream_wait(ctx));
-    dfree(keys); dfree(skeys);
-    ctx->nphits = cnt; ctx->have_pre = true;
-    ctx->ms["precompute"] = tm.stop();
-    Timer tb(ctx->stream);
-    TRY(build_bigrams(ctx));
-    ctx->ms["bigrams"] = tb.stop();
-    return CGX_OK;
-}
-
-// ------------------------------------------------------------------------------------
-// bigram table: SA interval of every 2-token phrase of the corpus in an open-addressing hash
-// table (key = tok0<<32|tok1, linear probing).  The interval search for l = 2 - the longest
-// binary search of the reference's K2, up to log2(count of a frequent token) dependent probe
-// pairs - becomes one or two probes; longer phrases are refined inside the bigram interval.
-// Built once per index from the suffix array (runs of equal first-two-tokens are contiguous).
-// ------------------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t bigram_key_at(const int32_t *str, const int32_t *sa, uint32_t i) {
-    int32_t p = sa[i]; int32_t a = str[p], b = str[p + 1];
-    return (a >= 2 && b >= 2) ? (((uint64_t)(uint32_t)a << 32) | (uint32_t)b) : 0ull;     // 0 = not a bigram (delimiter inside)
-}
-__device__ __forceinline__ uint32_t bigram_slot(uint64_t key, unsigned shift) { return (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> shift); }
-__global__ void k_bigram_count(const int32_t *str, const int32_t *sa, uint32_t n, unsigned int *count) {
-    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    bool head = false;
-    if (i < n) { uint64_t k = bigram_key_at(str, sa, (uint32_t)i); head = k != 0 && (i == 0 || bigram_key_at(str, sa, (uint32_t)i - 1) != k); }
-    unsigned long long m = __ballot(head);
-    if (m && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)m) - 1)) atomicAdd(count, (unsigned int)__popcll(m));
-}
-__global__ void k_bigram_fill(const int32_t *str, const int32_t *sa, uint32_t n, unsigned long long *keys, uint32_t *lo, uint32_t *hi, uint32_t mask, unsigned shift) {
-    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint64_t k = bigram_key_at(str, sa, (uint32_t)i);
-    if (k == 0) return;
-    bool head = i == 0 || bigram_key_at(str, sa, (uint32_t)i - 1) != k;
-    bool tail = i + 1 == n || bigram_key_at(str, sa, (uint32_t)i + 1) != k;
-    if (!head && !tail) return;
-    uint32_t s = bigram_slot(k, shift) & mask;
-    for (;;) {                                             // claim or find the slot of this key
-        unsigned long long prev = atomicCAS(&keys[s], 0ull, (unsigned long long)k);
-        if (prev == 0ull || prev == k) break;
-        s = (s + 1) & mask;
-    }
-    if (head) lo[s] = (uint32_t)i;
-    if (tail) hi[s] = (uint32_t)i;
-}
-static int build_bigrams(cgx_ctx *ctx) {
-    dfree(ctx->d_bg_key); dfree(ctx->d_bg_lo); dfree(ctx->d_bg_hi); ctx->bg_cap = 0;
-    unsigned int *cnt = nullptr; TRY(dalloc(ctx, &cnt, 1)); HIPCHK(hipMemsetAsync(cnt, 0, 4, ctx->stream));
-    k_bigram_count<<<nblocks(ctx->n, 256), 256, 0, ctx->stream>>>(ctx->d_str, ctx->d_sa, ctx->n, cnt);
-    unsigned int distinct = 0; TRY(d2h(ctx, &distinct, cnt, 1)); dfree(cnt);
-    uint64_t cap = 1024; while (cap < (uint64_t)distinct * 2) cap <<= 1;
-    if (cap > (1ull << 31)) { snprintf(ctx->err, sizeof ctx->err, "bigram table too large"); return CGX_ERR_NOMEM; }
-    ctx->bg_cap = (uint32_t)cap; ctx->bg_shift = 64 - (unsigned)bits_for(cap - 1);
-    TRY(dalloc(ctx, &ctx->d_bg_key, cap)); TRY(dalloc(ctx, &ctx->d_bg_lo, cap)); TRY(dalloc(ctx, &ctx->d_bg_hi, cap));
-    HIPCHK(hipMemsetAsync(ctx->d_bg_key, 0, cap * 8, ctx->stream));
-    k_bigram_fill<<<nblocks(ctx->n, 256), 256, 0, ctx->stream>>>(ctx->d_str, ctx->d_sa, ctx->n, (unsigned long long *)ctx->d_bg_key, ctx->d_bg_lo, ctx->d_bg_hi, (uint32_t)(cap - 1), ctx->bg_shift);
-    HIPCHK(stream_wait(ctx)); HIPCHK(hipGetLastError());
-    ctx->ms["bigrams_distinct"] = distinct;
-    return CGX_OK;
-}
-
-// ------------------------------------------------------------------------------------
-// multi-GPU replica plumbing
-// ------------------------------------------------------------------------------------
-struct bufdesc { const char *name; void **ptr; uint64_t bytes; };
-static std::vector<bufdesc> index_buffers(cgx_ctx *c) {
-    std::vector<bufdesc> b;
-    b.push_back({"str", (void **)&c->d_str, ((uint64_t)c->n + STR_PAD) * 4});
-    b.push_back({"sa", (void **)&c->d_sa, (uint64_t)c->n * 4});
-    b.push_back({"rlp", (void **)&c->d_rlp, ((uint64_t)c->n + STR_PAD) * 4});
-    b.push_back({"tstr", (void **)&c->d_tstr, ((uint64_t)c->nt + STR_PAD) * 4});
-    b.push_back({"ltar", (void **)&c->d_ltar, (uint64_t)c->nt + 256});
-    b.push_back({"rtar", (void **)&c->d_rtar, (uint64_t)c->nt + 256});
-    b.push_back({"lexkey", (void **)&c->d_lexkey, (uint64_t)c->nlex * 8});
-    b.push_back({"lexv1", (void **)&c->d_lexv1, (uint64_t)c->nlex * 4});
-    b.push_back({"lexv2", (void **)&c->d_lexv2, (uint64_t)c->nlex * 4});
-    b.push_back({"lexn1", (void **)&c->d_lexn1, (uint64_t)c->nlex * 4});
-    b.push_back({"lexn2", (void **)&c->d_lexn2, (uint64_t)c->nlex * 4});
-    b.push_back({"lexrow", (void **)&c->d_lexrow, ((uint64_t)c->lex_nrow + 2) * 4});
-    b.push_back({"lexnullt", (void **)&c->d_lexnullt, ((uint64_t)c->lex_ntgt + 1) * 4});
-    b.push_back({"tokstart", (void **)&c->d_tokstart, ((uint64_t)c->last + 3) * 4});
-    b.push_back({"tokrank", (void **)&c->d_tokrank, (uint64_t)c->last + 2});
-    b.push_back({"freq", (void **)&c->d_freq, CGX_TOP * 4});
-    b.push_back({"pidx", (void **)&c->d_pidx, 2 * CGX_TOP * CGX_TOP * 4});
-    b.push_back({"miss", (void **)&c->d_miss, CGX_TOP * CGX_TOP * 4});
-    b.push_back({"phit_start", (void **)&c->d_phit_start, (uint64_t)c->nphits * 4});
-    b.push_back({"phit_len", (void **)&c->d_phit_len, (uint64_t)c->nphits});
-    b.push_back({"bg_key", (void **)&c->d_bg_key, (uint64_t)c->bg_cap * 8});
-    b.push_back({"bg_lo", (void **)&c->d_bg_lo, (uint64_t)c->bg_cap * 4});
-    b.push_back({"bg_hi", (void **)&c->d_bg_hi, (uint64_t)c->bg_cap * 4});
-    return b;
-}
-extern "C" int cgx_index_shape(cgx_ctx *ctx, cgx_index_dims *d) {
-    if (!ctx || !d) return CGX_ERR_ARG;
-    d->n = ctx->n; d->nt = ctx->nt; d->nlex = ctx->nlex; d->nphits = ctx->nphits; d->last = ctx->last; d->lex_nrow = ctx->lex_nrow; d->lex_ntgt = ctx->lex_ntgt; d->bigram_cap = ctx->bg_cap;
-    return CGX_OK;
-}
-extern "C" int cgx_index_alloc(cgx_ctx *ctx, const cgx_index_dims *d) {
-    if (!ctx || !d) return CGX_ERR_ARG;
-    HIPCHK(hipSetDevice(ctx->device));
-    free_batch(ctx); free_index(ctx);
-    ctx->n = d->n; ctx->nt = d->nt; ctx->nlex = d->nlex; ctx->nphits = d->nphits; ctx->last = d->last; ctx->lex_nrow = d->lex_nrow; ctx->lex_ntgt = d->lex_ntgt; ctx->bg_cap = d->bigram_cap; ctx->bg_shift = d->bigram_cap ? 64 - (unsigned)bits_for((uint64_t)d->bigram_cap - 1) : 0;
-    for (auto &b : index_buffers(ctx)) TRY(dalloc_bytes(ctx, b.ptr, b.bytes ? b.bytes : 1));
-    return CGX_OK;
-}
-extern "C" int cgx_index_nbuffers(cgx_ctx *ctx) { return ctx ? (int)index_buffers(ctx).size() : CGX_ERR_ARG; }
-extern "C" int cgx_index_buffer(cgx_ctx *ctx, int i, const char **name, uint64_t *nbytes) {
-    if (!ctx) return CGX_ERR_ARG;
-    auto b = index_buffers(ctx);
-    if (i < 0 || i >= (int)b.size()) return CGX_ERR_ARG;
-    if (name) *name = b[i].name;
-    if (nbytes) *nbytes = b[i].bytes;
-    return CGX_OK;
-}
-extern "C" int cgx_index_d2d(cgx_ctx *ctx, int i, void *dptr, int dir) {
-    if (!ctx || !dptr) return CGX_ERR_ARG;
-    HIPCHK(hipSetDevice(ctx->device));
-    auto b = index_buffers(ctx);
-    if (i < 0 || i >= (int)b.size() || !*b[i].ptr) return CGX_ERR_ARG;
-    if (b[i].bytes == 0) return CGX_OK;
-    if (dir == 0) HIPCHK(hipMemcpyAsync(dptr, *b[i].ptr, b[i].bytes, hipMemcpyDeviceToDevice, ctx->stream));
-    else HIPCHK(hipMemcpyAsync(*b[i].ptr, dptr, b[i].bytes, hipMemcpyDeviceToDevice, ctx->stream));
-    HIPCHK(stream_wait(ctx));
-    return CGX_OK;
-}
-extern "C" int cgx_index_finalize(cgx_ctx *ctx) {
-    if (!ctx || !ctx->d_freq) return CGX_ERR_STATE;
-    TRY(d2h(ctx, ctx->freq, ctx->d_freq, CGX_TOP));
-    ctx->have_sa = ctx->have_pre = true;
-    return build_lex_hash(ctx);                               // derived data: rebuilt on the replica instead of being shipped
-}
-
-
-// one-time broadcast of the whole index over xGMI with RCCL.  librccl is loaded on demand so
-// that single-GPU use never pays for it.
-#include <dlfcn.h>
-typedef int (*nccl_bcast_fn)(const void *, void *, size_t, int, int, void *, hipStream_t);
-typedef int (*nccl_group_fn)(void);
-extern "C" int cgx_broadcast_index(cgx_ctx *ctx, void *nccl_comm, int root, int rank) {
-    if (!ctx || !nccl_comm) return CGX_ERR_ARG;
-    HIPCHK(hipSetDevice(ctx->device));
-    static void *lib = nullptr; static nccl_bcast_fn bcast = nullptr; static nccl_group_fn gstart = nullptr, gend = nullptr;
-    if (!lib) {
-        lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-        if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-        if (!lib) { snprintf(ctx->err, sizeof ctx->err, "cannot load librccl: %s", dlerror()); return CGX_ERR_STATE; }
-        bcast = (nccl_bcast_fn)dlsym(lib, "ncclBroadcast"); gstart = (nccl_group_fn)dlsym(lib, "ncclGroupStart"); gend = (nccl_group_fn)dlsym(lib, "ncclGroupEnd");
-        if (!bcast || !gstart || !gend) { snprintf(ctx->err, sizeof ctx->err, "librccl lacks ncclBroadcast"); return CGX_ERR_STATE; }
-    }
-    auto bufs = index_buffers(ctx);
-    for (auto &b : bufs) if (!*b.ptr) { snprintf(ctx->err, sizeof ctx->err, "index buffer %s not allocated (call cgx_index_alloc on non-root ranks)", b.name); return CGX_ERR_STATE; }
-    if (gstart() != 0) return fail(ctx, CGX_ERR_HIP, "ncclGroupStart", hipSuccess);
-    for (auto &b : bufs) if (b.bytes && bcast(*b.ptr, *b.ptr, (size_t)b.bytes, /*ncclUint8*/ 1, root, nccl_comm, ctx->stream) != 0) return fail(ctx, CGX_ERR_HIP, "ncclBroadcast", hipSuccess);
-    if (gend() != 0) return fail(ctx, CGX_ERR_HIP, "ncclGroupEnd", hipSuccess);
-    HIPCHK(stream_wait(ctx));
-    if (rank != root) return cgx_index_finalize(ctx);
-    return CGX_OK;
-}
-
-// ------------------------------------------------------------------------------------
-// queries
-// ------------------------------------------------------------------------------------
-#define QPAD 16
-extern "C" int cgx_upload_queries(cgx_ctx *ctx, const int32_t *qoff, int32_t nq, const int32_t *qtok, int32_t ntok) {
-    if (!ctx || nq < 0 || ntok < 0 || (nq && !qoff) || (ntok && !qtok)) return CGX_ERR_ARG;
-    HIPCHK(hipSetDevice(ctx->device));
-    free_batch(ctx);
-    ctx->nq = nq; ctx->ntok = ntok;
-    std::vector<int32_t> off((size_t)nq + 1), t2q((size_t)ntok + 1), tok((size_t)ntok + QPAD, -1);
-    for (int32_t q = 0; q < nq; q++) off[q] = qoff[q];
-    off[nq] = ntok;
-    for (int32_t q = 0; q < nq; q++) {
-        if (off[q] > off[q + 1] || off[q] < 0) { snprintf(ctx->err, sizeof ctx->err, "query offsets not monotone at %d", q); return CGX_ERR_ARG; }
-        for (int32_t t = off[q]; t < off[q + 1]; t++) t2q[t] = q;
-    }
-    for (int32_t t = 0; t < ntok; t++) { tok[t] = qtok[t]; if (qtok[t] > ctx->last || qtok[t] < -1 || qtok[t] == 0 || qtok[t] == 1) tok[t] = -1; }
-    TRY(dalloc(ctx, &ctx->d_qoff, off.size())); TRY(h2d(ctx, ctx->d_qoff, off.data(), off.size()));
-    TRY(dalloc(ctx, &ctx->d_tok2q, t2q.size())); TRY(h2d(ctx, ctx->d_tok2q, t2q.data(), t2q.size()));
-    TRY(dalloc(ctx, &ctx->d_qtok, tok.size())); TRY(h2d(ctx, ctx->d_qtok, tok.data(), tok.size()));
-    ctx->h_qoff = off; ctx->h_tok2q = t2q;
-    return CGX_OK;
-}
-
-// ------------------------------------------------------------------------------------
-// batched SA interval search (replaces K1 + K2, SuffixArray.cu:402-767 and 109-400).
-// One lane per query token.  l = 1 comes from the bucket table; for l = 2..5 the interval of
-// q[t..t+l) is found inside the interval of q[t..t+l-1) by comparing ONE corpus token per
-// probe (str[sa[m] + l-1]); lower and upper bound run in the same loop so each lane keeps
-// two independent gather chains in flight.  The block's query tokens are staged in LDS.
-// Result layout: lm[t] = min(longestmatch, 5); up/down[t*5 + l-1], -1 when l > lm.
-// ------------------------------------------------------------------------------------
-#define LOOK_BS 256
-__global__ __launch_bounds__(LOOK_BS) void k_sa_lookup(const int32_t *__restrict__ str, const int32_t *__restrict__ sa,
-        const int32_t *__restrict__ tokstart, const uint64_t *__restrict__ bg_key, const uint32_t *__restrict__ bg_lo, const uint32_t *__restrict__ bg_hi,
-        uint32_t bg_mask, unsigned bg_shift, const int32_t *__restrict__ qtok, const int32_t *__restrict__ qoff,
-        const int32_t *__restrict__ tok2q, int32_t ntok, int k1_limit,
-        int32_t *__restrict__ lm, int32_t *__restrict__ up, int32_t *__restrict__ down) {
-    __shared__ int32_t s_tok[LOOK_BS + 8];
-    const int32_t base = (int32_t)(blockIdx.x * LOOK_BS);
-    for (int i = threadIdx.x; i < LOOK_BS + 8; i += LOOK_BS) s_tok[i] = base + i < ntok + QPAD ? qtok[base + i] : -1;   // qtok is padded with -1
-    __syncthreads();
-    const int32_t t = base + (int32_t)threadIdx.x;
-    if (t >= ntok) return;
-    int32_t r_up[5], r_dn[5];
-#pragma unroll
-    for (int l = 0; l < 5; l++) { r_up[l] = -1; r_dn[l] = -1; }
-    int len = 0;
-    const int32_t q = tok2q[t], qs = qoff[q], qe = qoff[q + 1];
-    const int32_t c0 = s_tok[threadIdx.x];
-    if (c0 >= 2 && t - qs < k1_limit) {
-        int32_t lo = tokstart[c0], hi = tokstart[c0 + 1] - 1;
-        if (lo <= hi) {
-            r_up[0] = lo; r_dn[0] = hi; len = 1;
-            int l = 1;
-            if (bg_key && t + 1 < qe && s_tok[threadIdx.x + 1] >= 2) {      // l = 2 from the bigram table
-                const uint64_t key = ((uint64_t)(uint32_t)c0 << 32) | (uint32_t)s_tok[threadIdx.x + 1];
-                uint32_t s = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> bg_shift) & bg_mask;
-                uint64_t k = bg_key[s];
-                while (k != 0 && k != key) { s = (s + 1) & bg_mask; k = bg_key[s]; }
-                if (k == key) { lo = (int32_t)bg_lo[s]; hi = (int32_t)bg_hi[s]; r_up[1] = lo; r_dn[1] = hi; len = 2; l = 2; }
-                else l = 5;                                                  // the bigram does not occur: longestmatch = 1
-            }
-            for (; l < 5; l++) {
-                if (t + l >= qe) break;
-                const int32_t c = s_tok[threadIdx.x + l];
-                if (c < 2) break;
-                // first m in [lo,hi+1) with tok(m) >= c, and first with tok(m) > c; both searches advance together
-                int32_t a0 = lo, z0 = hi + 1, a1 = lo, z1 = hi + 1;
-                while (a0 < z0 || a1 < z1) {
-                    int32_t m0 = (a0 + z0) >> 1, m1 = (a1 + z1) >> 1;
-                    int32_t p0 = a0 < z0 ? sa[m0] : 0, p1 = a1 < z1 ? sa[m1] : 0;
-                    int32_t t0 = str[p0 + l], t1 = str[p1 + l];
-                    if (a0 < z0) { if (t0 < c) a0 = m0 + 1; else z0 = m0; }
-                    if (a1 < z1) { if (t1 <= c) a1 = m1 + 1; else z1 = m1; }
-                }
-                if (a0 >= a1) break;
-                lo = a0; hi = a1 - 1;
-                r_up[l] = lo; r_dn[l] = hi; len = l + 1;
-            }
-        }
-    }
-    lm[t] = len;
-#pragma unroll
-    for (int l = 0; l < 5; l++) { up[(size_t)t * 5 + l] = r_up[l]; down[(size_t)t * 5 + l] = r_dn[l]; }
-}
-extern "C" int cgx_sa_lookup(cgx_ctx *ctx) {
-    if (!ctx || !ctx->have_sa || !ctx->d_qtok) return CGX_ERR_STATE;
-    HIPCHK(hipSetDevice(ctx->device));
-    Timer tm(ctx->stream);
-    int32_t T = ctx->ntok;
-    dfree(ctx->d_lm); dfree(ctx->d_up); dfree(ctx->d_down);
-    TRY(dalloc(ctx, &ctx->d_lm, (size_t)T + 1)); TRY(dalloc(ctx, &ctx->d_up, (size_t)T * 5 + 1)); TRY(dalloc(ctx, &ctx->d_down, (size_t)T * 5 + 1));
-    if (T > 0) {
-        // kernel-exact timing: the events are attached to the dispatch itself (hipExtLaunchKernelGGL),
-        // so the figure is the kernel's own duration, the quantity rocprofv3 --kernel-trace reports
-        hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
-        hipExtLaunchKernelGGL(k_sa_lookup, dim3(nblocks(T, LOOK_BS)), dim3(LOOK_BS), 0, ctx->stream, a, b, 0,
-                              ctx->d_str, ctx->d_sa, ctx->d_tokstart, ctx->use_bigrams ? ctx->d_bg_key : nullptr, ctx->d_bg_lo, ctx->d_bg_hi,
-                              ctx->bg_cap ? ctx->bg_cap - 1 : 0, ctx->bg_shift, ctx->d_qtok, ctx->d_qoff,
-                              ctx->d_tok2q, T, ctx->k1_limit, ctx->d_lm, ctx->d_up, ctx->d_down);
-        HIPCHK(hipEventSynchronize(b));
-        float ms = 0; HIPCHK(hipEventElapsedTime(&ms, a, b)); ctx->ms["sa_lookup_kernel"] = ms;
-        (void)hipEventDestroy(a); (void)hipEventDestroy(b);
-        HIPCHK(hipGetLastError());
-    }
-    ctx->ms["sa_lookup"] = tm.stop();
-    return CGX_OK;
-}
-
-// ------------------------------------------------------------------------------------
-// one-gap enumeration (oneGapEnumeration, SuffixArray.cu:928-1039): count -> scan -> fill,
-// so the candidate list comes out in (token, a_len, b start, b_len) order without atomics.
-// ------------------------------------------------------------------------------------
-template <bool FILL>
-__global__ void k_enum1(const int32_t *qtok, const int32_t *qoff, const int32_t *tok2q, const int32_t *lm, int32_t ntok,
-                        uint32_t *count, const uint64_t *offset, cgx_gappy *g, cgx_gappat *p) {
-    int32_t t = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (t >= ntok) return;
-    uint32_t n = 0; uint64_t o = FILL ? offset[t] : 0;
-    int32_t end = qoff[tok2q[t] + 1];
-    if (t < ntok - 1 && t != end - 1 && t != end - 2) {
-        int lms = lm[t];
-        for (int al = 1; al <= lms && al + 2 <= CGX_MAX_SYMBOLS; al++) {
-            for (int32_t s = t + al + 1; s < end && s - t <= CGX_MAX_SPAN; s++) {
-                if (qtok[s] == -1) continue;
-                int lme = lm[s];
-                for (int bl = 1; al + 1 + bl <= CGX_MAX_SYMBOLS && bl <= lme && s - t + bl - 1 <= CGX_MAX_SPAN; bl++) {
-                    if (FILL) {
-                        cgx_gappy gg; gg.qrystart = t; gg.a_len = (uint8_t)al; gg.b_len = (uint8_t)bl; gg.gap = (uint8_t)(s - t - al);
-                        cgx_gappat pp; int num = al + 1 + bl;
-                        for (int i = 0; i < 5; i++) pp.pat[i] = i >= num ? -2 : i < al ? qtok[t + i] : i == al ? -1 : qtok[s + i - 1 - al];
-                        pp.number = (uint8_t)num;
-                        g[o + n] = gg; p[o + n] = pp;
-                    }
-                    n++;
-                }
-            }
-        }
-    }
-    if (!FILL) count[t] = n;
-}
-// 128-bit sort key of a pattern: number, then the five symbols (pad -2 -> 0, gap -1 -> 1, token c -> c)
-__global__ void k_pat_keys(const cgx_gappat *p, uint32_t n, int w, uint64_t *hi, uint64_t *lo) {
-    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    cgx_gappat x = p[i];
-    uint64_t h = 0, l = x.number;                         // 128-bit value (h:l), symbols appended w bits at a time
-    for (int j = 0; j < 5; j++) {
-        uint32_t s = x.pat[j] == -2 ? 0u : x.pat[j] == -1 ? 1u : (uint32_t)x.pat[j];
-        h = (h << w) | (l >> (64 - w)); l = (l << w) | s;
-    }
-    hi[i] = h; lo[i] = l;
-}
-__global__ void k_flags128(const uint64_t *hi, const uint64_t *lo, uint32_t *flags, uint32_t n) {
-    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (i < n) flags[i] = (i == 0 || hi[i] != hi[i - 1] || lo[i] != lo[i - 1]) ? 1u : 0u;
-}
-__global__ void k_make_s1(const cgx_gappy *g, const uint32_t *flags, const uint32_t *incl, uint32_t n, uint32_t *pid, cgx_gapsearch *s1) {
-    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint32_t id = incl[i] - 1; pid[i] = id;
-    if (flags[i]) {
-        cgx_gappy x = g[i]; cgx_gapsearch s;
-        s.qrystart = x.qrystart; s.a_len = x.a_len; s.b_len = x.b_len; s.gap = x.gap; s.position = (uint32_t)i; s.sa_start = -1; s.sa_end = -1; s.marker = 0;
-        s1[id] = s;
-    }
-}
-template <class T> __global__ void k_permute(const T *src, const uint32_t *perm, T *dst, uint32_t n) {
-    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; if (i < n) dst[i] = src[perm[i]];
-}
-
-
-// open-addressing hash (u64 key != 0 -> u32), linear probing, filled once per batch and then read-only
-__device__ __forceinline__ uint32_t h64_slot(uint64_t key, unsigned shift) { return (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> shift); }
-__device__ __forceinline__ void h64_insert(unsigned long long *keys, uint32_t *vals, uint32_t mask, unsigned shift, uint64_t key, uint32_t val) {
-    uint32_t s = h64_slot(key, shift) & mask;
-    for (;;) { unsigned long long prev = atomicCAS(&keys[s], 0ull, (unsigned long long)key); if (prev == 0ull || prev == key) break; s = (s + 1) & mask; }
-    vals[s] = val;
-}
-__device__ __forceinline__ bool h64_find(const uint64_t *keys, const uint32_t *vals, uint32_t mask, unsigned shift, uint64_t key, uint32_t *val) {
-    uint32_t s = h64_slot(key, shift) & mask;
-    for (;;) { uint64_t k = keys[s]; if (k == key) { *val = vals[s]; return true; } if (k == 0) return false; s = (s + 1) & mask; }
-}
-struct h64 { uint64_t *keys; uint32_t *vals; uint32_t mask; unsigned shift; };
-
-// ------------------------------------------------------------------------------------
-// one-gap lookup (oneGapLookUpSA, GappyLook.cu:128-474), inverted.
-// The reference scans, for EVERY distinct pattern aXb, the whole occurrence list of its rarer
-// side (one CUDA block per pattern).  Here the patterns are first grouped by the phrase they
-// would scan from: every occurrence of a driving phrase is visited ONCE, its <= 13-token window
-// is walked once, and each window token is looked up (binary search) among the group's
-// patterns keyed by the first token of their other side.  The hit set per pattern is the same
-// set {(start,len)} whichever side drives (the reference's three strategies are equivalent),
-// and the result is sorted on the full record afterwards, so the output is unchanged while the
-// work drops from sum_patterns |driver list| to sum_distinct-drivers |driver list|.
-//   record key: mode(1) | driver SA start(32) | driver length(3) | other side's first token(w<=25)
-// Frequent-pair "marker" patterns (single frequent a and b) keep the reference's one-record
-// representation pointing at the precomputed list (GappyLook.cu:258-272).
-// ------------------------------------------------------------------------------------
-__device__ __forceinline__ int pre_index_dev(const int8_t *tokrank, int32_t a, int32_t b) {
-    int ra = tokrank[a], rb = tokrank[b];
-    return (ra >= 0 && rb >= 0) ? ra * CGX_TOP + rb : -1;
-}
-#define REC_TOKBITS 25
-__global__ void k_plan1(cgx_gapsearch *s1, uint32_t d1, const int32_t *qtok, const int32_t *lm, const int32_t *up, const int32_t *down,
-                        const int8_t *tokrank, const uint32_t *pidx, uint64_t *reckey, uint32_t *recpid, unsigned int *nrec,
-                        uint64_t *markkey, unsigned int *nmark) {
-    uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
-    bool isrec = false, ismark = false; uint64_t key = 0, mkey = 0;
-    if (id < d1) {
-        cgx_gapsearch s = s1[id];
-        int al = s.a_len, bl = s.b_len; int32_t t = s.qrystart, sb = t + s.gap + al;
-        if (s.gap != 0 && t >= 0 && lm[sb] >= bl && lm[t] >= al) {
-            int pre = pre_index_dev(tokrank, qtok[t + al - 1], qtok[sb]);
-            if (pre != -1 && al == 1 && bl == 1) {
-                if ((int64_t)pidx[2 * pre + 1] - (int64_t)pidx[2 * pre] >= 0) { ismark = true; mkey = ((uint64_t)id << 36) | ((uint64_t)(uint32_t)pre << 4); s1[id].marker = 1; }
-            } else {
-                int64_t u1 = up[(size_t)t * 5 + al - 1], e1 = down[(size_t)t * 5 + al - 1], u2 = up[(size_t)sb * 5 + bl - 1], e2 = down[(size_t)sb * 5 + bl - 1];
-                isrec = true;
-                if (e1 - u1 <= e2 - u2) key = (0ull << 63) | ((uint64_t)(uint32_t)u1 << (3 + REC_TOKBITS)) | ((uint64_t)al << REC_TOKBITS) | (uint64_t)(uint32_t)qtok[sb];
-                else key = (1ull << 63) | ((uint64_t)(uint32_t)u2 << (3 + REC_TOKBITS)) | ((uint64_t)bl << REC_TOKBITS) | (uint64_t)(uint32_t)qtok[t + al - 1];
-            }
-        }
-    }
-    uint32_t slot = wave_append(nrec, isrec);
-    if (isrec) { reckey[slot] = key; recpid[slot] = id; }
-    slot = wave_append(nmark, ismark);
-    if (ismark) markkey[slot] = mkey;
-}
-struct grp1 { uint32_t rec0, rec1; uint32_t base; uint32_t len; uint32_t backward; };   // records [rec0,rec1), driver SA interval start, phrase length
-__global__ void k_groups1(const uint64_t *reckey, const uint32_t *flags, const uint32_t *incl, uint32_t nrec, grp1 *groups) {
-    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (i >= nrec) return;
-    uint32_t g = incl[i] - 1;
-    if (flags[i]) { uint64_t k = reckey[i]; groups[g].rec0 = (uint32_t)i; groups[g].base = (uint32_t)((k >> (3 + REC_TOKBITS)) & 0xFFFFFFFFu); groups[g].len = (uint32_t)((k >> REC_TOKBITS) & 7); groups[g].backward = (uint32_t)(k >> 63); }
-    if (i + 1 == nrec || flags[i + 1]) groups[g].rec1 = (uint32_t)i + 1;
-}
-__global__ void k_grpflags1(const uint64_t *reckey, uint32_t *flags, uint32_t nrec) {
-    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (i < nrec) flags[i] = (i == 0 || (reckey[i] >> REC_TOKBITS) != (reckey[i - 1] >> REC_TOKBITS)) ? 1u : 0u;
-}
-__global__ void k_grpwork1(const grp1 *groups, uint32_t ng, const uint32_t *grp_down, uint64_t *work) {
-    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g < ng) work[g] = (uint64_t)grp_down[g] - groups[g].base + 1;
-}
-// SA interval end of each group's driving phrase: taken from any of its patterns
-__global__ void k_grpdown1(const grp1 *groups, uint32_t ng, const uint32_t *recpid, const cgx_gapsearch *s1, const int32_t *down, uint32_t *grp_down) {
-    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= ng) return;
-    cgx_gapsearch s = s1[recpid[groups[g].rec0]];
-    grp_down[g] = groups[g].backward ? (uint32_t)down[(size_t)(s.qrystart + s.gap + s.a_len) * 5 + s.b_len - 1] : (uint32_t)down[(size_t)s.qrystart * 5 + s.a_len - 1];
-}
-#define HITKEY(id, start, len) (((uint64_t)(id) << 36) | ((uint64_t)(uint32_t)(start) << 4) | (uint64_t)(len))
-// (group, first token of the other side) -> first record with that token, so that a window token costs one probe
-__global__ void k_rechash_fill(const uint64_t *reckey, const uint32_t *incl, uint32_t nrec, h64 H) {
-    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (i >= nrec) return;
-    if (i == 0 || reckey[i] != reckey[i - 1]) {
-        uint64_t key = (((uint64_t)(incl[i] - 1) << REC_TOKBITS) | (reckey[i] & ((1u << REC_TOKBITS) - 1))) + 1;
-        h64_insert((unsigned long long *)H.keys, H.vals, H.mask, H.shift, key, (uint32_t)i);
-    }
-}
-// first record of [r0,r1) whose other-side first token is >= tk
-__device__ __forceinline__ uint32_t rec_lower(const uint64_t *reckey, uint32_t r0, uint32_t r1, uint32_t tk) {
-    while (r0 < r1) { uint32_t m = (r0 + r1) >> 1; if ((uint32_t)(reckey[m] & ((1u << REC_TOKBITS) - 1)) < tk) r0 = m + 1; else r1 = m; }
-    return r0;
-}
-// One block = one tile of L1_TILE occurrences of ONE group's driving phrase.  The group's pattern
-// records (other side's tokens, pattern id) are staged in LDS with a small hash on the first token,
-// so that walking a window costs LDS probes only; global memory is touched for the SA slice
-// (coalesced), the text window, the alignment words of the gap (same stride as the window) and,
-// for candidates whose tokens match, the target-side tightness test.  The gap's target span is
-// accumulated while the window is walked (cgx_gap_ok restated incrementally: start/end token
-// aligned, span < 15, tight) instead of being rebuilt per candidate.
-// Groups with more than L1_REC records (or an over-long other side) take the same walk with the
-// records read from global memory through the batch-wide hash.
-#define L1_TILE 1024
-#define L1_REC 256
-#define L1_SLOTS 512
-#define L1_EMPTY 0xFFFFFFFFu
-// cgx_tight for a target span of at most 16 words (te - ts <= 15): both byte tables are read
-// with five aligned dword loads each instead of a byte per word (the tables are padded).
-__device__ __forceinline__ bool tight16(const cgx_view &v, int ts, int te, int s_chk, int e_chk, int src0) {
-    const uint32_t *pl = (const uint32_t *)(v.ltar + (ts & ~3)), *pr = (const uint32_t *)(v.rtar + (ts & ~3));
-    uint32_t a[5], b[5];
-#pragma unroll
-    for (int i = 0; i < 5; i++) { a[i] = pl[i]; b[i] = pr[i]; }
-    const unsigned sh = (unsigned)ts & 3u;
-    int lo = 255, hi = 0; const int last = te - ts;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const uint32_t l4 = __builtin_amdgcn_alignbyte(a[i + 1], a[i], sh), r4 = __builtin_amdgcn_alignbyte(b[i + 1], b[i], sh);
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int L = (int)((l4 >> (8 * k)) & 0xFF), R = (int)((r4 >> (8 * k)) & 0xFF);
-            if (4 * i + k <= last && L != 255 && R != 255) { if (lo > L) lo = L; if (hi < R) hi = R; }
-        }
-    }
-    return src0 + lo == s_chk && src0 + hi == e_chk;
-}
-// 16 consecutive text tokens and their alignment words starting at the first gap token and
-// running away from the driving phrase (ascending addresses when walking right, descending when
-// walking left), fetched with wide loads in one go.  The arrays are padded past the corpus end;
-// only a window that would start before token 0 takes the guarded path.
-__device__ __forceinline__ void load_window(const cgx_view &v, int64_t edge, bool bw, int32_t (&ws)[16], uint32_t (&wr)[16]) {
-    const int64_t base = bw ? edge - 15 : edge;
-    if (base >= 0) {
-#pragma unroll
-        for (int j = 0; j < 16; j++) { ws[j] = v.str[base + j]; wr[j] = v.rlp[base + j]; }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 16; j++) { const int64_t q = base + j; ws[j] = q >= 0 ? v.str[q] : 0; wr[j] = q >= 0 ? v.rlp[q] : 0xFFFFFFFFu; }
-    }
-    if (bw) {
-#pragma unroll
-        for (int j = 0; j < 8; j++) { int32_t t = ws[j]; ws[j] = ws[15 - j]; ws[15 - j] = t; uint32_t u = wr[j]; wr[j] = wr[15 - j]; wr[15 - j] = u; }
-    }
-}
-struct l1rec { uint32_t tok, id; int32_t extra[2]; uint32_t olen; };
-__device__ __forceinline__ l1rec l1_load(const grp1 &gr, uint32_t r, const uint64_t *reckey, const uint32_t *recpid, const cgx_gapsearch *s1, const int32_t *qtok) {
-    l1rec o; o.tok = (uint32_t)(reckey[r] & ((1u << REC_TOKBITS) - 1)); o.id = recpid[r];
-    cgx_gapsearch s = s1[o.id];
-    o.extra[0] = o.extra[1] = -1;
-    if (!gr.backward) { o.olen = (uint32_t)s.b_len; const int32_t sb = s.qrystart + s.gap + s.a_len; for (uint32_t k = 1; k < o.olen && k < 3; k++) o.extra[k - 1] = qtok[sb + k]; }
-    else { o.olen = (uint32_t)s.a_len; const int32_t t = s.qrystart; for (uint32_t k = 1; k < o.olen && k < 3; k++) o.extra[k - 1] = qtok[t + (int)o.olen - 1 - (int)k]; }
-    return o;
-}
-__global__ __launch_bounds__(256) void k_look1(cgx_view v, const int32_t *sa, const cgx_gapsearch *s1, const grp1 *groups, const uint64_t *toff, const uint64_t *work, uint32_t ng,
-                        uint64_t tile0, const int32_t *qtok, const uint64_t *reckey, const uint32_t *recpid, h64 H, appender ap, uint32_t rec_cap) {
-    __shared__ pool_t pool;
-    __shared__ l1rec recs[L1_REC];
-    __shared__ uint32_t hkey[L1_SLOTS];
-    __shared__ uint16_t hval[L1_SLOTS];
-    __shared__ int s_big;
-    const uint64_t tg = tile0 + blockIdx.x;
-    const uint32_t g = seg_of(toff, ng, tg);
-    const uint64_t x0 = (tg - toff[g]) * L1_TILE, wg = work[g];
-    const grp1 gr = groups[g];
-    const uint32_t R = gr.rec1 - gr.rec0;
-    for (uint32_t i = threadIdx.x; i < L1_SLOTS; i += 256) hkey[i] = L1_EMPTY;
-    if (threadIdx.x == 0) { s_big = R > rec_cap ? 1 : 0; pool.n = 0; }
-    __syncthreads();
-    if (R <= rec_cap) {
-        for (uint32_t r = threadIdx.x; r < R; r += 256) {
-            l1rec e = l1_load(gr, gr.rec0 + r, reckey, recpid, s1, qtok);
-            recs[r] = e;
-            if (e.olen > 3) s_big = 1;
-            if (r == 0 || (uint32_t)(reckey[gr.rec0 + r - 1] & ((1u << REC_TOKBITS) - 1)) != e.tok) {
-                uint32_t slot = (e.tok * 0x9E3779B1u) >> 23;
-                while (atomicCAS(&hkey[slot], L1_EMPTY, e.tok) != L1_EMPTY) slot = (slot + 1) & (L1_SLOTS - 1);
-                hval[slot] = (uint16_t)r;
-            }
-        }
-    }
-    __syncthreads();
-    const bool big = s_big != 0;
-    const int dl = (int)gr.len;                              // length of the driving phrase
-    const bool bw = gr.backward != 0;
-    for (uint32_t it = 0; it < L1_TILE / 256; it++) {
-        const uint64_t x = x0 + (uint64_t)it * 256 + threadIdx.x;
-        if (x < wg) {
-            const int64_t go = sa[gr.base + x];
-            // first gap token (walking right: just after a; walking left: just before b)
-            const int64_t edge = bw ? go - 1 : go + dl;
-            if (edge >= 0) {
-                // the whole window in registers, logical index j = distance from the first gap token
-                int32_t ws[16]; uint32_t wr[16];
-                load_window(v, edge, bw, ws, wr);
-                if (ws[0] >= 2 && !cgx_unaligned(wr[0])) {
-                    const int64_t prev_delim = edge - cgx_P(wr[0]) - 1;
-                    const int src0 = (int)(prev_delim + 1), tb = prev_delim == -1 ? 0 : (int)v.rlp[prev_delim];
-                    int lo = cgx_L(wr[0]), hi = cgx_R(wr[0]);
-#pragma unroll
-                    for (int move = 0; move <= CGX_MAX_SPAN - 3; move++) {
-                        if (dl + 1 + move + 1 > CGX_MAX_SPAN) break;
-                        const int32_t tk = ws[move + 1];          // first token of the other side
-                        if (tk < 2) break;
-                        bool far_ok = true;                       // the gap token next to the other side must be aligned too
-                        if (move > 0) {
-                            const uint32_t w = wr[move];
-                            far_ok = !cgx_unaligned(w);
-                            if (far_ok) { int L = cgx_L(w), Rr = cgx_R(w); if (lo > L) lo = L; if (hi < Rr) hi = Rr; }
-                        }
-                        if (hi - lo >= CGX_MAX_SPAN) break;       // the span only grows
-                        uint32_t r, rend;
-                        if (!big) {
-                            uint32_t slot = ((uint32_t)tk * 0x9E3779B1u) >> 23; bool found = false;
-                            for (;;) { uint32_t k = hkey[slot]; if (k == (uint32_t)tk) { found = true; break; } if (k == L1_EMPTY) break; slot = (slot + 1) & (L1_SLOTS - 1); }
-                            if (!found) continue;
-                            r = hval[slot]; rend = R;
-                        } else {
-                            if (!h64_find(H.keys, H.vals, H.mask, H.shift, (((uint64_t)g << REC_TOKBITS) | (uint32_t)tk) + 1, &r)) continue;
-                            rend = gr.rec1;
-                        }
-                        const int64_t pos = bw ? edge - 1 - move : edge + 1 + move;
-                        int gapok = far_ok ? -1 : 0;
-                        for (; r < rend; r++) {
-                            l1rec e;
-                            if (!big) e = recs[r]; else e = l1_load(gr, r, reckey, recpid, s1, qtok);
-                            if (e.tok != (uint32_t)tk) break;
-                            const int ol = (int)e.olen;
-                            if (dl + 1 + move + ol > CGX_MAX_SPAN) continue;
-                            bool ok = true;
-                            if (ol <= 3) { if (ol > 1) ok = ws[move + 2] == e.extra[0]; if (ok && ol > 2) ok = ws[(move + 3) & 15] == e.extra[1]; }
-                            else {                                 // over-long other side: compare against the query text
-                                cgx_gapsearch sq = s1[e.id];
-                                for (int k = 1; ok && k < ol; k++) { int64_t q = bw ? pos - k : pos + k; ok = q >= 0 && v.str[q] == (bw ? qtok[sq.qrystart + ol - 1 - k] : qtok[sq.qrystart + sq.gap + sq.a_len + k]); }
-                            }
-                            if (!ok) continue;
-                            if (gapok < 0) gapok = bw ? (tight16(v, lo + tb, hi + tb, (int)(pos + 1), (int)edge, src0) ? 1 : 0)
-                                                      : (tight16(v, lo + tb, hi + tb, (int)edge, (int)(pos - 1), src0) ? 1 : 0);
-                            if (gapok) pool_put(pool, ap, bw ? HITKEY(e.id, pos - ol + 1, dl + 1 + move + ol - 1) : HITKEY(e.id, go, dl + 1 + move + ol - 1));
-                        }
-                    }
-                }
-            }
-        }
-        pool_drain(pool, ap, it + 1 < L1_TILE / 256 ? ap.pool_n / 2 : 0);
-    }
-}
-__global__ void k_tiles(const uint64_t *work, uint32_t ng, uint32_t tile, uint64_t *tiles) {
-    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g < ng) tiles[g] = (work[g] + tile - 1) / tile;
-}
-__global__ void k_unpack_hits1(const uint64_t *keys, uint32_t n, cgx_hit1 *hits, cgx_gapsearch *s1) {
-    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint64_t k = keys[i]; uint32_t id = (uint32_t)(k >> 36);
-    cgx_hit1 h; h.position = id; h.str_position = (uint32_t)((k >> 4) & 0xFFFFFFFFu); h.length = (uint8_t)(k & 15);
-    hits[i] = h;
-    if (i == 0 || (uint32_t)(keys[i - 1] >> 36) != id) s1[id].sa_start = (int32_t)i;
-    if (i + 1 == n || (uint32_t)(keys[i + 1] >> 36) != id) s1[id].sa_end = (int32_t)i;
-}
-
-// ------------------------------------------------------------------------------------
-// two-gap enumeration (twoGapEnumeration, SuffixArray.cu:816-926): one lane per sorted one-gap
-// instance; only single-token a, b, c can fit the five-symbol limit.
-// ------------------------------------------------------------------------------------
-template <bool FILL>
-__global__ void k_enum2(const cgx_gappy *g1, const uint32_t *pid1, const cgx_gapsearch *s1, uint32_t e1, const int32_t *qtok, const int32_t *qoff,
-                        const int32_t *tok2q, const int32_t *lm, int32_t ntok, uint32_t *count, const uint64_t *offset, cgx_twogappy *g2, int32_t *c2) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= e1) return;
-    uint32_t n = 0; uint64_t o = FILL ? offset[i] : 0;
-    uint32_t id = pid1[i]; cgx_gapsearch s = s1[id]; cgx_gappy x = g1[i];
-    int limit = CGX_MAX_SYMBOLS - 2 - s.a_len - s.b_len;
-    if (s.sa_start != -1 && s.sa_end != -1 && limit >= 1) {
-        int32_t sstart = x.qrystart + x.a_len + x.gap + x.b_len - 1;
-        if (sstart <= ntok - 1) {
-            int32_t end = qoff[tok2q[sstart] + 1];
-            for (int32_t sc = sstart + 2; sc < end; sc++) {
-                int lme = lm[sc];
-                for (int it = 1; it <= limit && it <= lme && sc - x.qrystart + it - 1 <= CGX_MAX_SPAN; it++) {
-                    if (FILL) { cgx_twogappy t; t.blockid = id; t.gap2 = (uint32_t)sc; t.c_len = (uint8_t)it; g2[o + n] = t; c2[o + n] = qtok[sc]; }
-                    n++;
-                }
-            }
-        }
-    }
-    if (!FILL) count[i] = n;
-}
-__global__ void k_keys2(const cgx_twogappy *g2, const int32_t *c2, uint32_t n, uint64_t *key) {
-    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (i < n) key[i] = ((uint64_t)g2[i].blockid << 32) | (uint32_t)c2[i];       // (one-gap id, number == 1, c)
-}
-__global__ void k_make_s2(const cgx_twogappy *g, const uint32_t *flags, const uint32_t *incl, uint32_t n, uint32_t *pid, cgx_twogapsearch *s2) {
-    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint32_t id = incl[i] - 1; pid[i] = id;
-    if (flags[i]) { cgx_twogappy x = g[i]; cgx_twogapsearch s; s.blockid = x.blockid; s.gap2 = x.gap2; s.c_len = x.c_len; s.position = (uint32_t)i; s.sa_start = -1; s.sa_end = -1; s2[id] = s; }
-}
-// two-gap lookup (twoGapLookUpSA, GappyLook.cu:476-737), inverted the same way: the distinct
-// aXbXc patterns are sorted by (one-gap id, c), so all patterns extending the same aXb form one
-// segment.  Every occurrence of that aXb is extended to the right ONCE; each window token is
-// binary-searched among the segment's c tokens.  Emission order is (one-gap id, occurrence,
-// window offset); a stable radix sort on the two-gap id alone then yields the canonical
-// (pattern, start, length, length2) order.
-struct grp2 { uint32_t s0, s1; uint32_t one; };          // s2 segment [s0,s1) of one-gap pattern `one`
-__global__ void k_grpflags2(const cgx_twogapsearch *s2, uint32_t d2, uint32_t *flags) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < d2) flags[i] = (i == 0 || s2[i].blockid != s2[i - 1].blockid) ? 1u : 0u;
-}
-__global__ void k_groups2(const cgx_twogapsearch *s2, const uint32_t *flags, const uint32_t *incl, uint32_t d2, grp2 *groups) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= d2) return;
-    uint32_t g = incl[i] - 1;
-    if (flags[i]) { groups[g].s0 = i; groups[g].one = s2[i].blockid; }
-    if (i + 1 == d2 || flags[i + 1]) groups[g].s1 = i + 1;
-}
-__global__ void k_grpwork2(const grp2 *groups, uint32_t ng, const cgx_gapsearch *s1, const uint32_t *pidx, const cgx_hit1 *hits1, uint64_t *work) {
-    uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gi >= ng) return;
-    cgx_gapsearch g = s1[groups[gi].one]; uint64_t w = 0;
-    if (g.sa_start != -1) {
-        if (g.marker) { uint32_t pre = hits1[g.sa_start].str_position; int64_t ps = pidx[2 * pre], pe = pidx[2 * pre + 1]; w = pe >= ps ? (uint64_t)(pe - ps + 1) : 0; }
-        else w = (uint64_t)(g.sa_end - g.sa_start + 1);
-    }
-    work[gi] = w;
-}
-__global__ void k_s2hash_fill(const cgx_twogapsearch *s2, const int32_t *s2c, uint32_t d2, h64 H) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < d2 && s2[i].c_len == 1) h64_insert((unsigned long long *)H.keys, H.vals, H.mask, H.shift, (((uint64_t)s2[i].blockid << 32) | (uint32_t)s2c[i]) + 1, i);
-}
-// hit record: pattern(<=24 bits) | start(32) | len(4) | len2(4) when the pattern id fits, else the id travels separately.
-// Same shape as k_look1: one block = one tile of occurrences of ONE aXb; the c tokens that extend
-// it in this batch sit in an LDS hash (token -> two-gap pattern), the window after b and its
-// alignment words are fetched once into registers and the second gap's span is accumulated
-// while walking.  An aXb extended by more than L2_REC different c uses the batch-wide hash.
-#define L2_TILE 1024
-#define L2_REC 512
-#define L2_SLOTS 1024
-template <bool WIDE>
-__global__ __launch_bounds__(256) void k_look2(cgx_view v, const cgx_twogapsearch *s2, const int32_t *s2c, const cgx_gapsearch *s1, const grp2 *groups, const uint64_t *toff, const uint64_t *work, uint32_t ng,
-                        uint64_t tile0, const cgx_hit1 *hits1, const uint32_t *pidx, const uint32_t *phs, const uint8_t *phl, h64 H, appender ap, uint32_t *wide_id, uint32_t rec_cap) {
-    __shared__ pool_t pool;
-    __shared__ uint32_t hkey[L2_SLOTS];
-    __shared__ uint32_t hval[L2_SLOTS];
-    const uint64_t tg = tile0 + blockIdx.x;
-    const uint32_t gi = seg_of(toff, ng, tg);
-    const uint64_t x0 = (tg - toff[gi]) * L2_TILE, wg = work[gi];
-    const grp2 gr = groups[gi]; const cgx_gapsearch g = s1[gr.one];
-    const uint32_t R = gr.s1 - gr.s0;
-    const bool big = R > rec_cap;
-    if (threadIdx.x == 0) pool.n = 0;
-    __syncthreads();
-    if (!big) {
-        for (uint32_t i = threadIdx.x; i < L2_SLOTS; i += 256) hkey[i] = L1_EMPTY;
-        __syncthreads();
-        for (uint32_t r = threadIdx.x; r < R; r += 256) {
-            if (s2[gr.s0 + r].c_len != 1) continue;
-            const uint32_t tok = (uint32_t)s2c[gr.s0 + r];
-            uint32_t slot = (tok * 0x9E3779B1u) >> 22;
-            while (atomicCAS(&hkey[slot], L1_EMPTY, tok) != L1_EMPTY) slot = (slot + 1) & (L2_SLOTS - 1);
-            hval[slot] = gr.s0 + r;
-        }
-        __syncthreads();
-    }
-    uint32_t listbase = 0;
-    if (g.marker) listbase = pidx[2 * hits1[g.sa_start].str_position];
-    for (uint32_t it = 0; it < L2_TILE / 256; it++) {
-        const uint64_t x = x0 + (uint64_t)it * 256 + threadIdx.x;
-        if (x < wg) {
-            uint32_t ps; int pl;
-            if (g.marker) { ps = phs[listbase + x]; pl = phl[listbase + x]; }
-            else { cgx_hit1 h = hits1[g.sa_start + x]; ps = h.str_position; pl = h.length; }
-            const int64_t edge = (int64_t)ps + pl + 1;          // first token of the second gap
-            if (pl > 0) {
-                int32_t ws[16]; uint32_t wr[16];
-                load_window(v, edge, false, ws, wr);
-                if (ws[0] >= 2 && !cgx_unaligned(wr[0])) {
-                    const int64_t prev_delim = edge - cgx_P(wr[0]) - 1;
-                    const int src0 = (int)(prev_delim + 1), tb = prev_delim == -1 ? 0 : (int)v.rlp[prev_delim];
-                    int lo = cgx_L(wr[0]), hi = cgx_R(wr[0]);
-#pragma unroll
-                    for (int move = 0; move <= CGX_MAX_SPAN - 4; move++) {
-                        if (pl + 3 + move > CGX_MAX_SPAN) break;
-                        const int32_t tk = ws[move + 1];
-                        if (tk < 2) break;
-                        bool far_ok = true;
-                        if (move > 0) {
-                            const uint32_t w = wr[move];
-                            far_ok = !cgx_unaligned(w);
-                            if (far_ok) { int L = cgx_L(w), Rr = cgx_R(w); if (lo > L) lo = L; if (hi < Rr) hi = Rr; }
-                        }
-                        if (hi - lo >= CGX_MAX_SPAN) break;
-                        uint32_t a;                                  // the pattern (this aXb, c = tk), if the batch has it
-                        if (!big) {
-                            uint32_t slot = ((uint32_t)tk * 0x9E3779B1u) >> 22; bool found = false;
-                            for (;;) { uint32_t k = hkey[slot]; if (k == (uint32_t)tk) { found = true; break; } if (k == L1_EMPTY) break; slot = (slot + 1) & (L2_SLOTS - 1); }
-                            if (!found) continue;
-                            a = hval[slot];
-                        } else if (!h64_find(H.keys, H.vals, H.mask, H.shift, (((uint64_t)gr.one << 32) | (uint32_t)tk) + 1, &a)) continue;
-                        if (!far_ok || !tight16(v, lo + tb, hi + tb, (int)edge, (int)(edge + move), src0)) continue;
-                        const uint64_t rec = ((uint64_t)ps << 8) | ((uint64_t)pl << 4) | (uint64_t)(pl + 2 + move);
-                        if (!WIDE) pool_put(pool, ap, ((uint64_t)a << 40) | rec);
-                        else { uint64_t slot = lanes_reserve(ap.total); if (slot < ap.cap) { ap.out[slot] = rec; wide_id[slot] = a; } }
-                    }
-                }
-            }
-        }
-        if (!WIDE) pool_drain(pool, ap, it + 1 < L2_TILE / 256 ? ap.pool_n / 2 : 0);
-    }
-}
-__global__ void k_s2c(const cgx_twogapsearch *s2, const int32_t *c2, uint32_t d2, int32_t *s2c) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < d2) s2c[i] = c2[s2[i].position];
-}
-template <bool WIDE>
-__global__ void k_unpack_hits2(const uint32_t *key, const uint64_t *val, uint32_t n, cgx_hit2 *hits, cgx_twogapsearch *s2) {
-    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint64_t w = val[i];
-    uint32_t id = WIDE ? key[i] : (uint32_t)(w >> 40);
-    cgx_hit2 h; h.position = id; h.str_position = (uint32_t)(w >> 8); h.length = (uint8_t)((w >> 4) & 15); h.length2 = (uint8_t)(w & 15);
-    hits[i] = h;
-    uint32_t prev = i ? (WIDE ? key[i - 1] : (uint32_t)(val[i - 1] >> 40)) : 0, next = i + 1 < n ? (WIDE ? key[i + 1] : (uint32_t)(val[i + 1] >> 40)) : 0;
-    if (i == 0 || prev != id) s2[id].sa_start = (int32_t)i;
-    if (i + 1 == n || next != id) s2[id].sa_end = (int32_t)i;
-}
-
-__global__ void k_compact1(const cgx_gapsearch *s1, const cgx_gappat *p1, uint32_t d1, cgx_gappat *out) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < d1) out[i] = p1[s1[i].position];
-}
-__global__ void k_compact2(const cgx_twogapsearch *s2, const int32_t *c2, uint32_t d2, int32_t *c2d, uint32_t *one2) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < d2) { c2d[i] = c2[s2[i].position]; one2[i] = s2[i].blockid; }
-}
-extern "C" int cgx_gappy_search(cgx_ctx *ctx) {
-    if (!ctx || !ctx->d_lm || !ctx->have_pre) return CGX_ERR_STATE;
-    HIPCHK(hipSetDevice(ctx->device));
-    Timer tm(ctx->stream);
-    const int32_t T = ctx->ntok; hipStream_t st = ctx->stream;
-    cgx_view v{ctx->d_str, ctx->d_rlp, ctx->d_ltar, ctx->d_rtar, ctx->n};
-    dfree(ctx->d_g1); dfree(ctx->d_p1); dfree(ctx->d_pid1); dfree(ctx->d_s1); dfree(ctx->d_hits1);
-    dfree(ctx->d_g2); dfree(ctx->d_c2); dfree(ctx->d_pid2); dfree(ctx->d_s2); dfree(ctx->d_hits2); dfree(ctx->d_p1d); dfree(ctx->d_c2d); dfree(ctx->d_one2);
-    ctx->e1 = ctx->d1 = ctx->h1 = ctx->e2 = ctx->d2 = ctx->h2 = 0;
-    if (T == 0) { ctx->ms["gappy"] = tm.stop(); return CGX_OK; }
-
-    // ---- one-gap enumeration ----
-    uint32_t *cnt = nullptr; uint64_t *off = nullptr;
-    TRY(dalloc(ctx, &cnt, (size_t)T + 1)); TRY(dalloc(ctx, &off, (size_t)T + 1));
-    HIPCHK(hipMemsetAsync(cnt, 0, ((size_t)T + 1) * 4, st));
-    k_enum1<false><<<nblocks(T, 128), 128, 0, st>>>(ctx->d_qtok, ctx->d_qoff, ctx->d_tok2q, ctx->d_lm, T, cnt, nullptr, nullptr, nullptr);
-    TRY(excl_scan(ctx, cnt, off, (size_t)T + 1));
-    uint64_t e1_64 = 0; TRY(d2h(ctx, &e1_64, off + T, 1));
-    if (e1_64 > 0xFFFFFFF0ull) { snprintf(ctx->err, sizeof ctx->err, "too many one-gap candidates"); return CGX_ERR_NOMEM; }
-    uint32_t E1 = (uint32_t)e1_64; ctx->e1 = E1;
-    cgx_gappy *g_raw = nullptr; cgx_gappat *p_raw = nullptr;
-    TRY(dalloc(ctx, &g_raw, E1)); TRY(dalloc(ctx, &p_raw, E1));
-    if (E1) k_enum1<true><<<nblocks(T, 128), 128, 0, st>>>(ctx->d_qtok, ctx->d_qoff, ctx->d_tok2q, ctx->d_lm, T, cnt, off, g_raw, p_raw);
-    dfree(cnt); dfree(off);
-    TRY(dalloc(ctx, &ctx->d_g1, E1)); TRY(dalloc(ctx, &ctx->d_p1, E1)); TRY(dalloc(ctx, &ctx->d_pid1, E1));
-    uint32_t D1 = 0;
-    if (E1) {
-        // stable sort by (number, symbols): thrust::sort_by_key(oneGapEnumerationCompare), SuffixArray.cu:1598
-        int w = bits_for((uint64_t)ctx->last + 1);
-        if (5 * w + 3 > 128) { snprintf(ctx->err, sizeof ctx->err, "vocabulary too large for the packed pattern key"); return CGX_ERR_ARG; }
-        uint64_t *hi = nullptr, *lo = nullptr, *shi = nullptr, *slo = nullptr; uint32_t *p0 = nullptr, *p1 = nullptr, *flags = nullptr;
-        TRY(dalloc(ctx, &hi, E1)); TRY(dalloc(ctx, &lo, E1)); TRY(dalloc(ctx, &shi, E1)); TRY(dalloc(ctx, &slo, E1));
-        TRY(dalloc(ctx, &p0, E1)); TRY(dalloc(ctx, &p1, E1)); TRY(dalloc(ctx, &flags, E1));
-        k_pat_keys<<<nblocks(E1, 256), 256, 0, st>>>(p_raw, E1, w, hi, lo);
-        k_iota<<<nblocks(E1, 256), 256, 0, st>>>(p0, E1);
-        int total_bits = 5 * w + 3, lo_bits = total_bits < 64 ? total_bits : 64, hi_bits = total_bits > 64 ? total_bits - 64 : 1;
-        TRY(sort_pairs(ctx, lo, slo, p0, p1, E1, 0, (unsigned)lo_bits));
-        k_gather<<<nblocks(E1, 256), 256, 0, st>>>(hi, p1, shi, E1);
-        TRY(sort_pairs(ctx, shi, hi, p1, p0, E1, 0, (unsigned)hi_bits));            // hi = sorted hi, p0 = final permutation
-        k_gather<<<nblocks(E1, 256), 256, 0, st>>>(lo, p0, slo, E1);                 // slo = lo in final order
-        k_permute<<<nblocks(E1, 256), 256, 0, st>>>(g_raw, p0, ctx->d_g1, E1);
-        k_permute<<<nblocks(E1, 256), 256, 0, st>>>(p_raw, p0, ctx->d_p1, E1);
-        k_flags128<<<nblocks(E1, 256), 256, 0, st>>>(hi, slo, flags, E1);            // zeroOneDiff, SuffixArray.cu:1041-1068
-        TRY(incl_scan(ctx, flags, p1, E1));
-        TRY(d2h(ctx, &D1, p1 + (E1 - 1), 1));
-        TRY(dalloc(ctx, &ctx->d_s1, D1));
-        k_make_s1<<<nblocks(E1, 256), 256, 0, st>>>(ctx->d_g1, flags, p1, E1, ctx->d_pid1, ctx->d_s1);
-        HIPCHK(stream_wait(ctx));
-        dfree(hi); dfree(lo); dfree(shi); dfree(slo); dfree(p0); dfree(p1); dfree(flags);
-    }
-    dfree(g_raw); dfree(p_raw);
-    ctx->d1 = D1;
-    if (D1 >= (1u << 28)) { snprintf(ctx->err, sizeof ctx->err, "too many distinct one-gap patterns"); return CGX_ERR_NOMEM; }
-
-    // ---- one-gap lookup (patterns grouped by driving phrase) ----
-    if (D1) {
-        uint64_t *reckey = nullptr, *sreckey = nullptr, *markkey = nullptr; uint32_t *recpid = nullptr, *srecpid = nullptr; unsigned int *ctr = nullptr;
-        TRY(dalloc(ctx, &reckey, D1)); TRY(dalloc(ctx, &sreckey, D1)); TRY(dalloc(ctx, &markkey, D1)); TRY(dalloc(ctx, &recpid, D1)); TRY(dalloc(ctx, &srecpid, D1)); TRY(dalloc(ctx, &ctr, 2));
-        HIPCHK(hipMemsetAsync(ctr, 0, 8, st));
-        if (bits_for((uint64_t)ctx->last + 1) > REC_TOKBITS) { snprintf(ctx->err, sizeof ctx->err, "vocabulary too large for the lookup record key"); return CGX_ERR_ARG; }
-        k_plan1<<<nblocks(D1, 256), 256, 0, st>>>(ctx->d_s1, D1, ctx->d_qtok, ctx->d_lm, ctx->d_up, ctx->d_down, ctx->d_tokrank, ctx->d_pidx, reckey, recpid, ctr, markkey, ctr + 1);
-        unsigned int hc[2] = {0, 0}; TRY(d2h(ctx, hc, ctr, 2));
-        uint32_t NR = hc[0], NM = hc[1];
-        dvec64 keys;
-        TRY(dvec_reserve(ctx, keys, (size_t)NM + 1));
-        if (NM) { HIPCHK(hipMemcpyAsync(keys.p, markkey, (size_t)NM * 8, hipMemcpyDeviceToDevice, st)); keys.n = NM; }
-        if (NR) {
-            TRY(sort_pairs(ctx, reckey, sreckey, recpid, srecpid, NR, 0, 64));
-            uint32_t *flags = nullptr, *incl = nullptr; TRY(dalloc(ctx, &flags, NR)); TRY(dalloc(ctx, &incl, NR));
-            k_grpflags1<<<nblocks(NR, 256), 256, 0, st>>>(sreckey, flags, NR);
-            TRY(incl_scan(ctx, flags, incl, NR));
-            uint32_t NG = 0; TRY(d2h(ctx, &NG, incl + (NR - 1), 1));
-            grp1 *groups = nullptr; uint32_t *gdown = nullptr; uint64_t *work = nullptr, *woff = nullptr;
-            TRY(dalloc(ctx, &groups, NG)); TRY(dalloc(ctx, &gdown, NG)); TRY(dalloc(ctx, &work, (size_t)NG + 1)); TRY(dalloc(ctx, &woff, (size_t)NG + 1));
-            HIPCHK(hipMemsetAsync(work, 0, ((size_t)NG + 1) * 8, st));
-            k_groups1<<<nblocks(NR, 256), 256, 0, st>>>(sreckey, flags, incl, NR, groups);
-            h64 H; { uint64_t cap = 1024; while (cap < (uint64_t)NR * 2) cap <<= 1; H.mask = (uint32_t)(cap - 1); H.shift = 64 - (unsigned)bits_for(cap - 1);
-                     TRY(dalloc(ctx, &H.keys, cap)); TRY(dalloc(ctx, &H.vals, cap)); HIPCHK(hipMemsetAsync(H.keys, 0, cap * 8, st)); }
-            k_rechash_fill<<<nblocks(NR, 256), 256, 0, st>>>(sreckey, incl, NR, H);
-            k_grpdown1<<<nblocks(NG, 256), 256, 0, st>>>(groups, NG, srecpid, ctx->d_s1, ctx->d_down, gdown);
-            k_grpwork1<<<nblocks(NG, 256), 256, 0, st>>>(groups, NG, gdown, work);
-            TRY(excl_scan(ctx, work, woff, (size_t)NG + 1));
-            uint64_t W = 0; TRY(d2h(ctx, &W, woff + NG, 1));
-            ctx->ms["look1_items"] = (double)W; ctx->ms["look1_groups"] = (double)NG;
-            const cgx_gapsearch *s1 = ctx->d_s1; const int32_t *sa = ctx->d_sa, *qtok = ctx->d_qtok;
-            if (getenv("CGX_DIAG_GROUPS")) {                    // work / record-count distribution of the groups (stderr)
-                std::vector<grp1> hg(NG); std::vector<uint64_t> hw((size_t)NG + 1);
-                TRY(d2h(ctx, hg.data(), groups, NG)); TRY(d2h(ctx, hw.data(), woff, (size_t)NG + 1));
-                double wsum[8] = {0}, rsum[8] = {0}; uint64_t cnt[8] = {0};
-                double wr[8] = {0};
-                for (uint32_t g = 0; g < NG; g++) {
-                    uint64_t w = hw[g + 1] - hw[g]; uint32_t r = hg[g].rec1 - hg[g].rec0;
-                    int bw = w < 64 ? 0 : w < 256 ? 1 : w < 1024 ? 2 : w < 4096 ? 3 : w < 16384 ? 4 : w < 65536 ? 5 : w < 262144 ? 6 : 7;
-                    int br = r < 16 ? 0 : r < 64 ? 1 : r < 256 ? 2 : r < 1024 ? 3 : r < 4096 ? 4 : r < 16384 ? 5 : r < 65536 ? 6 : 7;
-                    wsum[bw] += (double)w; cnt[bw]++; rsum[bw] += r; wr[br] += (double)w;
-                }
-                fprintf(stderr, "look1 groups=%u items=%llu records=%u\n", NG, (unsigned long long)W, NR);
-                for (int k = 0; k < 8; k++) fprintf(stderr, "  work-bucket %d: groups %llu work %.3g (%.1f%%) avg records %.1f | work in record-bucket %d: %.1f%%\n", k, (unsigned long long)cnt[k], wsum[k], 100 * wsum[k] / (double)W, cnt[k] ? rsum[k] / cnt[k] : 0.0, k, 100 * wr[k] / (double)W);
-            }
-            uint64_t *tiles = nullptr, *toff = nullptr; TRY(dalloc(ctx, &tiles, (size_t)NG + 1)); TRY(dalloc(ctx, &toff, (size_t)NG + 1));
-            HIPCHK(hipMemsetAsync(tiles, 0, ((size_t)NG + 1) * 8, st));
-            k_tiles<<<nblocks(NG, 256), 256, 0, st>>>(work, NG, L1_TILE, tiles);
-            TRY(excl_scan(ctx, tiles, toff, (size_t)NG + 1));
-            uint64_t NT = 0; TRY(d2h(ctx, &NT, toff + NG, 1));
-            const uint64_t tile_chunk = ctx->chunk_items / 64 ? (ctx->chunk_items / 64 < (1ull << 30) ? ctx->chunk_items / 64 : (1ull << 30)) : 1;
-            Timer tk1(st);
-            TRY(append_pass(ctx, NT, tile_chunk, W, keys, &ctx->look1_per_item, [&](uint64_t t0, uint64_t nt, appender ap) {
-                k_look1<<<(unsigned)nt, 256, 0, st>>>(v, sa, s1, groups, toff, work, NG, t0, qtok, sreckey, srecpid, H, ap, ctx->look_rec_cap < L1_REC ? ctx->look_rec_cap : L1_REC);
-            }));
-            ctx->ms["look1_kernel"] = tk1.stop();
-            dfree(tiles); dfree(toff);
-            dfree(flags); dfree(incl); dfree(groups); dfree(gdown); dfree(work); dfree(woff); dfree(H.keys); dfree(H.vals);
-        }
-        if (keys.n > 0xFFFFFFF0ull) { snprintf(ctx->err, sizeof ctx->err, "too many one-gap occurrences"); return CGX_ERR_NOMEM; }
-        uint32_t H1 = (uint32_t)keys.n; ctx->h1 = H1;
-        TRY(dalloc(ctx, &ctx->d_hits1, H1));
-        if (H1) {
-            uint64_t *sk = nullptr; TRY(dalloc(ctx, &sk, H1));
-            TRY(sort_keys(ctx, keys.p, sk, H1, 0, 64));                               // thrust::sort(oneGapSACompare) + canonical tie order
-            k_unpack_hits1<<<nblocks(H1, 256), 256, 0, st>>>(sk, H1, ctx->d_hits1, ctx->d_s1);
-            HIPCHK(stream_wait(ctx));
-            dfree(sk);
-        }
-        dfree(keys.p); dfree(reckey); dfree(sreckey); dfree(markkey); dfree(recpid); dfree(srecpid); dfree(ctr);
-    }
-
-    // ---- two-gap enumeration ----
-    uint32_t E2 = 0, D2 = 0;
-    if (E1 && D1) {
-        TRY(dalloc(ctx, &cnt, (size_t)E1 + 1)); TRY(dalloc(ctx, &off, (size_t)E1 + 1));
-        HIPCHK(hipMemsetAsync(cnt, 0, ((size_t)E1 + 1) * 4, st));
-        k_enum2<false><<<nblocks(E1, 128), 128, 0, st>>>(ctx->d_g1, ctx->d_pid1, ctx->d_s1, E1, ctx->d_qtok, ctx->d_qoff, ctx->d_tok2q, ctx->d_lm, T, cnt, nullptr, nullptr, nullptr);
-        TRY(excl_scan(ctx, cnt, off, (size_t)E1 + 1));
-        uint64_t e2_64 = 0; TRY(d2h(ctx, &e2_64, off + E1, 1));
-        if (e2_64 > 0xFFFFFFF0ull) { snprintf(ctx->err, sizeof ctx->err, "too many two-gap candidates"); return CGX_ERR_NOMEM; }
-        E2 = (uint32_t)e2_64;
-        cgx_twogappy *g2raw = nullptr; int32_t *c2raw = nullptr;
-        TRY(dalloc(ctx, &g2raw, E2)); TRY(dalloc(ctx, &c2raw, E2));
-        if (E2) k_enum2<true><<<nblocks(E1, 128), 128, 0, st>>>(ctx->d_g1, ctx->d_pid1, ctx->d_s1, E1, ctx->d_qtok, ctx->d_qoff, ctx->d_tok2q, ctx->d_lm, T, cnt, off, g2raw, c2raw);
-        dfree(cnt); dfree(off);
-        TRY(dalloc(ctx, &ctx->d_g2, E2)); TRY(dalloc(ctx, &ctx->d_c2, E2)); TRY(dalloc(ctx, &ctx->d_pid2, E2));
-        if (E2) {
-            uint64_t *key = nullptr, *skey = nullptr; uint32_t *p0 = nullptr, *p1 = nullptr, *flags = nullptr;
-            TRY(dalloc(ctx, &key, E2)); TRY(dalloc(ctx, &skey, E2)); TRY(dalloc(ctx, &p0, E2)); TRY(dalloc(ctx, &p1, E2)); TRY(dalloc(ctx, &flags, E2));
-            k_keys2<<<nblocks(E2, 256), 256, 0, st>>>(g2raw, c2raw, E2, key);
-            k_iota<<<nblocks(E2, 256), 256, 0, st>>>(p0, E2);
-            TRY(sort_pairs(ctx, key, skey, p0, p1, E2, 0, 64));                       // sort_by_key(twoGapEnumerationCompare), SuffixArray.cu:1989
-            k_permute<<<nblocks(E2, 256), 256, 0, st>>>(g2raw, p1, ctx->d_g2, E2);
-            k_permute<<<nblocks(E2, 256), 256, 0, st>>>(c2raw, p1, ctx->d_c2, E2);
-            k_head_flags<<<nblocks(E2, 256), 256, 0, st>>>(skey, flags, E2);         // zeroOneDiffTwoGap
-            TRY(incl_scan(ctx, flags, p0, E2));
-            TRY(d2h(ctx, &D2, p0 + (E2 - 1), 1));
-            TRY(dalloc(ctx, &ctx->d_s2, D2));
-            k_make_s2<<<nblocks(E2, 256), 256, 0, st>>>(ctx->d_g2, flags, p0, E2, ctx->d_pid2, ctx->d_s2);
-            HIPCHK(stream_wait(ctx));
-            dfree(key); dfree(skey); dfree(p0); dfree(p1); dfree(flags);
-        }
-        dfree(g2raw); dfree(c2raw);
-    }
-    ctx->e2 = E2; ctx->d2 = D2;
-
-    // ---- two-gap lookup (patterns grouped by the aXb they extend) ----
-    TRY(dalloc(ctx, &ctx->d_hits2, 1)); ctx->h2 = 0;
-    if (D2) {
-        int32_t *s2c = nullptr; uint32_t *flags = nullptr, *incl = nullptr;
-        TRY(dalloc(ctx, &s2c, D2)); TRY(dalloc(ctx, &flags, D2)); TRY(dalloc(ctx, &incl, D2));
-        k_s2c<<<nblocks(D2, 256), 256, 0, st>>>(ctx->d_s2, ctx->d_c2, D2, s2c);
-        k_grpflags2<<<nblocks(D2, 256), 256, 0, st>>>(ctx->d_s2, D2, flags);
-        TRY(incl_scan(ctx, flags, incl, D2));
-        uint32_t NG = 0; TRY(d2h(ctx, &NG, incl + (D2 - 1), 1));
-        grp2 *groups = nullptr; uint64_t *work = nullptr, *woff = nullptr;
-        TRY(dalloc(ctx, &groups, NG)); TRY(dalloc(ctx, &work, (size_t)NG + 1)); TRY(dalloc(ctx, &woff, (size_t)NG + 1));
-        HIPCHK(hipMemsetAsync(work, 0, ((size_t)NG + 1) * 8, st));
-        k_groups2<<<nblocks(D2, 256), 256, 0, st>>>(ctx->d_s2, flags, incl, D2, groups);
-        k_grpwork2<<<nblocks(NG, 256), 256, 0, st>>>(groups, NG, ctx->d_s1, ctx->d_pidx, ctx->d_hits1, work);
-        TRY(excl_scan(ctx, work, woff, (size_t)NG + 1));
-        uint64_t W = 0; TRY(d2h(ctx, &W, woff + NG, 1));
-        ctx->ms["look2_items"] = (double)W; ctx->ms["look2_groups"] = (double)NG;
-        h64 H2; { uint64_t cap = 1024; while (cap < (uint64_t)D2 * 2) cap <<= 1; H2.mask = (uint32_t)(cap - 1); H2.shift = 64 - (unsigned)bits_for(cap - 1);
-                  TRY(dalloc(ctx, &H2.keys, cap)); TRY(dalloc(ctx, &H2.vals, cap)); HIPCHK(hipMemsetAsync(H2.keys, 0, cap * 8, st)); }
-        k_s2hash_fill<<<nblocks(D2, 256), 256, 0, st>>>(ctx->d_s2, s2c, D2, H2);
-        const unsigned idbits = (unsigned)bits_for(D2);
-        const bool wide = idbits > 24 || ctx->wide_hits2;          // the pattern id does not fit beside the 40-bit occurrence
-        dvec64 recs; uint32_t *wid = nullptr; size_t accn = 0;
-        uint64_t *tiles = nullptr, *toff = nullptr; TRY(dalloc(ctx, &tiles, (size_t)NG + 1)); TRY(dalloc(ctx, &toff, (size_t)NG + 1));
-        HIPCHK(hipMemsetAsync(tiles, 0, ((size_t)NG + 1) * 8, st));
-        k_tiles<<<nblocks(NG, 256), 256, 0, st>>>(work, NG, L2_TILE, tiles);
-        TRY(excl_scan(ctx, tiles, toff, (size_t)NG + 1));
-        uint64_t NT = 0; TRY(d2h(ctx, &NT, toff + NG, 1));
-        const uint64_t tile_chunk = ctx->chunk_items / 64 ? (ctx->chunk_items / 64 < (1ull << 30) ? ctx->chunk_items / 64 : (1ull << 30)) : 1;
-        Timer tk2(st);
-        if (!wide) {
-            TRY(append_pass(ctx, NT, tile_chunk, W, recs, &ctx->look2_per_item, [&](uint64_t t0, uint64_t nt, appender ap) {
-                k_look2<false><<<(unsigned)nt, 256, 0, st>>>(v, ctx->d_s2, s2c, ctx->d_s1, groups, toff, work, NG, t0, ctx->d_hits1, ctx->d_pidx, ctx->d_phit_start, ctx->d_phit_len, H2, ap, nullptr, ctx->look_rec_cap < L2_REC ? ctx->look_rec_cap : L2_REC);
-            }));
-            accn = recs.n;
-        } else {
-            // ids travel in a parallel array, so capacity is fixed before launching: count first with cap 0
-            for (int pass = 0; pass < 2; pass++) {
-                unsigned long long *total = nullptr; TRY(dalloc(ctx, &total, 1)); HIPCHK(hipMemsetAsync(total, 0, 8, st));
-                appender ap{recs.p, recs.cap, total, POOL_N};
-                for (uint64_t t0 = 0; t0 < NT; t0 += tile_chunk) {
-                    uint64_t nt = NT - t0 < tile_chunk ? NT - t0 : tile_chunk;
-                    k_look2<true><<<(unsigned)nt, 256, 0, st>>>(v, ctx->d_s2, s2c, ctx->d_s1, groups, toff, work, NG, t0, ctx->d_hits1, ctx->d_pidx, ctx->d_phit_start, ctx->d_phit_len, H2, ap, wid, ctx->look_rec_cap < L2_REC ? ctx->look_rec_cap : L2_REC);
-                }
-                unsigned long long got = 0; TRY(d2h(ctx, &got, total, 1)); dfree(total);
-                accn = (size_t)got;
-                if (pass == 0) { TRY(dvec_reserve(ctx, recs, accn + 1)); TRY(dalloc(ctx, &wid, accn + 1)); }
-            }
-        }
-        ctx->ms["look2_kernel"] = tk2.stop();
-        dfree(tiles); dfree(toff);
-        HIPCHK(hipGetLastError());
-        if (accn > 0xFFFFFFF0ull) { snprintf(ctx->err, sizeof ctx->err, "too many two-gap occurrences"); return CGX_ERR_NOMEM; }
-        if (accn) {
-            // order: pattern, then (start, length, length2) -- thrust::sort(twoGapSACompare) + canonical tie order
-            uint64_t *sv = nullptr; TRY(dalloc(ctx, &sv, accn));
-            dfree(ctx->d_hits2); TRY(dalloc(ctx, &ctx->d_hits2, accn));
-            if (!wide) {
-                TRY(sort_keys(ctx, recs.p, sv, accn, 0, 40 + idbits));
-                k_unpack_hits2<false><<<nblocks(accn, 256), 256, 0, st>>>(nullptr, sv, (uint32_t)accn, ctx->d_hits2, ctx->d_s2);
-            } else {
-                uint32_t *sk = nullptr, *sk2 = nullptr; uint64_t *sv2 = nullptr; TRY(dalloc(ctx, &sk, accn)); TRY(dalloc(ctx, &sk2, accn)); TRY(dalloc(ctx, &sv2, accn));
-                TRY(sort_pairs(ctx, recs.p, sv, wid, sk, accn, 0, 40));
-                TRY(sort_pairs(ctx, sk, sk2, sv, sv2, accn, 0, idbits));
-                k_unpack_hits2<true><<<nblocks(accn, 256), 256, 0, st>>>(sk2, sv2, (uint32_t)accn, ctx->d_hits2, ctx->d_s2);
-                HIPCHK(stream_wait(ctx));
-                dfree(sk); dfree(sk2); dfree(sv2);
-            }
-            HIPCHK(stream_wait(ctx));
-            dfree(sv);
-        }
-        ctx->h2 = (uint32_t)accn;
-        dfree(recs.p); dfree(wid); dfree(work); dfree(woff); dfree(groups); dfree(s2c); dfree(flags); dfree(incl); dfree(H2.keys); dfree(H2.vals);
-    }
-    // compact per-distinct-pattern views for the host writer
-    TRY(dalloc(ctx, &ctx->d_p1d, D1)); TRY(dalloc(ctx, &ctx->d_c2d, D2)); TRY(dalloc(ctx, &ctx->d_one2, D2));
-    if (D1) k_compact1<<<nblocks(D1, 256), 256, 0, st>>>(ctx->d_s1, ctx->d_p1, D1, ctx->d_p1d);
-    if (D2) k_compact2<<<nblocks(D2, 256), 256, 0, st>>>(ctx->d_s2, ctx->d_c2, D2, ctx->d_c2d, ctx->d_one2);
-    HIPCHK(stream_wait(ctx));
-    HIPCHK(hipGetLastError());
-    ctx->ms["gappy"] = tm.stop();
-    return CGX_OK;
-}
-
-// ------------------------------------------------------------------------------------
-// extraction (three launches of ExtractPair.cu:3361, 3492, 3603).  Work item = one SAMPLED
-// occurrence, flattened over blocks / patterns with a scan, so a 300-sample block and a
-// 1-sample block cost what they should.  Valid rules are appended with one atomic per wave
-// (ballot + popcount) as 128-bit sort keys; a radix sort on the whole record then yields the
-// canonical order (id, target start, end, gaps), independent of arrival order.
-// ------------------------------------------------------------------------------------
-struct keybuf { uint64_t *hi, *lo; unsigned int *count; };
-__device__ __forceinline__ void emit_key(keybuf kb, bool valid, uint64_t hi, uint64_t lo) {
-    uint32_t slot = wave_append(kb.count, valid);
-    if (valid) { kb.hi[slot] = hi; kb.lo[slot] = lo; }
-}
-#define K1_HI(r) (((uint64_t)(uint32_t)(r).id << 32) | (uint64_t)(r).tstart)
-#define K1_LO(r) (((uint64_t)(r).end << 16) | ((uint64_t)(r).gap1 << 8) | (uint64_t)(r).gap1_1)
-#define K2_LO(r) (((uint64_t)(r).end << 32) | ((uint64_t)(r).gap1 << 24) | ((uint64_t)(r).gap1_1 << 16) | ((uint64_t)(r).gap2 << 8) | (uint64_t)(r).gap2_1)
-
-__global__ void k_work_blocks(const cgx_block *b, uint32_t g, uint64_t *work) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= g) return;
-    int64_t n = (int64_t)b[i].end - b[i].start + 1;
-    work[i] = (b[i].matchlen < 1 || n < 1) ? 0 : (uint64_t)(n < CGX_SAMPLER ? n : CGX_SAMPLER);
-}
-__global__ void k_extract0(cgx_view v, const int32_t *sa, const cgx_block *blocks, const uint64_t *woff, uint32_t g, uint64_t w0, uint64_t nw,
-                           keybuf k0, keybuf k1, keybuf k2, unsigned int *guard) {
-    uint64_t wi = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-    bool active = wi < nw;
-    cgx_r0 ab; cgx_r1 xab, abx; cgx_r2 xabx; ab.valid = 0; xab.valid = 0; abx.valid = 0; xabx.valid = 0;
-    if (active) {
-        uint32_t bn = seg_of(woff, g, w0 + wi);
-        int k = (int)(w0 + wi - woff[bn]);
-        cgx_block b = blocks[bn];
-        int n = b.end - b.start + 1;
-        int x = cgx_sample_index(n, CGX_SAMPLER, k);
-        if (cgx_extract_contig(v, (int32_t)bn, (int32_t)g, b.matchlen, sa[b.start + x], &ab, &xab, &abx, &xabx)) atomicAdd(guard, 1u);
-    }
-    emit_key(k0, ab.valid, ((uint64_t)(uint32_t)ab.block << 32) | (uint32_t)ab.tar_start, ab.tar_end);
-    emit_key(k1, xab.valid, K1_HI(xab), K1_LO(xab));
-    emit_key(k1, abx.valid, K1_HI(abx), K1_LO(abx));
-    emit_key(k2, xabx.valid, K1_HI(xabx), K2_LO(xabx));
-}
-__global__ void k_work_two(const cgx_twogapsearch *s2, uint32_t d2, uint64_t *work) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= d2) return;
-    int64_t n = s2[i].sa_start == -1 ? 0 : (int64_t)s2[i].sa_end - s2[i].sa_start + 1;
-    work[i] = (uint64_t)(n < CGX_SAMPLER_TWOGAP ? n : CGX_SAMPLER_TWOGAP);
-}
-__global__ void k_extract2(cgx_view v, const cgx_twogapsearch *s2, const cgx_gapsearch *s1, const cgx_hit2 *hits2, const uint64_t *woff, uint32_t d2,
-                           uint64_t w0, uint64_t nw, keybuf k2, unsigned int *guard) {
-    uint64_t wi = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-    cgx_r2 r; r.valid = 0;
-    if (wi < nw) {
-        uint32_t id = seg_of(woff, d2, w0 + wi);
-        int k = (int)(w0 + wi - woff[id]);
-        cgx_twogapsearch ts = s2[id]; cgx_gapsearch g = s1[ts.blockid];
-        int n = ts.sa_end - ts.sa_start + 1;
-        cgx_hit2 h = hits2[ts.sa_start + cgx_sample_index(n, CGX_SAMPLER_TWOGAP, k)];
-        if (cgx_extract_twogap(v, (int32_t)id, g.a_len, g.b_len, ts.c_len, h.str_position, h.length, h.length2, &r)) atomicAdd(guard, 1u);
-    }
-    emit_key(k2, r.valid, K1_HI(r), K2_LO(r));
-}
-__global__ void k_work_one(const cgx_gapsearch *s1, uint32_t d1, const cgx_hit1 *hits1, const uint32_t *pidx, uint64_t *work) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= d1) return;
-    cgx_gapsearch s = s1[i]; int64_t n = 0;
-    if (s.sa_start != -1) {
-        if (s.marker) { uint32_t pre = hits1[s.sa_start].str_position; n = (int64_t)pidx[2 * pre + 1] - (int64_t)pidx[2 * pre] + 1; }
-        else n = (int64_t)s.sa_end - s.sa_start + 1;
-    }
-    if (n < 0) n = 0;
-    work[i] = (uint64_t)(n < CGX_SAMPLER_ONEGAP ? n : CGX_SAMPLER_ONEGAP);
-}
-__global__ void k_extract1(cgx_view v, const cgx_gapsearch *s1, const cgx_hit1 *hits1, const uint32_t *pidx, const uint32_t *phs, const uint8_t *phl,
-                           const uint64_t *woff, uint32_t d1, uint64_t w0, uint64_t nw, keybuf k1, keybuf k2, unsigned int *guard) {
-    uint64_t wi = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-    cgx_r1 axb; cgx_r2 xaxb, axbx; axb.valid = 0; xaxb.valid = 0; axbx.valid = 0;
-    if (wi < nw) {
-        uint32_t id = seg_of(woff, d1, w0 + wi);
-        int k = (int)(w0 + wi - woff[id]);
-        cgx_gapsearch s = s1[id];
-        uint32_t cur; int fe;
-        if (s.marker) {
-            uint32_t pre = hits1[s.sa_start].str_position; uint32_t b = pidx[2 * pre]; int n = (int)(pidx[2 * pre + 1] - b + 1);
-            int x = cgx_sample_index(n, CGX_SAMPLER_ONEGAP, k); cur = phs[b + x]; fe = phl[b + x];
-        } else {
-            int n = s.sa_end - s.sa_start + 1;
-            cgx_hit1 h = hits1[s.sa_start + cgx_sample_index(n, CGX_SAMPLER_ONEGAP, k)]; cur = h.str_position; fe = h.length;
-        }
-        if (cgx_extract_onegap(v, (int32_t)id, (int32_t)d1, s.a_len, s.b_len, cur, fe, &axb, &xaxb, &axbx)) atomicAdd(guard, 1u);
-    }
-    emit_key(k1, axb.valid, K1_HI(axb), K1_LO(axb));
-    emit_key(k2, xaxb.valid, K1_HI(xaxb), K2_LO(xaxb));
-    emit_key(k2, axbx.valid, K1_HI(axbx), K2_LO(axbx));
-}
-__global__ void k_pack_r0(const uint64_t *hi, const uint64_t *lo, uint32_t n, cgx_rule0 *out) {
-    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; if (i >= n) return;
-    cgx_rule0 r; r.block = (int32_t)(hi[i] >> 32); r.tar_start = (int32_t)(hi[i] & 0xFFFFFFFFu); r.tar_end = (uint8_t)lo[i]; out[i] = r;
-}
-__global__ void k_pack_r1(const uint64_t *hi, const uint64_t *lo, uint32_t n, cgx_rule1 *out) {
-    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; if (i >= n) return;
-    cgx_rule1 r; r.id = (int32_t)(hi[i] >> 32); r.tstart = (uint32_t)(hi[i] & 0xFFFFFFFFu);
-    r.end = (uint8_t)(lo[i] >> 16); r.gap1 = (uint8_t)(lo[i] >> 8); r.gap1_1 = (uint8_t)lo[i]; out[i] = r;
-}
-__global__ void k_pack_r2(const uint64_t *hi, const uint64_t *lo, uint32_t n, cgx_rule2 *out) {
-    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; if (i >= n) return;
-    cgx_rule2 r; r.id = (int32_t)(hi[i] >> 32); r.tstart = (uint32_t)(hi[i] & 0xFFFFFFFFu);
-    r.end = (uint8_t)(lo[i] >> 32); r.gap1 = (uint8_t)(lo[i] >> 24); r.gap1_1 = (uint8_t)(lo[i] >> 16); r.gap2 = (uint8_t)(lo[i] >> 8); r.gap2_1 = (uint8_t)lo[i]; out[i] = r;
-}
-
-__global__ void k_block_starts(cgx_block *b, uint32_t g, const int32_t *sa) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < g) b[i].string_start = sa[b[i].start];
-}
-extern "C" int cgx_set_blocks(cgx_ctx *ctx, cgx_block *blocks, uint32_t g) {
-    if (!ctx || (g && !blocks)) return CGX_ERR_ARG;
-    if (!ctx->have_sa) return CGX_ERR_STATE;
-    HIPCHK(hipSetDevice(ctx->device));
-    for (uint32_t i = 0; i < g; i++) if (blocks[i].start < 0 || (uint32_t)blocks[i].end >= ctx->n || blocks[i].start > blocks[i].end || blocks[i].matchlen < 1 || blocks[i].matchlen > 5) {
-        snprintf(ctx->err, sizeof ctx->err, "block %u is not a valid SA interval", i); return CGX_ERR_ARG; }
-    dfree(ctx->d_blocks);
-    TRY(dalloc(ctx, &ctx->d_blocks, g));
-    if (g) {
-        TRY(h2d(ctx, ctx->d_blocks, blocks, g));
-        k_block_starts<<<nblocks(g, 256), 256, 0, ctx->stream>>>(ctx->d_blocks, g, ctx->d_sa);
-        TRY(d2h(ctx, blocks, ctx->d_blocks, g));
-    }
-    ctx->g = g;
-    return CGX_OK;
-}
-
-// ------------------------------------------------------------------------------------
-// GenerateBlocks (ExtractPair.cu:2740-2830 / Start.cu:585): the distinct contiguous phrases of the
-// batch = distinct (SA interval start, length) over every query token t and length ct <= lm[t],
-// numbered in first-seen order of the scan (query, token, length), plus per query the list of
-// its distinct phrases in first-seen order.  The host version walked 1.2 M items through a hash
-// map (40 ms per 10 k queries); here it is four small radix sorts:
-//   (key, ordinal) sorted by key      -> groups, first ordinal of each group
-//   groups sorted by first ordinal    -> block id = rank
-//   (query, block, ordinal) sorted    -> first ordinal of each (query, block)
-//   those sorted by ordinal           -> per-query lists in first-seen order
-// ------------------------------------------------------------------------------------
-#define BLK_INVALID (1ull << 36)
-__global__ void k_blk_keys(const int32_t *lm, const int32_t *up, uint32_t m, uint64_t *key, uint32_t *ord) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
-    const uint32_t t = i / 5, ct = i % 5 + 1;
-    key[i] = (int32_t)ct <= lm[t] ? (((uint64_t)(uint32_t)up[i] << 3) | ct) : BLK_INVALID;
-    ord[i] = i;
-}
-__global__ void k_blk_heads(const uint64_t *skey, uint32_t m, uint32_t *flags) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < m) flags[i] = (skey[i] != BLK_INVALID && (i == 0 || skey[i] != skey[i - 1])) ? 1u : 0u;
-}
-__global__ void k_blk_headord(const uint32_t *flags, const uint32_t *incl, const uint32_t *sord, uint32_t m, uint32_t *ho, uint32_t *giota) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < m && flags[i]) { ho[incl[i] - 1] = sord[i]; giota[incl[i] - 1] = incl[i] - 1; }
-}
-__global__ void k_blk_make(const uint32_t *ho_sorted, const uint32_t *g_sorted, uint32_t g, const int32_t *up, const int32_t *down, const int32_t *sa, cgx_block *blocks, uint32_t *rank_of_group) {
-    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= g) return;
-    const uint32_t o = ho_sorted[r];
-    cgx_block b; b.start = up[o]; b.end = down[o]; b.matchlen = (int32_t)(o % 5 + 1); b.string_start = sa[b.start];
-    blocks[r] = b; rank_of_group[g_sorted[r]] = r;
-}
-__global__ void k_blk_qkeys(const uint64_t *skey, const uint32_t *sord, const uint32_t *incl, const uint32_t *rank_of_group, const int32_t *tok2q, uint32_t m, uint64_t *qkey, uint32_t *qord) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
-    if (skey[i] == BLK_INVALID) { qkey[i] = ~0ull; qord[i] = 0; return; }
-    const uint32_t o = sord[i];
-    qkey[i] = ((uint64_t)(uint32_t)tok2q[o / 5] << 32) | rank_of_group[incl[i] - 1];
-    qord[i] = o;
-}
-__global__ void k_blk_qheads(const uint64_t *sqkey, uint32_t m, uint32_t *flags) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < m) flags[i] = (sqkey[i] != ~0ull && (i == 0 || sqkey[i] != sqkey[i - 1])) ? 1u : 0u;
-}
-__global__ void k_blk_qcompact(const uint64_t *sqkey, const uint32_t *sqord, const uint32_t *flags, const uint32_t *incl, uint32_t m, uint32_t *ord_out, uint32_t *id_out) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < m && flags[i]) { ord_out[incl[i] - 1] = sqord[i]; id_out[incl[i] - 1] = (uint32_t)sqkey[i]; }
-}
-__global__ void k_blk_qof(const uint32_t *ord_sorted, uint32_t n, const int32_t *tok2q, uint32_t *q_out) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) q_out[i] = (uint32_t)tok2q[ord_sorted[i] / 5];
-}
-__global__ void k_csr_offsets(const uint32_t *q_sorted, uint32_t n, int32_t nq, uint32_t *off) {   // off[q] = first index with q_sorted >= q, q = 0..nq
-    int32_t q = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (q > nq) return;
-    uint32_t a = 0, z = n;
-    while (a < z) { uint32_t mid = (a + z) >> 1; if (q_sorted[mid] < (uint32_t)q) a = mid + 1; else z = mid; }
-    off[q] = a;
-}
-extern "C" int cgx_make_blocks(cgx_ctx *ctx) {
-    if (!ctx || !ctx->d_lm || !ctx->have_sa) return CGX_ERR_STATE;
-    HIPCHK(hipSetDevice(ctx->device));
-    Timer tm(ctx->stream);
-    hipStream_t st = ctx->stream; const int32_t nq = ctx->nq; const uint32_t T = (uint32_t)ctx->ntok;
-    dfree(ctx->d_blocks); dfree(ctx->d_qb_off); dfree(ctx->d_qb_ids); ctx->g = 0;
-    TRY(dalloc(ctx, &ctx->d_qb_off, (size_t)nq + 2));
-    HIPCHK(hipMemsetAsync(ctx->d_qb_off, 0, ((size_t)nq + 2) * 4, st));
-    if ((uint64_t)T * 5 > 0x7FFFFFF0ull) { snprintf(ctx->err, sizeof ctx->err, "too many query tokens for one batch"); return CGX_ERR_NOMEM; }
-    const uint32_t M = T * 5;
-    if (M == 0) { TRY(dalloc(ctx, &ctx->d_blocks, 1)); TRY(dalloc(ctx, &ctx->d_qb_ids, 1)); ctx->ms["blocks"] = tm.stop(); return CGX_OK; }
-    uint64_t *key = nullptr, *skey = nullptr; uint32_t *ord = nullptr, *sord = nullptr, *flags = nullptr, *incl = nullptr;
-    TRY(dalloc(ctx, &key, M)); TRY(dalloc(ctx, &skey, M)); TRY(dalloc(ctx, &ord, M)); TRY(dalloc(ctx, &sord, M)); TRY(dalloc(ctx, &flags, M)); TRY(dalloc(ctx, &incl, M));
-    k_blk_keys<<<nblocks(M, 256), 256, 0, st>>>(ctx->d_lm, ctx->d_up, M, key, ord);
-    TRY(sort_pairs(ctx, key, skey, ord, sord, M, 0, 37));                              // stable: ordinals ascend inside a group
-    k_blk_heads<<<nblocks(M, 256), 256, 0, st>>>(skey, M, flags);
-    TRY(incl_scan(ctx, flags, incl, M));
-    uint32_t G = 0; TRY(d2h(ctx, &G, incl + (M - 1), 1));
-    TRY(dalloc(ctx, &ctx->d_blocks, (size_t)G + 1));
-    uint32_t nlist = 0;
-    if (G) {
-        uint32_t *ho = nullptr, *gi = nullptr, *hos = nullptr, *gis = nullptr, *rank = nullptr;
-        TRY(dalloc(ctx, &ho, G)); TRY(dalloc(ctx, &gi, G)); TRY(dalloc(ctx, &hos, G)); TRY(dalloc(ctx, &gis, G)); TRY(dalloc(ctx, &rank, G));
-        k_blk_headord<<<nblocks(M, 256), 256, 0, st>>>(flags, incl, sord, M, ho, gi);
-        TRY(sort_pairs(ctx, ho, hos, gi, gis, G, 0, (unsigned)bits_for(M)));
-        k_blk_make<<<nblocks(G, 256), 256, 0, st>>>(hos, gis, G, ctx->d_up, ctx->d_down, ctx->d_sa, ctx->d_blocks, rank);
-        // per-query lists
-        uint64_t *qkey = nullptr, *sqkey = nullptr; uint32_t *qord = nullptr, *sqord = nullptr;
-        TRY(dalloc(ctx, &qkey, M)); TRY(dalloc(ctx, &sqkey, M)); TRY(dalloc(ctx, &qord, M)); TRY(dalloc(ctx, &sqord, M));
-        k_blk_qkeys<<<nblocks(M, 256), 256, 0, st>>>(skey, sord, incl, rank, ctx->d_tok2q, M, qkey, qord);
-        TRY(sort_pairs(ctx, qkey, sqkey, qord, sqord, M, 0, 64));
-        k_blk_qheads<<<nblocks(M, 256), 256, 0, st>>>(sqkey, M, flags);
-        TRY(incl_scan(ctx, flags, incl, M));
-        TRY(d2h(ctx, &nlist, incl + (M - 1), 1));
-        uint32_t *lo = nullptr, *lid = nullptr, *los = nullptr, *lq = nullptr;
-        TRY(dalloc(ctx, &lo, (size_t)nlist + 1)); TRY(dalloc(ctx, &lid, (size_t)nlist + 1)); TRY(dalloc(ctx, &los, (size_t)nlist + 1)); TRY(dalloc(ctx, &lq, (size_t)nlist + 1));
-        TRY(dalloc(ctx, &ctx->d_qb_ids, (size_t)nlist + 1));
-        k_blk_qcompact<<<nblocks(M, 256), 256, 0, st>>>(sqkey, sqord, flags, incl, M, lo, lid);
-        TRY(sort_pairs(ctx, lo, los, lid, ctx->d_qb_ids, nlist, 0, (unsigned)bits_for(M)));
-        k_blk_qof<<<nblocks(nlist, 256), 256, 0, st>>>(los, nlist, ctx->d_tok2q, lq);
-        k_csr_offsets<<<nblocks((size_t)nq + 1, 256), 256, 0, st>>>(lq, nlist, nq, ctx->d_qb_off);
-        HIPCHK(stream_wait(ctx)); HIPCHK(hipGetLastError());
-        dfree(ho); dfree(gi); dfree(hos); dfree(gis); dfree(rank); dfree(qkey); dfree(sqkey); dfree(qord); dfree(sqord); dfree(lo); dfree(lid); dfree(los); dfree(lq);
-    } else { TRY(dalloc(ctx, &ctx->d_qb_ids, 1)); }
-    dfree(key); dfree(skey); dfree(ord); dfree(sord); dfree(flags); dfree(incl);
-    ctx->g = G; ctx->nqb = nlist;
-    ctx->ms["blocks"] = tm.stop();
-    return CGX_OK;
-}
-
-// one launch family: scan the per-unit sample counts, run the kernel in chunks, sort the keys
-struct keyset { uint64_t *hi = nullptr, *lo = nullptr; unsigned int *count = nullptr; size_t cap = 0; uint32_t n = 0; };
-static int keyset_alloc(cgx_ctx *ctx, keyset &k, size_t cap) {
-    k.cap = cap; TRY(dalloc(ctx, &k.hi, cap)); TRY(dalloc(ctx, &k.lo, cap)); TRY(dalloc(ctx, &k.count, 1));
-    HIPCHK(hipMemsetAsync(k.count, 0, 4, ctx->stream));
-    return CGX_OK;
-}
-static int keyset_finish(cgx_ctx *ctx, keyset &k, unsigned lo_bits) {
-    unsigned int c = 0; TRY(d2h(ctx, &c, k.count, 1)); k.n = c;
-    if (c > k.cap) { snprintf(ctx->err, sizeof ctx->err, "rule buffer overflow"); return CGX_ERR_STATE; }
-    TRY(sort128(ctx, k.hi, k.lo, c, lo_bits, 64));
-    return CGX_OK;
-}
-static void keyset_free(keyset &k) { dfree(k.hi); dfree(k.lo); dfree(k.count); }
-
-extern "C" int cgx_extract(cgx_ctx *ctx) {
-    if (!ctx || !ctx->d_blocks || !ctx->have_sa) return CGX_ERR_STATE;
-    HIPCHK(hipSetDevice(ctx->device));
-    Timer tm(ctx->stream);
-    hipStream_t st = ctx->stream;
-    cgx_view v{ctx->d_str, ctx->d_rlp, ctx->d_ltar, ctx->d_rtar, ctx->n};
-    dfree(ctx->d_r0); dfree(ctx->d_r1); dfree(ctx->d_r2);
-    unsigned int *guard = nullptr; TRY(dalloc(ctx, &guard, 1)); HIPCHK(hipMemsetAsync(guard, 0, 4, st));
-    const uint32_t G = ctx->g, D1 = ctx->d1, D2 = ctx->d2;
-    uint64_t chunk = ctx->chunk_items;
-
-    // work lists
-    uint64_t *wA = nullptr, *oA = nullptr, *wB = nullptr, *oB = nullptr, *wC = nullptr, *oC = nullptr; uint64_t WA = 0, WB = 0, WC = 0;
-    TRY(dalloc(ctx, &wA, (size_t)G + 1)); TRY(dalloc(ctx, &oA, (size_t)G + 1)); HIPCHK(hipMemsetAsync(wA, 0, ((size_t)G + 1) * 8, st));
-    if (G) k_work_blocks<<<nblocks(G, 256), 256, 0, st>>>(ctx->d_blocks, G, wA);
-    TRY(excl_scan(ctx, wA, oA, (size_t)G + 1)); TRY(d2h(ctx, &WA, oA + G, 1));
-    TRY(dalloc(ctx, &wB, (size_t)D2 + 1)); TRY(dalloc(ctx, &oB, (size_t)D2 + 1)); HIPCHK(hipMemsetAsync(wB, 0, ((size_t)D2 + 1) * 8, st));
-    if (D2) k_work_two<<<nblocks(D2, 256), 256, 0, st>>>(ctx->d_s2, D2, wB);
-    TRY(excl_scan(ctx, wB, oB, (size_t)D2 + 1)); TRY(d2h(ctx, &WB, oB + D2, 1));
-    TRY(dalloc(ctx, &wC, (size_t)D1 + 1)); TRY(dalloc(ctx, &oC, (size_t)D1 + 1)); HIPCHK(hipMemsetAsync(wC, 0, ((size_t)D1 + 1) * 8, st));
-    if (D1) k_work_one<<<nblocks(D1, 256), 256, 0, st>>>(ctx->d_s1, D1, ctx->d_hits1, ctx->d_pidx, wC);
-    TRY(excl_scan(ctx, wC, oC, (size_t)D1 + 1)); TRY(d2h(ctx, &WC, oC + D1, 1));
-    ctx->ms["extract_items"] = (double)(WA + WB + WC);
-    if (WA + 2 * WC > 0x7FFFFFF0ull || 2 * WA > 0x7FFFFFF0ull || WA + WB + 2 * WC > 0x7FFFFFF0ull) { snprintf(ctx->err, sizeof ctx->err, "too many sampled occurrences for one batch"); return CGX_ERR_NOMEM; }
-
-    // launch 1: ab / Xab / abX / XabX
-    keyset a0, a1, a2, b2, c1, c2;
-    TRY(keyset_alloc(ctx, a0, WA)); TRY(keyset_alloc(ctx, a1, 2 * WA)); TRY(keyset_alloc(ctx, a2, WA));
-    for (uint64_t w0 = 0; w0 < WA; w0 += chunk) {
-        uint64_t nw = WA - w0 < chunk ? WA - w0 : chunk;
-        k_extract0<<<nblocks(nw, 256), 256, 0, st>>>(v, ctx->d_sa, ctx->d_blocks, oA, G, w0, nw, keybuf{a0.hi, a0.lo, a0.count}, keybuf{a1.hi, a1.lo, a1.count}, keybuf{a2.hi, a2.lo, a2.count}, guard);
-    }
-    HIPCHK(hipGetLastError());
-    TRY(keyset_finish(ctx, a0, 8)); TRY(keyset_finish(ctx, a1, 24)); TRY(keyset_finish(ctx, a2, 40));
-    // launch 2: aXbXc
-    TRY(keyset_alloc(ctx, b2, WB));
-    for (uint64_t w0 = 0; w0 < WB; w0 += chunk) {
-        uint64_t nw = WB - w0 < chunk ? WB - w0 : chunk;
-        k_extract2<<<nblocks(nw, 256), 256, 0, st>>>(v, ctx->d_s2, ctx->d_s1, ctx->d_hits2, oB, D2, w0, nw, keybuf{b2.hi, b2.lo, b2.count}, guard);
-    }
-    HIPCHK(hipGetLastError());
-    TRY(keyset_finish(ctx, b2, 40));
-    // launch 3: aXb / XaXb / aXbX
-    TRY(keyset_alloc(ctx, c1, WC)); TRY(keyset_alloc(ctx, c2, 2 * WC));
-    for (uint64_t w0 = 0; w0 < WC; w0 += chunk) {
-        uint64_t nw = WC - w0 < chunk ? WC - w0 : chunk;
-        k_extract1<<<nblocks(nw, 256), 256, 0, st>>>(v, ctx->d_s1, ctx->d_hits1, ctx->d_pidx, ctx->d_phit_start, ctx->d_phit_len, oC, D1, w0, nw,
-                                                     keybuf{c1.hi, c1.lo, c1.count}, keybuf{c2.hi, c2.lo, c2.count}, guard);
-    }
-    HIPCHK(hipGetLastError());
-    TRY(keyset_finish(ctx, c1, 24)); TRY(keyset_finish(ctx, c2, 40));
-
-    // concatenate like ExtractPair.cu:3419-3666: r1 = [Xab,abX | aXb], r2 = [XabX | aXbXc | XaXb,aXbX]
-    ctx->n0 = a0.n; ctx->sep1 = a1.n; ctx->n1 = a1.n + c1.n; ctx->sep2a = a2.n; ctx->sep2b = a2.n + b2.n; ctx->n2 = a2.n + b2.n + c2.n;
-    TRY(dalloc(ctx, &ctx->d_r0, ctx->n0)); TRY(dalloc(ctx, &ctx->d_r1, ctx->n1)); TRY(dalloc(ctx, &ctx->d_r2, ctx->n2));
-    if (a0.n) k_pack_r0<<<nblocks(a0.n, 256), 256, 0, st>>>(a0.hi, a0.lo, a0.n, ctx->d_r0);
-    if (a1.n) k_pack_r1<<<nblocks(a1.n, 256), 256, 0, st>>>(a1.hi, a1.lo, a1.n, ctx->d_r1);
-    if (c1.n) k_pack_r1<<<nblocks(c1.n, 256), 256, 0, st>>>(c1.hi, c1.lo, c1.n, ctx->d_r1 + a1.n);
-    if (a2.n) k_pack_r2<<<nblocks(a2.n, 256), 256, 0, st>>>(a2.hi, a2.lo, a2.n, ctx->d_r2);
-    if (b2.n) k_pack_r2<<<nblocks(b2.n, 256), 256, 0, st>>>(b2.hi, b2.lo, b2.n, ctx->d_r2 + a2.n);
-    if (c2.n) k_pack_r2<<<nblocks(c2.n, 256), 256, 0, st>>>(c2.hi, c2.lo, c2.n, ctx->d_r2 + a2.n + b2.n);
-    HIPCHK(stream_wait(ctx));
-    unsigned int gx = 0; TRY(d2h(ctx, &gx, guard, 1)); ctx->guard_exits = gx;
-    keyset_free(a0); keyset_free(a1); keyset_free(a2); keyset_free(b2); keyset_free(c1); keyset_free(c2);
-    dfree(wA); dfree(oA); dfree(wB); dfree(oB); dfree(wC); dfree(oC); dfree(guard);
-    HIPCHK(hipGetLastError());
-    ctx->ms["extract"] = tm.stop();
-    return CGX_OK;
-}
-
-// ------------------------------------------------------------------------------------
-// lexical features (lexicalTaskMaxEF, ExtractPair.cu:2144-2432): one lane per distinct rule
-// ------------------------------------------------------------------------------------
-__global__ void k_lextask(cgx_lexview t, const int32_t *tstr, const cgx_lextask *tasks, uint32_t n, uint32_t n1, uint32_t n12, float *fe, float *ef) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    cgx_lextask k = tasks[i];
-    int kind = i < n1 ? 0 : i < n12 ? 1 : 2;
-    int32_t src[5];
-    for (int j = 0; j < 5; j++) src[j] = k.src[j];
-    float a, b;
-    cgx_maxlex(t, tstr, src, k.nsrc, k.tstart, k.end, k.gap1, k.gap1_1, k.gap2, k.gap2_1, kind, &a, &b);
-    fe[i] = a; ef[i] = b;
-}
-extern "C" int cgx_lex_features(cgx_ctx *ctx, const cgx_lextask *tasks, uint32_t ntask, uint32_t n_onegap, uint32_t n_twogap, float *max_fe, float *max_ef) {
-    if (!ctx || !ctx->d_lexkey || (ntask && (!tasks || !max_fe || !max_ef))) return CGX_ERR_ARG;
-    HIPCHK(hipSetDevice(ctx->device));
-    Timer tm(ctx->stream);
-    if (ntask) {
-        cgx_lextask *d = nullptr; float *fe = nullptr, *ef = nullptr;
-        TRY(dalloc(ctx, &d, ntask)); TRY(dalloc(ctx, &fe, ntask)); TRY(dalloc(ctx, &ef, ntask));
-        TRY(h2d(ctx, d, tasks, ntask));
-        cgx_lexview t = lex_view(ctx);
-        k_lextask<<<nblocks(ntask, 128), 128, 0, ctx->stream>>>(t, ctx->d_tstr, d, ntask, n_onegap, n_onegap + n_twogap, fe, ef);
-        HIPCHK(hipGetLastError());
-        TRY(d2h(ctx, max_fe, fe, ntask)); TRY(d2h(ctx, max_ef, ef, ntask));
-        dfree(d); dfree(fe); dfree(ef);
-    }
-    ctx->ms["lex"] = tm.stop();
-    return CGX_OK;
-}
-
-// ------------------------------------------------------------------------------------
-// device lexicon (replaces createLexiconGappyFast / TwoGapFast / Fast, ExtractPair.c:515-1276,
-// and feeds lexicalTaskMaxEF without a host round trip).
-// Per rule array (already in canonical order): hash the target side (words, [X,1], [X,2]) ->
-// stable sort by (converted id, hash) -> each run is one lexicon line whose first rule is the
-// smallest rule index (first occurrence) and whose length is paircount -> lines re-sorted by
-// first rule index = the reference's first-occurrence order inside each id group.  Equal keys
-// are verified tuple-by-tuple; a genuine 64-bit collision is reported so that the caller can
-// take the exact host path instead.
-// ------------------------------------------------------------------------------------
-struct lexsrc {              // everything needed to name a group's source side on the device
-    const cgx_block *blocks; const cgx_gapsearch *s1; const cgx_twogapsearch *s2; const cgx_gappat *p1; const int32_t *c2;
-    const int32_t *str; const int32_t *tstr; const cgx_hit1 *hits1; const uint32_t *pidx; const int32_t *miss;
-    uint32_t G, D1, D2, sep1, sep2a, sep2b;
-};
-struct rulerec { int32_t id; uint32_t tstart; uint8_t end, g1, g1e, g2, g2e; };
-__device__ __forceinline__ rulerec load_rule(int kind, const cgx_rule0 *r0, const cgx_rule1 *r1, const cgx_rule2 *r2, uint32_t i) {
-    rulerec r; r.g1 = r.g1e = r.g2 = r.g2e = 0;
-    if (kind == 0) { cgx_rule0 x = r0[i]; r.id = x.block; r.tstart = (uint32_t)x.tar_start; r.end = x.tar_end; }
-    else if (kind == 1) { cgx_rule1 x = r1[i]; r.id = x.id; r.tstart = x.tstart; r.end = x.end; r.g1 = x.gap1; r.g1e = x.gap1_1; }
-    else { cgx_rule2 x = r2[i]; r.id = x.id; r.tstart = x.tstart; r.end = x.end; r.g1 = x.gap1; r.g1e = x.gap1_1; r.g2 = x.gap2; r.g2e = x.gap2_1; }
-    return r;
-}
-__device__ __forceinline__ uint32_t conv_id(const lexsrc &L, int kind, uint32_t i, int32_t id) {      // ExtractPair.c:724-728, 1000-1006
-    if (kind == 0) return (uint32_t)id;
-    if (kind == 1) return i < L.sep1 ? (uint32_t)id : 2 * L.G + (uint32_t)id;
-    return i < L.sep2a ? (uint32_t)id : i < L.sep2b ? L.G + (uint32_t)id : L.G + L.D2 + (uint32_t)id;
-}
-// target side as symbols: words, -1 for [X,1], -2 for [X,2] (ExtractPair.c:813-837, 1141-1163)
-__device__ __forceinline__ int target_syms(const int32_t *tstr, const rulerec &r, int kind, int32_t *out) {
-    int n = 0; uint32_t t0 = r.tstart, t1 = t0 + r.end, a = t0 + r.g1, b = t0 + r.g1e, c = t0 + r.g2, d = t0 + r.g2e;
-    for (uint32_t jj = t0; jj <= t1 && n < 32; jj++) {
-        if (kind >= 1 && jj >= a && jj <= b) { out[n++] = -1; jj = b; }
-        else if (kind >= 2 && jj >= c && jj <= d) { out[n++] = -2; jj = d; }
-        else out[n++] = tstr[jj];
-    }
-    return n;
-}
-__global__ void k_rule_hash(lexsrc L, int kind, const cgx_rule0 *r0, const cgx_rule1 *r1, const cgx_rule2 *r2, uint32_t n, uint64_t *hi, uint64_t *lo) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    rulerec r = load_rule(kind, r0, r1, r2, i);
-    int32_t sym[32]; int m = target_syms(L.tstr, r, kind, sym);
-    uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)m;
-    for (int k = 0; k < m; k++) { h ^= (uint64_t)(uint32_t)sym[k]; h *= 0xff51afd7ed558ccdull; h ^= h >> 32; h *= 0xc4ceb9fe1a85ec53ull; h ^= h >> 29; }
-    hi[i] = conv_id(L, kind, i, r.id); lo[i] = h;
-}
-__global__ void k_lex_heads(lexsrc L, int kind, const cgx_rule0 *r0, const cgx_rule1 *r1, const cgx_rule2 *r2, const uint64_t *hi, const uint64_t *lo, const uint32_t *perm,
-                            uint32_t n, uint32_t *flags, unsigned int *collisions) {
-    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    bool head = j == 0 || hi[j] != hi[j - 1] || lo[j] != lo[j - 1];
-    if (!head) {                                            // same key as the previous rule: the tuples must really be equal
-        rulerec a = load_rule(kind, r0, r1, r2, perm[j]), b = load_rule(kind, r0, r1, r2, perm[j - 1]);
-        int32_t sa[32], sb[32]; int na = target_syms(L.tstr, a, kind, sa), nb = target_syms(L.tstr, b, kind, sb);
-        bool same = na == nb; for (int k = 0; same && k < na; k++) same = sa[k] == sb[k];
-        if (!same) atomicAdd(collisions, 1u);
-    }
-    flags[j] = head ? 1u : 0u;
-}
-// one record per lexicon line, keyed by its first rule index
-__global__ void k_lex_entries(const uint32_t *flags, const uint32_t *incl, const uint32_t *perm, uint32_t n, uint32_t *first_rule, uint32_t *runstart) {
-    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < n && flags[j]) { uint32_t e = incl[j] - 1; first_rule[e] = perm[j]; runstart[e] = j; }
-}
-__device__ __forceinline__ int dev_marker_fsample(const lexsrc &L, uint32_t one) {         // ExtractPair.c:895-908
-    cgx_gapsearch s = L.s1[one]; int fs = 1 + s.sa_end - s.sa_start;
-    if (s.marker) { uint32_t pre = L.hits1[s.sa_start].str_position; fs = (int)(1 - L.pidx[2 * pre] + L.pidx[2 * pre + 1] + (uint32_t)L.miss[pre]); }
-    return fs;
-}
-__device__ __forceinline__ int dev_group_fsample(const lexsrc &L, int kind, uint32_t cid) {
-    const uint32_t G = L.G, D1 = L.D1, D2 = L.D2; int fs;
-    if (kind == 0) fs = 1 + L.blocks[cid].end - L.blocks[cid].start;
-    else if (kind == 1) { if (cid < 2 * G) { uint32_t r = cid >= G ? cid - G : cid; fs = 1 + L.blocks[r].end - L.blocks[r].start; } else fs = dev_marker_fsample(L, cid - 2 * G); }
-    else if (cid < G) fs = 1 + L.blocks[cid].end - L.blocks[cid].start;
-    else if (cid < G + D2) fs = 1 + L.s2[cid - G].sa_end - L.s2[cid - G].sa_start;
-    else fs = dev_marker_fsample(L, cid < G + D2 + D1 ? cid - G - D2 : cid - G - D2 - D1);
-    return fs > CGX_SAMPLER ? CGX_SAMPLER : fs;
-}
-__device__ __forceinline__ int dev_pattern_src(const cgx_gappat *p, int32_t *src) { int n = 0; cgx_gappat x = *p; for (int j = 0; j < x.number; j++) if (x.pat[j] >= 0) src[n++] = x.pat[j]; return n; }
-__device__ __forceinline__ int dev_block_src(const lexsrc &L, uint32_t bn, int32_t *src) { cgx_block k = L.blocks[bn]; for (int s = 0; s < k.matchlen; s++) src[s] = L.str[k.string_start + s]; return k.matchlen; }
-__device__ __forceinline__ int dev_group_src(const lexsrc &L, int kind, uint32_t cid, int32_t *src) {
-    const uint32_t G = L.G, D1 = L.D1, D2 = L.D2;
-    if (kind == 0) return dev_block_src(L, cid, src);
-    if (kind == 1) return cid < 2 * G ? dev_block_src(L, cid < G ? cid : cid - G, src) : dev_pattern_src(&L.p1[L.s1[cid - 2 * G].position], src);
-    if (cid < G) return dev_block_src(L, cid, src);
-    if (cid < G + D2) { cgx_twogapsearch t = L.s2[cid - G]; int n = dev_pattern_src(&L.p1[L.s1[t.blockid].position], src); src[n++] = L.c2[t.position]; return n; }
-    return dev_pattern_src(&L.p1[L.s1[cid < G + D2 + D1 ? cid - G - D2 : cid - G - D2 - D1].position], src);
-}
-// group size f of every rule: rules of one converted id are contiguous
-__global__ void k_cid_flags(lexsrc L, int kind, const cgx_rule0 *r0, const cgx_rule1 *r1, const cgx_rule2 *r2, uint32_t n, uint32_t *flags) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint32_t c = conv_id(L, kind, i, load_rule(kind, r0, r1, r2, i).id);
-    flags[i] = (i == 0 || c != conv_id(L, kind, i - 1, load_rule(kind, r0, r1, r2, i - 1).id)) ? 1u : 0u;
-}
-__global__ void k_group_starts(const uint32_t *flags, const uint32_t *incl, uint32_t n, uint32_t *gstart) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && flags[i]) gstart[incl[i] - 1] = i;
-}
-// final pass: one lane per lexicon line (in first-occurrence order): fill the wire record and run MaxLex
-__global__ __launch_bounds__(128) void k_lex_finish(lexsrc L, cgx_lexview T, int kind, const cgx_rule0 *r0, const cgx_rule1 *r1, const cgx_rule2 *r2, uint32_t nrules,
-                             const uint32_t *first_rule_sorted, const uint32_t *entry_of_sorted, const uint32_t *runstart, uint32_t nent, uint32_t nruns_total,
-                             const uint32_t *gidx_incl, const uint32_t *gstart, uint32_t ngroups, cgx_lexent *out) {
-    uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= nent) return;
-    uint32_t rule = first_rule_sorted[e], orig = entry_of_sorted[e];
-    uint32_t rs = runstart[orig], re = orig + 1 < nruns_total ? runstart[orig + 1] : nrules;      // run [rs,re) in (id,hash) order
-    rulerec r = load_rule(kind, r0, r1, r2, rule);
-    uint32_t cid = conv_id(L, kind, rule, r.id);
-    uint32_t g = gidx_incl[rule] - 1; uint32_t gs = gstart[g], ge = g + 1 < ngroups ? gstart[g + 1] : nrules;
-    cgx_lexent o;
-    o.id = (int32_t)cid; o.tstart = r.tstart; o.end = r.end; o.gap1 = r.g1; o.gap1_1 = r.g1e; o.gap2 = r.g2; o.gap2_1 = r.g2e; o.kind = (uint8_t)kind;
-    o.f = (uint16_t)(ge - gs); o.fsample = (uint16_t)dev_group_fsample(L, kind, cid); o.paircount = (uint16_t)(re - rs);
-    int32_t src[8]; int nsrc = dev_group_src(L, kind, cid, src);
-    float fe, ef;
-    cgx_maxlex(T, L.tstr, src, nsrc, r.tstart, r.end, r.g1, r.g1e, r.g2, r.g2e, kind == 1 ? 0 : kind == 2 ? 1 : 2, &fe, &ef);
-    o.fe = fe; o.ef = ef;
-    out[e] = o;
-}
-
-// id -> [first,last] lexicon line (the host loops of ExtractPair.cu:3745-3756, 3805-3816 and extractGlobalPairsUpDown)
-__global__ void k_lex_ranges(const cgx_lexent *lex, uint32_t nl, int32_t *rng) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nl) return;
-    int32_t id = lex[i].id;
-    if (i == 0 || lex[i - 1].id != id) rng[2 * (size_t)id] = (int32_t)i;
-    if (i + 1 == nl || lex[i + 1].id != id) rng[2 * (size_t)id + 1] = (int32_t)i;
-}
-static int lexicon_kind(cgx_ctx *ctx, const lexsrc &L, const cgx_lexview &T, int kind, uint32_t n, uint32_t nid, cgx_lexent **out, uint32_t *nout, int32_t **rng) {
-    hipStream_t st = ctx->stream;
-    *out = nullptr; *nout = 0;
-    TRY(dalloc(ctx, out, 1));
-    TRY(dalloc(ctx, rng, (size_t)2 * nid + 2));
-    HIPCHK(hipMemsetAsync(*rng, 0xFF, ((size_t)2 * nid + 2) * 4, st));
-    if (n == 0) return CGX_OK;
-    uint64_t *hi = nullptr, *lo = nullptr; uint32_t *perm = nullptr, *flags = nullptr, *incl = nullptr; unsigned int *coll = nullptr;
-    TRY(dalloc(ctx, &hi, n)); TRY(dalloc(ctx, &lo, n)); TRY(dalloc(ctx, &flags, n)); TRY(dalloc(ctx, &incl, n)); TRY(dalloc(ctx, &coll, 1));
-    HIPCHK(hipMemsetAsync(coll, 0, 4, st));
-    k_rule_hash<<<nblocks(n, 256), 256, 0, st>>>(L, kind, ctx->d_r0, ctx->d_r1, ctx->d_r2, n, hi, lo);
-    TRY(sort128(ctx, hi, lo, n, 64, (unsigned)bits_for(nid), &perm));
-    k_lex_heads<<<nblocks(n, 256), 256, 0, st>>>(L, kind, ctx->d_r0, ctx->d_r1, ctx->d_r2, hi, lo, perm, n, flags, coll);
-    TRY(incl_scan(ctx, flags, incl, n));
-    uint32_t nent = 0; TRY(d2h(ctx, &nent, incl + (n - 1), 1));
-    unsigned int nc = 0; TRY(d2h(ctx, &nc, coll, 1));
-    if (nc) { snprintf(ctx->err, sizeof ctx->err, "target-side hash collision in the device lexicon (%u)", nc); return CGX_ERR_STATE; }
-    uint32_t *first = nullptr, *runstart = nullptr, *sfirst = nullptr, *eid = nullptr, *seid = nullptr;
-    TRY(dalloc(ctx, &first, nent)); TRY(dalloc(ctx, &runstart, nent)); TRY(dalloc(ctx, &sfirst, nent)); TRY(dalloc(ctx, &eid, nent)); TRY(dalloc(ctx, &seid, nent));
-    k_lex_entries<<<nblocks(n, 256), 256, 0, st>>>(flags, incl, perm, n, first, runstart);
-    k_iota<<<nblocks(nent, 256), 256, 0, st>>>(eid, nent);
-    TRY(sort_pairs(ctx, first, sfirst, eid, seid, nent, 0, (unsigned)bits_for(n)));             // lines in first-occurrence order
-    // group sizes
-    uint32_t *gflags = flags, *gincl = incl;                                                   // reuse
-    k_cid_flags<<<nblocks(n, 256), 256, 0, st>>>(L, kind, ctx->d_r0, ctx->d_r1, ctx->d_r2, n, gflags);
-    TRY(incl_scan(ctx, gflags, gincl, n));
-    uint32_t ng = 0; TRY(d2h(ctx, &ng, gincl + (n - 1), 1));
-    uint32_t *gstart = nullptr; TRY(dalloc(ctx, &gstart, ng));
-    k_group_starts<<<nblocks(n, 256), 256, 0, st>>>(gflags, gincl, n, gstart);
-    dfree(*out); TRY(dalloc(ctx, out, nent));
-    k_lex_finish<<<nblocks(nent, 128), 128, 0, st>>>(L, T, kind, ctx->d_r0, ctx->d_r1, ctx->d_r2, n, sfirst, seid, runstart, nent, nent, gincl, gstart, ng, *out);
-    k_lex_ranges<<<nblocks(nent, 256), 256, 0, st>>>(*out, nent, *rng);
-    HIPCHK(stream_wait(ctx)); HIPCHK(hipGetLastError());
-    *nout = nent;
-    dfree(hi); dfree(lo); dfree(perm); dfree(flags); dfree(incl); dfree(coll); dfree(first); dfree(runstart); dfree(sfirst); dfree(eid); dfree(seid); dfree(gstart);
-    return CGX_OK;
-}
-extern "C" int cgx_lexicon(cgx_ctx *ctx) {
-    if (!ctx || !ctx->d_blocks || !ctx->d_r0 || !ctx->d_lexkey) return CGX_ERR_STATE;
-    HIPCHK(hipSetDevice(ctx->device));
-    if (ctx->force_host_lexicon) { snprintf(ctx->err, sizeof ctx->err, "target-side hash collision in the device lexicon (forced by option)"); return CGX_ERR_STATE; }
-    Timer tm(ctx->stream);
-    dfree(ctx->d_lex0); dfree(ctx->d_lex1); dfree(ctx->d_lex2); ctx->nl0 = ctx->nl1 = ctx->nl2 = 0;
-    lexsrc L{ctx->d_blocks, ctx->d_s1, ctx->d_s2, ctx->d_p1, ctx->d_c2, ctx->d_str, ctx->d_tstr, ctx->d_hits1, ctx->d_pidx, ctx->d_miss,
-             ctx->g, ctx->d1, ctx->d2, ctx->sep1, ctx->sep2a, ctx->sep2b};
-    cgx_lexview T = lex_view(ctx);
-    dfree(ctx->d_rng0); dfree(ctx->d_rng1); dfree(ctx->d_rng2);
-    TRY(lexicon_kind(ctx, L, T, 1, ctx->n1, 2 * ctx->g + ctx->d1, &ctx->d_lex1, &ctx->nl1, &ctx->d_rng1));
-    TRY(lexicon_kind(ctx, L, T, 2, ctx->n2, ctx->g + 2 * ctx->d1 + ctx->d2, &ctx->d_lex2, &ctx->nl2, &ctx->d_rng2));
-    TRY(lexicon_kind(ctx, L, T, 0, ctx->n0, ctx->g, &ctx->d_lex0, &ctx->nl0, &ctx->d_rng0));
-    ctx->ms["lexicon"] = tm.stop();
-    return CGX_OK;
-}
-
-
-// ------------------------------------------------------------------------------------
-// pinned result arenas: the big per-batch results (lexicon lines) are copied device->host by
-// DMA into page-locked memory owned by the context.  Two arenas alternate between batches so
-// that the background writer of batch k can still read its arena while batch k+1 is fetched.
-// ------------------------------------------------------------------------------------
-extern "C" int cgx_pinned_next_batch(cgx_ctx *ctx) {
-    if (!ctx) return CGX_ERR_ARG;
-    ctx->arena_sel ^= 1; ctx->arena_used[ctx->arena_sel] = 0;
-    return CGX_OK;
-}
-extern "C" int cgx_fetch_pinned(cgx_ctx *ctx, const char *name, void **out, int64_t *nbytes) {
-    if (!ctx || !name || !out || !nbytes) return CGX_ERR_ARG;
-    HIPCHK(hipSetDevice(ctx->device));
-    int64_t bytes = cgx_fetch(ctx, name, nullptr, 0);
-    if (bytes < 0) return (int)bytes;
-    int a = ctx->arena_sel;
-    size_t need = ((size_t)bytes + 255) & ~(size_t)255;
-    if (ctx->arena_used[a] + need > ctx->arena_cap[a]) {
-        if (ctx->arena_used[a] != 0) {                       // arena already holds results of this batch: fall back to a plain fetch into malloc memory
-            *out = nullptr; *nbytes = bytes; return CGX_ERR_NOMEM;
-        }
-        if (ctx->arena[a]) (void)hipHostFree(ctx->arena[a]);
-        ctx->arena[a] = nullptr; ctx->arena_cap[a] = 0;
-        size_t cap = need * 3 + (64u << 20);                 // room for the three lexicons of a batch of this size
-        if (hipHostMalloc(&ctx->arena[a], cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); *out = nullptr; *nbytes = bytes; return CGX_ERR_NOMEM; }
-        ctx->arena_cap[a] = cap;
-    }
-    char *dst = (char *)ctx->arena[a] + ctx->arena_used[a];
-    if (bytes) { int64_t got = cgx_fetch(ctx, name, dst, bytes); if (got < 0) return (int)got; }
-    ctx->arena_used[a] += need;
-    *out = dst; *nbytes = bytes;
-    return CGX_OK;
-}
-
-#include "cgx_format.inc"
+// The stages live in .inc files that are part of this translation unit (shared static helpers above):
+#include "cgx_index.inc"      // index upload, suffix array, frequent-pair precomputation, bigram table, replica plumbing
+#include "cgx_search.inc"     // query upload, batched SA interval search, one-/two-gap enumeration and corpus lookups (cgx_sa_lookup, cgx_gappy_search)
+#include "cgx_extract.inc"    // rule extraction (three launch families) and GenerateBlocks on the device (cgx_extract, cgx_make_blocks, cgx_set_blocks)
+#include "cgx_lexicon.inc"    // lexical features, device lexicon, pinned result arenas (cgx_lex_features, cgx_lexicon)
 
 // ------------------------------------------------------------------------------------
 // result fetch
