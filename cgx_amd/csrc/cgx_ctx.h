@@ -41,6 +41,7 @@ struct cgx_ctx {
     bool use_lex_hash = true;           // MaxLex pair lookups through the pair hash (0: binary search in the source word's row)
     int64_t auto_batch_tokens = 300000; // with sub_batch == 0: query tokens per internal batch (bounds device memory per call)
     int64_t sub_batch = 0;              // queries per internal batch of cgx_extract_grammars* (0 = all at once)
+    int64_t fault_inject = 0;           // test hook: the n-th device allocation from now fails
     uint32_t pool_cap = 1u << 30;       // test hook: entries of the per-block append pool in use (clamped to POOL_N)
     uint32_t look_rec_cap = 65535;      // test hook: groups with more records than this read them from global memory
     bool wide_hits2 = false;            // test hook: take the >2^24-distinct-two-gap-patterns path

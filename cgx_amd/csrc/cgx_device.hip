@@ -44,31 +44,41 @@ static int fail(cgx_ctx *c, int code, const char *what, hipError_t e) {
 // them (contexts on different devices may be driven from different threads).
 #include <mutex>
 struct DevPool {
-    std::unordered_map<void *, size_t> live;
+    struct blk { size_t bytes; const void *owner; };          // owner != null: a temporary of that context (see dalloc)
+    std::unordered_map<void *, blk> live;
     std::multimap<size_t, void *> cached;
     size_t cached_bytes = 0;
-    void *get(size_t bytes) {
+    void *get(size_t bytes, const void *owner) {
         auto it = cached.lower_bound(bytes);
-        if (it != cached.end() && it->first <= bytes * 2 + (1u << 20)) { void *p = it->second; live[p] = it->first; cached_bytes -= it->first; cached.erase(it); return p; }
+        if (it != cached.end() && it->first <= bytes * 2 + (1u << 20)) { void *p = it->second; live[p] = blk{it->first, owner}; cached_bytes -= it->first; cached.erase(it); return p; }
         void *p = nullptr;
         if (hipMalloc(&p, bytes) != hipSuccess) { trim(); (void)hipGetLastError(); if (hipMalloc(&p, bytes) != hipSuccess) return nullptr; }
-        live[p] = bytes;
+        live[p] = blk{bytes, owner};
         return p;
     }
     bool put(void *p) {
         auto it = live.find(p);
         if (it == live.end()) return false;
-        cached.insert({it->second, p}); cached_bytes += it->second; live.erase(it);
+        cached.insert({it->second.bytes, p}); cached_bytes += it->second.bytes; live.erase(it);
         return true;
+    }
+    size_t sweep(const void *owner) {                         // temporaries a failed call of `owner` left behind
+        size_t n = 0;
+        for (auto it = live.begin(); it != live.end();) {
+            if (it->second.owner == owner) { cached.insert({it->second.bytes, it->first}); cached_bytes += it->second.bytes; it = live.erase(it); n++; }
+            else ++it;
+        }
+        return n;
     }
     void trim() { for (auto &kv : cached) (void)hipFree(kv.second); cached.clear(); cached_bytes = 0; }
 };
 #define CGX_MAX_DEVICES 64
 static DevPool g_pools[CGX_MAX_DEVICES];
 static std::mutex g_pool_lock;
-static void *pool_get(int device, size_t bytes) {
+static DevPool &pool_of(int device) { return g_pools[device < 0 || device >= CGX_MAX_DEVICES ? 0 : device]; }
+static void *pool_get(int device, size_t bytes, const void *owner) {
     std::lock_guard<std::mutex> g(g_pool_lock);
-    return g_pools[device < 0 || device >= CGX_MAX_DEVICES ? 0 : device].get(bytes);      // the caller has made `device` current
+    return pool_of(device).get(bytes, owner);                 // the caller has made `device` current
 }
 static void pool_put(void *p) {
     std::lock_guard<std::mutex> g(g_pool_lock);
@@ -77,12 +87,22 @@ static void pool_put(void *p) {
 }
 static void pool_trim(int device) {
     std::lock_guard<std::mutex> g(g_pool_lock);
-    g_pools[device < 0 || device >= CGX_MAX_DEVICES ? 0 : device].trim();
+    pool_of(device).trim();
+}
+// Every stage entry point starts with this: device temporaries of an earlier call that returned through TRY with an
+// error are handed back to the pool.  A block is a temporary when the pointer that receives it is not a member of the
+// context object (a local of the stage function); results live in context members and are left alone.
+static void stage_enter(cgx_ctx *ctx) {
+    std::lock_guard<std::mutex> g(g_pool_lock);
+    size_t n = pool_of(ctx->device).sweep(ctx);
+    if (n) ctx->ms["swept_temporaries"] += (double)n;
 }
 template <class T> static int dalloc(cgx_ctx *ctx, T **p, size_t count) {
     size_t bytes = (count ? count : 1) * sizeof(T);
     bytes = (bytes + 255) & ~(size_t)255;
-    *p = (T *)pool_get(ctx->device, bytes);
+    const bool member = (const char *)p >= (const char *)ctx && (const char *)p < (const char *)(ctx + 1);
+    if (ctx->fault_inject > 0 && --ctx->fault_inject == 0) { *p = nullptr; return fail(ctx, CGX_ERR_NOMEM, "device allocation (injected fault)", hipErrorOutOfMemory); }
+    *p = (T *)pool_get(ctx->device, bytes, member ? nullptr : (const void *)ctx);
     if (!*p) return fail(ctx, CGX_ERR_NOMEM, "device allocation", hipErrorOutOfMemory);
     return CGX_OK;
 }
@@ -342,6 +362,7 @@ extern "C" void cgx_destroy(cgx_ctx *c) {
     for (int r = 0; r < CGX_COPY_STREAMS; r++) if (c->copy_streams[r]) (void)hipStreamDestroy(c->copy_streams[r]);
     for (int r = 0; r < CGX_MAX_READERS; r++) if (c->copy_done[r]) (void)hipEventDestroy(c->copy_done[r]);
     (void)hipStreamSynchronize(c->stream);
+    stage_enter(c);
     pool_trim(c->device);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -355,6 +376,7 @@ extern "C" int cgx_set_option(cgx_ctx *c, const char *name, int64_t value) {
     if (!strcmp(name, "numa_pin")) { c->numa_pin = value != 0; return CGX_OK; }
     if (!strcmp(name, "use_lex_hash")) { c->use_lex_hash = value != 0; return CGX_OK; }
     if (!strcmp(name, "wide_hits2")) { c->wide_hits2 = value != 0; return CGX_OK; }
+    if (!strcmp(name, "fault_inject")) { c->fault_inject = value; return CGX_OK; }
     if (!strcmp(name, "pool_cap")) { if (value < 1) return CGX_ERR_ARG; c->pool_cap = (uint32_t)(value > POOL_N ? POOL_N : value); return CGX_OK; }
     if (!strcmp(name, "look_rec_cap")) { if (value < 0) return CGX_ERR_ARG; c->look_rec_cap = (uint32_t)(value > 65535 ? 65535 : value); return CGX_OK; }
     if (!strcmp(name, "sub_batch")) { if (value < 0) return CGX_ERR_ARG; c->sub_batch = value; return CGX_OK; }

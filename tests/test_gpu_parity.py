@@ -213,6 +213,29 @@ def test_index_replica_gives_the_same_files(cgx, fixtures_dir, tmp_path):
     rep.close(); root.close(); corpus.close()
 
 
+def test_a_failed_stage_leaves_the_context_usable(cgx, fixtures_dir, tmp_path):
+    """Out-of-memory in the middle of a stage (injected): the call fails loudly, the device temporaries it had allocated
+    are reclaimed at the next stage entry, and the same context then produces the right files."""
+    fx = make_fixture("toy", fixtures_dir); files = op.fixture_args(fx)
+    ex = cgx.Extractor(0); corpus = cgx.Corpus.load(files[0], files[2], files[3], files[4]); ex.upload_corpus(corpus)
+    failures = 0
+    for nth in (3, 9, 17, 30, 55, 90):
+        os.makedirs(str(tmp_path / ("f%d" % nth)))
+        ex.set_option("fault_inject", nth)
+        try:
+            ex.extract_grammars(corpus, files[1], str(tmp_path / ("f%d" % nth)))
+        except cgx.CgxError as e:
+            failures += 1
+            assert "injected fault" in str(e) or "device allocation" in str(e)
+        ex.set_option("fault_inject", 0)
+    assert failures >= 4
+    os.makedirs(str(tmp_path / "ok"))
+    ex.extract_grammars(corpus, files[1], str(tmp_path / "ok"))
+    assert op.sha_dir(str(tmp_path / "ok"), 7) == META["toy"]["grammar"]
+    assert ex.stage_ms("swept_temporaries") > 0
+    ex.close(); corpus.close()
+
+
 def test_bigram_table_does_not_change_intervals(cgx, oracle_bin, fixtures_dir, tmp_path):
     """l = 2 from the bigram hash table vs. by binary search: same lm / up / down (and both equal the oracle)."""
     fx = make_fixture("toy", fixtures_dir); dump = str(tmp_path / "d.bin")
