@@ -119,7 +119,7 @@ def main():
     if args.no_numa_pin:
         ex.set_option("numa_pin", 0)
     if not args.sync_write:
-        ex.set_option("async_write", 1)       # files of step k are written by host threads while the GPU runs step k+1; flushed inside the timed region
+        ex.set_option("async_write", 1); ex.set_option("prealloc_text", 1)       # files of step k are written by host threads while the GPU runs step k+1; flushed inside the timed region
 
     # ---- synthetic corpus (same seed on every rank: host arrays are needed by the host stages) ----
     t0 = time.perf_counter()

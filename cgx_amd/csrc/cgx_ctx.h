@@ -37,6 +37,7 @@ struct cgx_ctx {
     uint32_t *d_pidx = nullptr; int32_t *d_miss = nullptr; uint32_t *d_phit_start = nullptr; uint8_t *d_phit_len = nullptr;
     uint64_t *d_bg_key = nullptr; uint32_t *d_bg_lo = nullptr, *d_bg_hi = nullptr; uint32_t bg_cap = 0; unsigned bg_shift = 0;   // bigram -> SA interval
     bool use_bigrams = true;
+    bool prealloc_text = false;         // allocate both text slots at the first batch (set when more batches will follow)
     bool numa_pin = true;               // writer threads run on the CPUs of the GPU's NUMA node
     bool use_lex_hash = true;           // MaxLex pair lookups through the pair hash (0: binary search in the source word's row)
     int64_t auto_batch_tokens = 300000; // with sub_batch == 0: query tokens per internal batch (bounds device memory per call)

@@ -374,6 +374,7 @@ extern "C" int cgx_set_option(cgx_ctx *c, const char *name, int64_t value) {
     if (!strcmp(name, "device_format")) { c->device_format = value != 0; return CGX_OK; }
     if (!strcmp(name, "use_bigrams")) { c->use_bigrams = value != 0; return CGX_OK; }
     if (!strcmp(name, "numa_pin")) { c->numa_pin = value != 0; return CGX_OK; }
+    if (!strcmp(name, "prealloc_text")) { c->prealloc_text = value != 0; return CGX_OK; }
     if (!strcmp(name, "use_lex_hash")) { c->use_lex_hash = value != 0; return CGX_OK; }
     if (!strcmp(name, "wide_hits2")) { c->wide_hits2 = value != 0; return CGX_OK; }
     if (!strcmp(name, "fault_inject")) { c->fault_inject = value; return CGX_OK; }

@@ -983,6 +983,23 @@ static uint64_t g_pin_bytes;                              /* piece size: fixed a
 #define PIN_RING 3                                        /* copies in flight per writer thread: keeps PCIe busy while the thread sits in pwrite() */
 #define MAX_WRITERS (CGX_MAX_READERS / PIN_RING)
 static void *g_pin[MAX_WRITERS][PIN_RING];                /* page-locked staging buffers, kept for the life of the process */
+static void pin_bytes_init(void) { if (!g_pin_bytes) { const char *e = getenv("CGX_PIN_MB"); long mb = e ? atol(e) : 0; g_pin_bytes = (uint64_t)(mb >= 1 && mb <= 256 ? mb : 16) << 20; } }
+static void pin_to_device_node(cgx_ctx *ctx);
+/* The first batch of a process would otherwise pay for 48 page-locked allocations (about 0.15 s) between the end of
+ * its GPU work and its first file: a helper thread makes them while the GPU stages of that batch run. */
+static pthread_t g_pin_thread; static int g_pin_state;     /* 0 not started, 1 running, 2 joined */
+static void *pin_prepare_main(void *arg) {
+    cgx_ctx *ctx = arg; int nt = nthreads_host(); if (nt > MAX_WRITERS) nt = MAX_WRITERS;
+    pin_to_device_node(ctx);                                  /* first touch on the GPU's node */
+    for (int t = 0; t < nt; t++) for (int k = 0; k < PIN_RING; k++) if (!g_pin[t][k]) g_pin[t][k] = cgx_pinned_alloc(PIN_BYTES);
+    return NULL;
+}
+static void pin_prepare_start(cgx_ctx *ctx) {
+    if (g_pin_state) return;
+    pin_bytes_init();
+    g_pin_state = pthread_create(&g_pin_thread, NULL, pin_prepare_main, ctx) ? 2 : 1;
+}
+static void pin_prepare_join(void) { if (g_pin_state == 1) { pthread_join(g_pin_thread, NULL); g_pin_state = 2; } }
 /* The text of a batch is one byte stream (query after query).  Writers claim fixed PIN_BYTES pieces of the
  * STREAM, not files: every D2H copy is large whatever the file sizes are, and a piece is then scattered
  * into the files it overlaps with pwrite (a file cut by a piece boundary is completed by two writers). */
@@ -1061,12 +1078,12 @@ static int write_empty_files(const uint64_t *qtext, int32_t nq, const char *outd
     }
     return CGX_OK;
 }
-static int write_from_device(cgx_ctx *ctx, int slot, const uint64_t *qtext, int32_t nq, const char *outdir, int32_t first, double *wait_ms, double *file_ms) {
+static int write_from_device_locked(cgx_ctx *ctx, int slot, const uint64_t *qtext, int32_t nq, const char *outdir, int32_t first, double *wait_ms, double *file_ms) {
     int rc = write_empty_files(qtext, nq, outdir, first);
     if (rc != CGX_OK) return rc;
     *wait_ms = *file_ms = 0;
     const uint64_t total = qtext[nq];
-    if (!g_pin_bytes) { const char *e = getenv("CGX_PIN_MB"); long mb = e ? atol(e) : 0; g_pin_bytes = (uint64_t)(mb >= 1 && mb <= 256 ? mb : 16) << 20; }
+    pin_bytes_init(); pin_prepare_join();
     int64_t npieces = (int64_t)((total + PIN_BYTES - 1) / PIN_BYTES), next = 0;
     if (!npieces) return CGX_OK;
     int nt = nthreads_host(); if (nt > MAX_WRITERS) nt = MAX_WRITERS; if (nt > npieces) nt = (int)npieces;
@@ -1084,6 +1101,14 @@ static int write_from_device(cgx_ctx *ctx, int slot, const uint64_t *qtext, int3
     for (int t = 0; t < nt; t++) { if (jobs[t].rc != CGX_OK) return jobs[t].rc; wait += jobs[t].wait_ms; wr += jobs[t].write_ms; }
     *wait_ms = wait / nt; *file_ms = wr / nt;                /* per-thread averages; reported by the caller's thread */
     return CGX_OK;
+}
+/* The staging buffers belong to the process, not to a context: writers of two contexts in one process take turns. */
+static pthread_mutex_t g_writer_lock = PTHREAD_MUTEX_INITIALIZER;
+static int write_from_device(cgx_ctx *ctx, int slot, const uint64_t *qtext, int32_t nq, const char *outdir, int32_t first, double *wait_ms, double *file_ms) {
+    pthread_mutex_lock(&g_writer_lock);
+    int rc = write_from_device_locked(ctx, slot, qtext, nq, outdir, first, wait_ms, file_ms);
+    pthread_mutex_unlock(&g_writer_lock);
+    return rc;
 }
 
 /* number of grammar lines the writer will produce (PrintResults.c:451-570 walked without formatting) */
@@ -1123,6 +1148,7 @@ static int run_batch(cgx_ctx *ctx, const cgx_corpus *c, batch *b, const char *ou
     }
     LAP("blocks");
     const int devfmt = outdir && cgx__option(ctx, "device_format");
+    if (devfmt) pin_prepare_start(ctx);
     if (devfmt && (rc = ensure_vocab(ctx, c)) != CGX_OK) return rc;
     LAP("qblocks");
     if ((rc = cgx_gappy_search(ctx)) != CGX_OK) return rc;
@@ -1303,6 +1329,7 @@ int cgx_extract_grammars_ids(cgx_ctx *ctx, const cgx_corpus *c, const int32_t *q
     const int64_t sub = cgx__option(ctx, "sub_batch"), AUTO_BATCH_TOKENS = cgx__option(ctx, "auto_batch_tokens");
     if ((sub <= 0 || sub >= nq) && ntok <= AUTO_BATCH_TOKENS) return extract_ids_once(ctx, c, qoff, nq, qtok, ntok, outdir, first, nrules);
     uint64_t total = 0;
+    (void)cgx_set_option(ctx, "prealloc_text", 1);           /* several internal batches: both text slots are going to be needed */
     for (int32_t q0 = 0; q0 < nq;) {
         int32_t q1 = q0;
         if (sub > 0) q1 = q0 + (int32_t)sub < nq ? q0 + (int32_t)sub : nq;
