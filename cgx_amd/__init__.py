@@ -281,7 +281,7 @@ class Extractor:
     # ---- whole path ----
     def extract_grammars(self, corpus, qryfile, outdir, q_begin=0, q_end=-1):
         n = C.c_uint64()
-        self._chk(self.lib.cgx_extract_grammars(self.h, corpus.h, qryfile.encode(), outdir.encode(), q_begin, q_end, C.byref(n)), "cgx_extract_grammars")
+        self._chk(self.lib.cgx_extract_grammars(self.h, corpus.h, qryfile.encode(), outdir.encode() if outdir else None, q_begin, q_end, C.byref(n)), "cgx_extract_grammars")
         return int(n.value)
 
     def extract_grammars_ids(self, corpus, qoff, qtok, outdir=None, first=0):

@@ -1160,6 +1160,15 @@ static int run_batch(cgx_ctx *ctx, const cgx_corpus *c, batch *b, const char *ou
     rc = cgx_lexicon(ctx);
     if (rc == CGX_ERR_STATE && strstr(cgx_last_error(ctx), "hash collision")) exact_host = 1; else if (rc != CGX_OK) return rc;
     LAP("lexicon");
+    if (!outdir && !exact_host && cgx__option(ctx, "device_format")) {     /* nothing to write: only the number of rules is wanted */
+        uint64_t nl = 0;
+        if ((rc = cgx_format(ctx, NULL, &nl, NULL)) != CGX_OK) return rc;
+        LAP("format");
+        if (nrules) *nrules = nl;
+        cgx__set_host_ms(ctx, "lists", 0); cgx__set_host_ms(ctx, "lexicon", 0); cgx__set_host_ms(ctx, "write", 0);
+        cgx__set_host_ms(ctx, "total", now_ms() - t0);
+        return CGX_OK;
+    }
     if (devfmt && !exact_host) {
         /* the text of every file is laid out on the GPU; host threads only pull byte ranges and write them */
         uint64_t bytes = 0, nl = 0; int slot = 0;

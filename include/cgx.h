@@ -108,7 +108,7 @@ int cgx_lex_features(cgx_ctx *ctx, const cgx_lextask *tasks, uint32_t ntask, uin
 int cgx_upload_vocab(cgx_ctx *ctx, const char *spool, const uint32_t *soff, uint32_t ns, const char *tpool, const uint32_t *toff, uint32_t nt);
 int cgx_upload_score_tables(cgx_ctx *ctx, const float *aa, const float *bb, const float *fs);
 int cgx_set_query_blocks(cgx_ctx *ctx, const uint32_t *off, const uint32_t *ids);    /* CSR over the batch's queries */
-int cgx_format(cgx_ctx *ctx, uint64_t *total_bytes, uint64_t *total_lines, int *slot); /* after cgx_lexicon; two text slots alternate */
+int cgx_format(cgx_ctx *ctx, uint64_t *total_bytes, uint64_t *total_lines, int *slot); /* after cgx_lexicon; two text slots alternate; slot == NULL: only count the rule lines (total_lines), lay out no text */
 int cgx_text_offsets(cgx_ctx *ctx, int slot, uint64_t *qtext);                       /* nq+1 byte offsets of the queries' text in that slot */
 #define CGX_MAX_READERS 64
 int cgx_text_read(cgx_ctx *ctx, int slot, uint64_t off, uint64_t bytes, void *dst, int reader); /* D2H on side stream `reader` (0..CGX_MAX_READERS-1), thread safe per reader */

@@ -173,6 +173,10 @@ def test_chunking_and_sharding_do_not_change_results(cgx, fixtures_dir, tmp_path
     ex.close()
     ex, corpus2, n2 = run_product(cgx, fx, str(tmp_path / "b"), chunk_items=4096)
     assert n == n2 and op.sha_dir(str(tmp_path / "a"), 7) == op.sha_dir(str(tmp_path / "b"), 7) == META["toy"]["grammar"]
+    for fmt in (1, 0):                                                  # no output directory: only the rule count, same number
+        ex.set_option("device_format", fmt)
+        assert ex.extract_grammars(corpus2, op.fixture_args(fx)[1], None) == n
+    ex.set_option("device_format", 1)
     os.makedirs(str(tmp_path / "c"))
     files = op.fixture_args(fx)
     ex.extract_grammars(corpus2, files[1], str(tmp_path / "c"), 0, 4)
