@@ -50,7 +50,7 @@ ABI = [
     "cgx_create", "cgx_destroy", "cgx_last_error", "cgx_set_option", "cgx_upload_index", "cgx_build_sa", "cgx_precompute",
     "cgx_index_shape", "cgx_index_alloc", "cgx_index_nbuffers", "cgx_index_buffer", "cgx_index_d2d", "cgx_index_finalize", "cgx_broadcast_index",
     "cgx_upload_queries", "cgx_sa_lookup", "cgx_gappy_search", "cgx_make_blocks", "cgx_set_blocks", "cgx_extract", "cgx_lexicon", "cgx_lex_features", "cgx_fetch",
-    "cgx_stage_ms", "cgx_corpus_load", "cgx_corpus_free", "cgx_corpus_checksum", "cgx_corpus_upload", "cgx_extract_grammars", "cgx_extract_grammars_ids",
+    "cgx_stage_ms", "cgx_corpus_load", "cgx_corpus_free", "cgx_corpus_checksum", "cgx_corpus_save", "cgx_corpus_load_cache", "cgx_corpus_upload", "cgx_extract_grammars", "cgx_extract_grammars_ids",
     "cgx_corpus_from_ids", "cgx_host_ms", "cgx_flush", "cgx_fetch_pinned", "cgx_pinned_next_batch", "cgx_upload_vocab", "cgx_upload_score_tables", "cgx_set_query_blocks",
     "cgx_format", "cgx_text_offsets", "cgx_text_read", "cgx_text_read_begin", "cgx_text_read_wait", "cgx_pinned_alloc", "cgx_pinned_free",
 ]
@@ -98,6 +98,8 @@ def load_library():
     lib.cgx_corpus_load.restype = C.c_void_p; lib.cgx_corpus_load.argtypes = [C.c_char_p] * 4 + [C.c_char_p, C.c_size_t]
     lib.cgx_corpus_free.restype = None; lib.cgx_corpus_free.argtypes = [C.c_void_p]
     lib.cgx_corpus_checksum.restype = C.c_uint64; lib.cgx_corpus_checksum.argtypes = [C.c_void_p]
+    lib.cgx_corpus_save.argtypes = [C.c_void_p, C.c_char_p]
+    lib.cgx_corpus_load_cache.restype = C.c_void_p; lib.cgx_corpus_load_cache.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
     lib.cgx_corpus_upload.argtypes = [C.c_void_p, C.c_void_p]
     lib.cgx_extract_grammars.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_uint64)]
     lib.cgx_extract_grammars_ids.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_char_p, C.c_int32, C.POINTER(C.c_uint64)]
@@ -140,6 +142,19 @@ class Corpus:
                                     _ptr(a[4]), _ptr(a[5]), _ptr(a[6]), _ptr(a[7]), _ptr(a[8]), _ptr(a[9]), len(a[8]))
         if not h:
             raise CgxError("cgx_corpus_from_ids failed")
+        return cls(h)
+
+    def save(self, path):
+        rc = load_library().cgx_corpus_save(self.h, path.encode())
+        if rc != 0:
+            raise CgxError("cgx_corpus_save failed (%d)" % rc)
+
+    @classmethod
+    def load_cache(cls, path):
+        lib = load_library(); err = C.create_string_buffer(512)
+        h = lib.cgx_corpus_load_cache(path.encode(), err, 512)
+        if not h:
+            raise CgxError(err.value.decode(errors="replace"))
         return cls(h)
 
     def checksum(self):

@@ -506,6 +506,82 @@ cgx_corpus *cgx_corpus_from_ids(const int32_t *str, uint32_t n, const int32_t *s
     return c;
 }
 
+/* ------------------------------------------------------------------ */
+/* on-disk corpus cache: the parsed corpus as one binary file, so that later runs skip the text loaders
+ * (the reference re-reads and re-tokenises its four text files on every start; its own index cache is
+ * commented out, SuffixArray.c:208-230).  Native byte order; the header carries every count and the
+ * loader checks the file size against them. */
+/* ------------------------------------------------------------------ */
+typedef struct { char magic[8]; uint64_t checksum; uint32_t n, nt, nsent, nlex, nsvocab, ntvocab, maxword, reserved; uint64_t sbytes, tbytes; } cachehdr;
+static const char CACHE_MAGIC[8] = {'C', 'G', 'X', 'C', 'O', 'R', 'P', '1'};
+int cgx_corpus_save(const cgx_corpus *c, const char *path) {
+    if (!c || !path || !c->rlp || !c->svocab || !c->tvocab) return CGX_ERR_ARG;
+    FILE *f = fopen(path, "wb");
+    if (!f) return CGX_ERR_IO;
+    cachehdr h; memset(&h, 0, sizeof h); memcpy(h.magic, CACHE_MAGIC, 8);
+    h.checksum = cgx_corpus_checksum(c); h.n = c->n; h.nt = c->nt; h.nsent = (uint32_t)c->nsent; h.nlex = c->nlex;
+    h.nsvocab = (uint32_t)c->nsvocab; h.ntvocab = (uint32_t)c->ntvocab; h.maxword = c->maxword;
+    for (int32_t i = 0; i < c->nsvocab; i++) h.sbytes += c->svocab[i] ? c->svlen[i] : 0;
+    for (int32_t i = 0; i < c->ntvocab; i++) h.tbytes += c->tvocab[i] ? c->tvlen[i] : 0;
+    int ok = fwrite(&h, sizeof h, 1, f) == 1;
+#define PUT(ptr, count, size) do { if (ok && (count) && fwrite((ptr), (size), (count), f) != (size_t)(count)) ok = 0; } while (0)
+    PUT(c->str, c->n, 4); PUT(c->tstr, c->nt, 4); PUT(c->sentind, (size_t)c->nsent + 1, 4); PUT(c->tsentind, (size_t)c->nsent + 1, 4);
+    PUT(c->P, c->n, 1); PUT(c->rlp, c->n, 4); PUT(c->ltar, c->nt, 1); PUT(c->rtar, c->nt, 1);
+    PUT(c->lexk, c->nlex, sizeof *c->lexk); PUT(c->lexv, c->nlex, sizeof *c->lexv);
+    /* spelling lengths (0 for the unused ids 0 and 1), then the spellings back to back */
+    for (int32_t i = 0; ok && i < c->nsvocab; i++) { uint32_t L = c->svocab[i] ? c->svlen[i] : 0; PUT(&L, 1, 4); }
+    for (int32_t i = 0; ok && i < c->ntvocab; i++) { uint32_t L = c->tvocab[i] ? c->tvlen[i] : 0; PUT(&L, 1, 4); }
+    for (int32_t i = 0; ok && i < c->nsvocab; i++) if (c->svocab[i]) PUT(c->svocab[i], c->svlen[i], 1);
+    for (int32_t i = 0; ok && i < c->ntvocab; i++) if (c->tvocab[i]) PUT(c->tvocab[i], c->tvlen[i], 1);
+#undef PUT
+    if (fclose(f)) ok = 0;
+    return ok ? CGX_OK : CGX_ERR_IO;
+}
+static int cache_words(FILE *f, int32_t nv, char ***voc_out, uint32_t **len_out) {
+    char **voc = calloc((size_t)nv + 1, sizeof *voc); uint32_t *len = calloc((size_t)nv + 1, 4);
+    *voc_out = voc; *len_out = len;
+    if (!voc || !len) return -1;
+    if (nv && fread(len, 4, (size_t)nv, f) != (size_t)nv) return -1;
+    return 0;
+}
+cgx_corpus *cgx_corpus_load_cache(const char *path, char *err, size_t errcap) {
+    char dummy[8]; if (!err) { err = dummy; errcap = sizeof dummy; }
+    err[0] = 0;
+    FILE *f = path ? fopen(path, "rb") : NULL;
+    if (!f) { snprintf(err, errcap, "cannot open corpus cache \"%s\"", path ? path : ""); return NULL; }
+    cachehdr h; cgx_corpus *c = NULL;
+    if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, CACHE_MAGIC, 8)) { snprintf(err, errcap, "\"%s\" is not a corpus cache of this version", path); fclose(f); return NULL; }
+    uint64_t want = sizeof h + (uint64_t)h.n * 9 + (uint64_t)h.nt * 6 + ((uint64_t)h.nsent + 1) * 8 + (uint64_t)h.nlex * (sizeof(cgx_lexkey) + sizeof(cgx_lexval))
+                  + ((uint64_t)h.nsvocab + h.ntvocab) * 4 + h.sbytes + h.tbytes;
+    fseek(f, 0, SEEK_END); uint64_t have = (uint64_t)ftell(f); fseek(f, (long)sizeof h, SEEK_SET);
+    if (have != want || h.n < 4 || h.nt < 2) { snprintf(err, errcap, "corpus cache \"%s\" is truncated or corrupt (%llu bytes, header says %llu)", path, (unsigned long long)have, (unsigned long long)want); fclose(f); return NULL; }
+    c = calloc(1, sizeof *c);
+    if (!c) { fclose(f); return NULL; }
+    c->n = h.n; c->nt = h.nt; c->nsent = (int32_t)h.nsent; c->nlex = h.nlex; c->nsvocab = (int32_t)h.nsvocab; c->ntvocab = (int32_t)h.ntvocab; c->maxword = h.maxword;
+    int ok = 1;
+#define GET(field, count, size) do { if (ok) { (field) = malloc((size_t)(count) * (size) + 16); if (!(field) || ((count) && fread((field), (size), (count), f) != (size_t)(count))) ok = 0; } } while (0)
+    GET(c->str, c->n, 4); GET(c->tstr, c->nt, 4); GET(c->sentind, (size_t)c->nsent + 1, 4); GET(c->tsentind, (size_t)c->nsent + 1, 4);
+    GET(c->P, c->n, 1); GET(c->rlp, c->n, 4); GET(c->ltar, c->nt, 1); GET(c->rtar, c->nt, 1);
+    GET(c->lexk, c->nlex, sizeof *c->lexk); GET(c->lexv, c->nlex, sizeof *c->lexv);
+#undef GET
+    if (ok && (cache_words(f, c->nsvocab, &c->svocab, &c->svlen) || cache_words(f, c->ntvocab, &c->tvocab, &c->tvlen))) ok = 0;
+    if (ok && (wordmap_init(&c->smap, 1 << 16) || wordmap_init(&c->tmap, 1 << 16))) ok = 0;
+    for (int side = 0; ok && side < 2; side++) {
+        int32_t nv = side ? c->ntvocab : c->nsvocab; char **voc = side ? c->tvocab : c->svocab; uint32_t *len = side ? c->tvlen : c->svlen; wordmap *map = side ? &c->tmap : &c->smap;
+        for (int32_t i = 0; ok && i < nv; i++) {
+            if (i < 2 || !len[i]) { if (i >= 2) { snprintf(err, errcap, "corpus cache \"%s\": word %d has no spelling", path, i); ok = 0; } continue; }
+            char *w = malloc((size_t)len[i] + 1);
+            if (!w || fread(w, 1, len[i], f) != len[i]) { free(w); ok = 0; break; }
+            w[len[i]] = 0; voc[i] = w;
+            if (wordmap_put(map, w, i)) ok = 0;
+        }
+    }
+    fclose(f);
+    if (ok && build_word_slots(c)) ok = 0;
+    if (!ok) { if (!err[0]) snprintf(err, errcap, "cannot read corpus cache \"%s\"", path); cgx_corpus_free(c); return NULL; }
+    return c;
+}
+
 int cgx_corpus_upload(cgx_ctx *ctx, const cgx_corpus *c) {
     if (!ctx || !c) return CGX_ERR_ARG;
     cgx_index_host ix; memset(&ix, 0, sizeof ix);

@@ -3,7 +3,8 @@
  * bin/strmatchcuda (Main.c:29-86):
  *   strmatchcuda [-h] [-l minmatchlen] [-t fingerlen] [-s timefile] <src> <query> <tgt> <align> <lex> <outdir>
  * Extra, optional: --device N (default 0), --shard i/n (this process handles the i-th of n
- * contiguous query shards; one process per GPU).
+ * contiguous query shards; one process per GPU), --index-cache FILE (load the parsed corpus from
+ * FILE if it exists, otherwise parse the four text files and write FILE for the next run).
  */
 #include "../../include/cgx.h"
 #include <stdio.h>
@@ -18,11 +19,12 @@ static void print_help(void) {
 }
 
 int main(int argc, char **argv) {
-    int minmatchlen = 1, fingerlen = 10, device = 0, shard = 0, nshard = 1; const char *timefile = NULL;
+    int minmatchlen = 1, fingerlen = 10, device = 0, shard = 0, nshard = 1; const char *timefile = NULL, *cache = NULL;
     /* pull the long options out first so getopt sees the reference's grammar only */
     char **av = malloc(sizeof(char *) * (size_t)(argc + 1)); int ac = 0;
     for (int i = 0; i < argc; i++) {
         if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--index-cache") && i + 1 < argc) cache = argv[++i];
         else if (!strcmp(argv[i], "--shard") && i + 1 < argc) { if (sscanf(argv[++i], "%d/%d", &shard, &nshard) != 2 || nshard < 1 || shard < 0 || shard >= nshard) print_help(); }
         else av[ac++] = argv[i];
     }
@@ -51,7 +53,12 @@ int main(int argc, char **argv) {
     fclose(qf);
 
     char err[512];
-    cgx_corpus *corpus = cgx_corpus_load(src, tgt, ali, lex, err, sizeof err);
+    cgx_corpus *corpus = cache ? cgx_corpus_load_cache(cache, err, sizeof err) : NULL;
+    if (cache && corpus) fprintf(stderr, "strmatchcuda: corpus read from cache %s\n", cache);
+    if (!corpus) {
+        corpus = cgx_corpus_load(src, tgt, ali, lex, err, sizeof err);
+        if (corpus && cache && cgx_corpus_save(corpus, cache) != CGX_OK) fprintf(stderr, "strmatchcuda: could not write the corpus cache %s\n", cache);
+    }
     if (!corpus) {
         if (!strncmp(err, "Not possible, too long", 22)) { printf("%s\n", err); return 1; }
         if (!strcmp(err, "Not possible!")) { printf("%s\n", err); return 0; }

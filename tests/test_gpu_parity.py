@@ -52,6 +52,22 @@ def test_grammar_files_bit_exact(name, device_format, cgx, oracle_bin, fixtures_
     ex.close(); corpus.close()
 
 
+def test_corpus_cache_gives_the_same_files(cgx, fixtures_dir, tmp_path):
+    """--index-cache: the first run parses the text files and writes the cache, the second reads only the cache
+    (the text corpus is gone by then); both produce the golden grammar files."""
+    fx = make_fixture("toy", fixtures_dir); d = tmp_path / "fx"; shutil.copytree(fx, d)
+    cache = str(tmp_path / "toy.cgx"); exe = os.path.join(ROOT, "bin", "strmatchcuda")
+    for run in (0, 1):
+        out = tmp_path / ("o%d" % run); out.mkdir()
+        r = subprocess.run([exe, "--index-cache", cache] + op.fixture_args(str(d)) + [str(out)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        assert ("corpus read from cache" in r.stderr) == (run == 1)
+        assert op.sha_dir(str(out), 7) == META["toy"]["grammar"]
+        if run == 0:
+            for n in ("corpus.f", "corpus.e", "corpus.a", "lex.txt"):
+                os.remove(d / n)
+
+
 def test_cli_is_a_drop_in(cgx, oracle_bin, fixtures_dir, tmp_path):
     """bin/strmatchcuda with the reference's six positionals writes the same files."""
     fx = make_fixture("tiny", fixtures_dir); out = tmp_path / "cli"; out.mkdir()

@@ -64,3 +64,22 @@ def test_lexical_entries_that_straddle_lines(cgx, fixtures_dir, tmp_path):
     rows = (d / "lex.txt").read_text().split()
     (d / "lex.txt").write_text("\n".join(" ".join(rows[i:i + 3]) for i in range(0, len(rows), 3)) + "\n")   # three fields per line
     assert _load(cgx, str(d), 16, 1) == _load(cgx, str(d), 1, 1 << 30) == _load(cgx, fx, 1, 1 << 30)
+
+
+@pytest.mark.parametrize("name", ["tiny", "mid"])
+def test_corpus_cache_round_trip(name, cgx, fixtures_dir, tmp_path):
+    """cgx_corpus_save / cgx_corpus_load_cache: the reloaded corpus is the corpus (checksum over every array and
+    spelling), and damaged files are refused."""
+    fx = make_fixture(name, fixtures_dir); f = op.fixture_args(fx)
+    c = cgx.Corpus.load(f[0], f[2], f[3], f[4]); want = c.checksum()
+    path = str(tmp_path / "corpus.cgx"); c.save(path); c.close()
+    c2 = cgx.Corpus.load_cache(path); assert c2.checksum() == want; c2.close()
+    blob = open(path, "rb").read()
+    open(path, "wb").write(blob[:-7])
+    with pytest.raises(cgx.CgxError, match="truncated or corrupt"):
+        cgx.Corpus.load_cache(path)
+    open(path, "wb").write(b"NOTACGX!" + blob[8:])
+    with pytest.raises(cgx.CgxError, match="not a corpus cache"):
+        cgx.Corpus.load_cache(path)
+    with pytest.raises(cgx.CgxError, match="cannot open"):
+        cgx.Corpus.load_cache(str(tmp_path / "missing.cgx"))
