@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include "cgx_rules.h"
 #define CGX_COPY_STREAMS 3
+struct __attribute__((aligned(16))) cgx_ngslot { unsigned long long key; uint32_t lo, hi; };   // one 16-byte slot: a probe touches one sector
 #include <stdint.h>
 #include <map>
 #include <string>
@@ -35,8 +36,9 @@ struct cgx_ctx {
     uint64_t *d_lexhkey = nullptr; uint32_t *d_lexhidx = nullptr; uint32_t lex_hmask = 0; unsigned lex_hshift = 0;   // pair hash (derived, rebuilt on replicas)
     int32_t *d_tokstart = nullptr; int8_t *d_tokrank = nullptr; int32_t *d_freq = nullptr;
     uint32_t *d_pidx = nullptr; int32_t *d_miss = nullptr; uint32_t *d_phit_start = nullptr; uint8_t *d_phit_len = nullptr;
-    uint64_t *d_bg_key = nullptr; uint32_t *d_bg_lo = nullptr, *d_bg_hi = nullptr; uint32_t bg_cap = 0; unsigned bg_shift = 0;   // bigram -> SA interval
-    bool use_bigrams = true;
+    cgx_ngslot *d_ng[4] = {nullptr, nullptr, nullptr, nullptr}; uint32_t ng_cap[4] = {0, 0, 0, 0}; unsigned ng_shift[4] = {0, 0, 0, 0};   // l-gram (l = 2..5) -> SA interval
+    int ngram_max = 5;                  // longest phrase answered from the l-gram tables (1: none, every l >= 2 by binary search)
+    bool count_probes = false;          // cgx_sa_lookup also runs the probe-counting variant of its kernel (untimed; "sa_probe_*")
     bool prealloc_text = false;         // allocate both text slots at the first batch (set when more batches will follow)
     bool numa_pin = true;               // writer threads run on the CPUs of the GPU's NUMA node
     bool use_lex_hash = true;           // MaxLex pair lookups through the pair hash (0: binary search in the source word's row)

@@ -81,7 +81,7 @@ int cgx_build_sa(cgx_ctx *ctx);                                 /* replaces suff
 int cgx_precompute(cgx_ctx *ctx);                               /* replaces preComputation + precomp kernel (SuffixArray.cu:1132-1340) */
 /* multi-GPU: allocate an empty replica of given sizes, then move buffers device-to-device
  * (dir 0: index buffer -> dptr, dir 1: dptr -> index buffer) around a collective broadcast. */
-typedef struct { uint32_t n, nt, nlex, nphits; int32_t last; uint32_t lex_nrow, lex_ntgt, bigram_cap; } cgx_index_dims;
+typedef struct { uint32_t n, nt, nlex, nphits; int32_t last; uint32_t lex_nrow, lex_ntgt, reserved; } cgx_index_dims;   /* derived tables (pair hash, l-gram tables) are rebuilt by cgx_index_finalize, not shipped */
 int cgx_index_shape(cgx_ctx *ctx, cgx_index_dims *dims);        /* sizes of a built index (root rank) */
 int cgx_index_alloc(cgx_ctx *ctx, const cgx_index_dims *dims);  /* empty replica of the same sizes (other ranks) */
 int cgx_index_nbuffers(cgx_ctx *ctx);

@@ -1543,6 +1543,12 @@ static void put_lex(FILE *f, const char *pre, const orc_lexent *lex, uint32_t n)
     snprintf(tag, sizeof tag, "%s_txt", pre); put_strings(f, tag, txt, n, 0);
     free(iv.v); free(fv.v); free(txt);
 }
+/* stage timers of the last orc_run_all (seconds: lookup, gappy search, extraction, lexicon, MaxLex task, writing); returns the number of grammar lines */
+uint64_t orc_batch_times(const orc_batch *b, double *t6) {
+    t6[0] = b->t_lookup; t6[1] = b->t_gappy; t6[2] = b->t_extract; t6[3] = b->t_lexicon; t6[4] = b->t_lextask; t6[5] = b->t_write;
+    return b->nlines;
+}
+
 int orc_dump(const orc_index *ix, const orc_batch *b, const char *path) {
     FILE *f = fopen(path, "wb");
     if (!f) return -1;

@@ -169,6 +169,7 @@ void orc_extract(const orc_index *ix, orc_batch *b);          /* ExtractPair.cu:
 void orc_features(const orc_index *ix, orc_batch *b);         /* ExtractPair.cu:3694-3982 + ExtractPair.c */
 int  orc_write_grammars(const orc_batch *b, const char *outdir, int first_query_index); /* PrintResults.c:407-577 */
 int  orc_run_all(const orc_index *ix, orc_batch *b, const char *outdir);
+uint64_t orc_batch_times(const orc_batch *b, double *t6);   /* the six stage timers above, seconds; returns nlines */
 
 /* helpers exported for unit tests */
 int orc_check_gap(const orc_index *ix, uint32_t start, uint32_t ender);                     /* GappyLook.cu:43-126 */

@@ -16,6 +16,7 @@
  * usage: ref_harness sa <dump>                 -> exit 0 when the reference SA == dumped SA
  *        ref_harness grammar <dump> <outdir>   -> writes grammar.<q>.s via the reference
  *        ref_harness time-sa <dump>            -> prints seconds of suffixArrayConstruct
+ *        ref_harness time-grammar <dump> <outdir> -> as "grammar", prints seconds of createLexicon*Fast + print_query_GPU_Gappy
  */
 #include "ComTypes.h"
 #include "SuffixArray.h"
@@ -82,7 +83,8 @@ static int run_sa(dump_t &d, bool timing) {
     return 0;
 }
 
-static int run_grammar(dump_t &d, char *outdir) {
+static double wall_s() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; }
+static int run_grammar(dump_t &d, char *outdir, bool timing) {
     unsigned int *hdr = arr<unsigned int>(d, "header");
     int nq = (int)hdr[7]; unsigned int G = hdr[9], D1 = hdr[10], D2 = hdr[11], sep1 = hdr[12], sep2a = hdr[13], sep2b = hdr[14];
     int *str = arr<int>(d, "str"), *tstr = arr<int>(d, "tstr");
@@ -102,6 +104,7 @@ static int run_grammar(dump_t &d, char *outdir) {
     unsigned int ntask = 0;
     int nl1 = 0, nl2 = 0, nl0 = 0;
     std::vector<red_dup_t> buf1(n1 + 1), buf2(n2 + 1), buf0(n0 + 1);
+    const double w0 = wall_s();
     red_dup_t *lex1 = createLexiconGappyFast(str, tstr, &nl1, blocks, maxEF.data(), names, (int)G, r1, r2, n1, n2,
                                              (int)sep1, (int)sep2a, (int)sep2b, D1, D2, p1, p2, tv.data(), sv.data(),
                                              buf1.data(), s1, s2, &ntask, hits1, &ref);
@@ -111,6 +114,7 @@ static int run_grammar(dump_t &d, char *outdir) {
     hashtbl_aux *lexic = NULL; hash_lexicon *tc = NULL, *fc = NULL;
     red_dup_t *lex0 = createLexiconFast(n0, r0, str, tstr, &lexic, &tc, &fc, &nl0, blocks, maxEF.data(), names, (int)G,
                                         buf0.data(), tv.data(), &ntask);
+    const double w_lex = wall_s() - w0;
 
     /* the oracle's lexical tasks must be the reference's, field for field */
     lexicalTask *otask = arr<lexicalTask>(d, "tasks"); size_t on = cnt<lexicalTask>(d, "tasks");
@@ -139,16 +143,19 @@ static int run_grammar(dump_t &d, char *outdir) {
     for (int i = 0; i < nl0; i++) { if (i == 0 || lex0[i].blocknumber != lex0[i - 1].blocknumber) rg0[lex0[i].blocknumber].down = i; rg0[lex0[i].blocknumber].up = i; }
 
     std::vector<std::vector<unsigned int> > qb = lists(d, "qblocks", nq), q1 = lists(d, "qone", nq), q2 = lists(d, "qtwo", nq);
+    const double w1 = wall_s();
     print_query_GPU_Gappy(qb, q1, q2, nq, rg0.data(), rg1.data(), rg2.data(), lex0, lex1, lex2, outdir, G, D1, D2);
+    if (timing) { printf("%.6f\n", w_lex + (wall_s() - w1)); return 0; }
     printf("GRAMMAR OK lex %d/%d/%d tasks %u\n", nl1, nl2, nl0, ntask);
     return 0;
 }
 
 int main(int argc, char **argv) {
-    if (argc < 3) { fprintf(stderr, "usage: ref_harness sa|time-sa <dump> | grammar <dump> <outdir>\n"); return 2; }
+    if (argc < 3) { fprintf(stderr, "usage: ref_harness sa|time-sa <dump> | grammar|time-grammar <dump> <outdir>\n"); return 2; }
     dump_t d = read_dump(argv[2]);
     if (!strcmp(argv[1], "sa")) return run_sa(d, false);
     if (!strcmp(argv[1], "time-sa")) return run_sa(d, true);
-    if (!strcmp(argv[1], "grammar") && argc >= 4) return run_grammar(d, argv[3]);
+    if (!strcmp(argv[1], "grammar") && argc >= 4) return run_grammar(d, argv[3], false);
+    if (!strcmp(argv[1], "time-grammar") && argc >= 4) return run_grammar(d, argv[3], true);
     return 2;
 }

@@ -256,21 +256,26 @@ def test_a_failed_stage_leaves_the_context_usable(cgx, fixtures_dir, tmp_path):
     ex.close(); corpus.close()
 
 
-def test_bigram_table_does_not_change_intervals(cgx, oracle_bin, fixtures_dir, tmp_path):
-    """l = 2 from the bigram hash table vs. by binary search: same lm / up / down (and both equal the oracle)."""
+def test_ngram_tables_do_not_change_intervals(cgx, oracle_bin, fixtures_dir, tmp_path):
+    """l = 2..5 from the l-gram hash tables (one probe per length) vs. by nested binary search, for every split between
+    the two ("ngram_tables" = longest length answered from a table): same lm / up / down, all equal to the oracle; the
+    probe-counting variant of the kernel writes the same results and reports what it read."""
     fx = make_fixture("toy", fixtures_dir); dump = str(tmp_path / "d.bin")
     op.run_oracle(oracle_bin, fx, str(tmp_path / "o"), dump)
     d = op.read_dump(dump); h = d["hdr"]
     ex = cgx.Extractor(0)
     ex.upload_index(d["str"][:h["n"]], d["rlp"], d["tstr"][:h["nt"]], d["ltar"], d["rtar"], d["lexk"], d["lexv"])
     ex.build_sa(); ex.precompute(); ex.upload_queries(d["qoff"][:-1], d["qtok"])
-    res = []
-    for flag in (1, 0):
-        ex.set_option("use_bigrams", flag); ex.sa_lookup()
-        res.append((ex.fetch("lm"), ex.fetch("up"), ex.fetch("down")))
-    for a, b in zip(res[0], res[1]):
-        assert np.array_equal(a, b)
-    assert np.array_equal(res[0][0], np.minimum(d["lm"], 5)) and np.array_equal(res[0][1], d["up"]) and np.array_equal(res[0][2], d["down"])
+    want = (np.minimum(d["lm"], 5), d["up"], d["down"])
+    for maxl in (5, 4, 3, 2, 1):
+        ex.set_option("ngram_tables", maxl); ex.set_option("count_probes", 1); ex.sa_lookup()
+        for a, b in zip((ex.fetch("lm"), ex.fetch("up"), ex.fetch("down")), want):
+            assert np.array_equal(a, b), maxl
+        assert ex.stage_ms("sa_probe_lookups") == int(want[0].sum())
+        assert (ex.stage_ms("sa_probe_search") == 0) == (maxl == 5 or int((want[0] > maxl).sum()) == 0)
+        assert (ex.stage_ms("sa_probe_slots") > 0) == (maxl >= 2)
+    ex.set_option("use_bigrams", 0); ex.set_option("count_probes", 0); ex.sa_lookup()      # round-1 option name: no tables at all
+    assert np.array_equal(ex.fetch("up"), want[1])
     ex.close()
 
 
