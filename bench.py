@@ -325,6 +325,7 @@ def report(ex, args, cfg, L):
     steps, world, nq, qtok, n_src = L["steps"], L["world"], L["nq"], L["qtok"], L["n_src_tokens"]
     stage, hoststage = L["stage"], L["hoststage"]
     free_b, total_b = torch.cuda.mem_get_info()                # after the timed steps: index + cached batch buffers + both text slots
+    c = ex.counts(); w1, w2 = ex.stage_ms("look1_items"), ex.stage_ms("look2_items")     # of the last batch, before the extra lookup below resets them
     # ---- the batched SA interval search, priced by the probes it executes (counted by the kernel itself, untimed launch) ----
     kms = float(np.mean(L["kernel_ms"])) if L["kernel_ms"] else 0.0
     a, b = L["chunks"][-1]
@@ -359,8 +360,7 @@ def report(ex, args, cfg, L):
                 "target_60pct_met": bool(ach / 8000.0 >= 0.6),
                 "note": "achieved = bytes of the probes the kernel executed (counted by the kernel) / its event-timed duration; a dependent-probe kernel over %d query tokens is latency-bound, not bandwidth-bound" % T}
     # ---- the kernels that take the most time per step, priced per corpus occurrence they visit ----
-    w1, w2 = ex.stage_ms("look1_items"), ex.stage_ms("look2_items")
-    c = ex.counts(); nch = len(L["chunks"])
+    nch = len(L["chunks"])
     k1, k2 = stage["look1_kernel"] / steps / nch, stage["look2_kernel"] / steps / nch
     by_time = []
     for name, w, per, hits, ms in (("k_look1 (one-gap corpus lookups)", w1, ex.stage_ms("look1_bytes_per_item"), c["h1"], k1), ("k_look2 (two-gap corpus lookups)", w2, ex.stage_ms("look2_bytes_per_item"), c["h2"], k2)):

@@ -73,6 +73,7 @@ struct cgx_ctx {
     uint32_t nqb = 0;                                         // entries of d_qb_ids
     uint32_t *d_qb_off = nullptr, *d_qb_ids = nullptr, *d_qo_off = nullptr, *d_qo_ids = nullptr, *d_qt_off = nullptr, *d_qt_ids = nullptr;
     char *d_text[2] = {nullptr, nullptr}; size_t text_cap[2] = {0, 0}; uint64_t text_bytes[2] = {0, 0}; uint64_t *d_qtext[2] = {nullptr, nullptr}; int32_t text_nq[2] = {0, 0}; int text_sel = 0;
+    uint64_t *d_seg_off[2] = {nullptr, nullptr}, *d_qseg[2] = {nullptr, nullptr}; uint32_t *d_seg_len[2] = {nullptr, nullptr}; uint64_t text_nseg[2] = {0, 0}, text_total[2] = {0, 0};   // pieces of the unique text per query
     hipStream_t copy_streams[CGX_COPY_STREAMS] = {nullptr};   // few, so that they do not share a hardware queue with `stream`
     hipEvent_t sync_ev = nullptr;                             // blocking-sync event for host waits on `stream`
     hipEvent_t copy_done[CGX_MAX_READERS] = {nullptr};        // one per reader: its last enqueued copy

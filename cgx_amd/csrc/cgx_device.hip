@@ -356,7 +356,7 @@ extern "C" void cgx_destroy(cgx_ctx *c) {
     (void)hipSetDevice(c->device);
     free_batch(c); free_index(c);
     for (int a = 0; a < 2; a++) if (c->arena[a]) { (void)hipHostFree(c->arena[a]); c->arena[a] = nullptr; }
-    for (int a = 0; a < 2; a++) { dfree(c->d_text[a]); dfree(c->d_qtext[a]); }
+    for (int a = 0; a < 2; a++) { dfree(c->d_text[a]); dfree(c->d_qtext[a]); dfree(c->d_seg_off[a]); dfree(c->d_seg_len[a]); dfree(c->d_qseg[a]); }
     dfree(c->d_spool); dfree(c->d_soff); dfree(c->d_tpool); dfree(c->d_toff); dfree(c->d_aa); dfree(c->d_bb); dfree(c->d_fs);
     if (c->sync_ev) (void)hipEventDestroy(c->sync_ev);
     for (int r = 0; r < CGX_COPY_STREAMS; r++) if (c->copy_streams[r]) (void)hipStreamDestroy(c->copy_streams[r]);
@@ -415,6 +415,7 @@ extern "C" void cgx__device_cpulist(cgx_ctx *c, char *buf, size_t cap) {
     if (!fgets(buf, (int)cap, f)) buf[0] = 0;
     fclose(f);
 }
+extern "C" void cgx__bind_thread(cgx_ctx *c) { if (c) (void)hipSetDevice(c->device); }
 extern "C" const void *cgx__get_vocab_owner(cgx_ctx *c) { return c ? c->vocab_owner : nullptr; }
 extern "C" void cgx__set_vocab_owner(cgx_ctx *c, const void *p) { if (c) c->vocab_owner = p; }
 extern "C" void cgx__set_host_state(cgx_ctx *c, void *p) { if (c) c->host_state = p; }

@@ -1053,53 +1053,56 @@ static int ensure_vocab(cgx_ctx *ctx, const cgx_corpus *c) {
     free(sp); free(tp); free(soff); free(toff);
     return rc;
 }
-typedef struct { cgx_ctx *ctx; int slot; const uint64_t *qtext; int32_t nq, first; const char *outdir; int64_t *next; int64_t npieces; int tid, rc; double wait_ms, write_ms, t_start, t_first, t_end; } devjob;
-static uint64_t g_pin_bytes;                              /* piece size: fixed at the first batch (CGX_PIN_MB, default 16) */
-#define PIN_BYTES g_pin_bytes
-#define PIN_RING 3                                        /* copies in flight per writer thread: keeps PCIe busy while the thread sits in pwrite() */
-#define MAX_WRITERS (CGX_MAX_READERS / PIN_RING)
-static void *g_pin[MAX_WRITERS][PIN_RING];                /* page-locked staging buffers, kept for the life of the process */
-static void pin_bytes_init(void) { if (!g_pin_bytes) { const char *e = getenv("CGX_PIN_MB"); long mb = e ? atol(e) : 0; g_pin_bytes = (uint64_t)(mb >= 1 && mb <= 256 ? mb : 16) << 20; } }
-static void pin_to_device_node(cgx_ctx *ctx);
-/* The first batch of a process would otherwise pay for 48 page-locked allocations (about 0.15 s) between the end of
- * its GPU work and its first file: a helper thread makes them while the GPU stages of that batch run. */
-static pthread_t g_pin_thread; static int g_pin_state;     /* 0 not started, 1 running, 2 joined */
-static void *pin_prepare_main(void *arg) {
-    cgx_ctx *ctx = arg; int nt = nthreads_host(); if (nt > MAX_WRITERS) nt = MAX_WRITERS;
-    pin_to_device_node(ctx);                                  /* first touch on the GPU's node */
-    for (int t = 0; t < nt; t++) for (int k = 0; k < PIN_RING; k++) if (!g_pin[t][k]) g_pin[t][k] = cgx_pinned_alloc(PIN_BYTES);
-    return NULL;
+/* ---- writer -------------------------------------------------------------------------------------------------------
+ * The device hands over the UNIQUE text of the batch (every lexicon line once) and, per query, the list of pieces of it
+ * that make up its grammar file (cgx_text_info / cgx_text_segments_begin).  A batch's output then takes two phases:
+ *   1. DMA: unique text + piece lists -> page-locked host memory (enqueued by the submitting thread on the context's
+ *      side streams; no CPU work);
+ *   2. host threads assemble the files: one pwritev per <= IOV_MAX pieces straight from the unique text into the page
+ *      cache (a phrase that occurs in thousands of queries has its rules formatted once and sent over PCIe once).
+ * Two host buffer sets alternate, so with async_write the DMA of batch k+1 runs while the files of batch k are being
+ * assembled, and both overlap the GPU stages of batch k+2.  File phases run strictly in submission order. */
+#include <sys/uio.h>
+#include <limits.h>
+#ifndef IOV_MAX
+#define IOV_MAX 1024
+#endif
+#define MAX_WRITERS 64
+#define COPY_PIECE ((uint64_t)64 << 20)                   /* unique text is copied in pieces of this size, round robin over the copy streams */
+#define READERS_PER_SLOT 4                                /* reader ids of text slot s: s*4 .. s*4+2 text pieces, s*4+3 the piece lists */
+typedef struct { char *utext; uint64_t utext_cap; uint64_t *segoff, *qseg; uint32_t *seglen; uint64_t segoff_cap, seglen_cap, qseg_cap; } hostbuf;
+struct pending;
+typedef struct {
+    pthread_mutex_t m; pthread_cond_t cv;
+    uint64_t next_seq, done_seq;                           /* file phases finish in submission order: done_seq counts them */
+    struct pending *inflight[2]; int n;
+    hostbuf hb[2];
+} wstate;
+typedef struct pending {
+    wstate *ws; uint64_t seq; cgx_ctx *ctx; pthread_t th; int rc;
+    batch *b;                                              /* host-formatter path: the batch whose lexicon the threads format */
+    int dev, slot, hb; int32_t nq, first; char *outdir;
+    uint64_t ubytes, nseg, fbytes, lines; double ms, wait_ms, file_ms;
+} pending;
+static wstate *get_wstate(cgx_ctx *ctx) {
+    wstate *ws = cgx__get_host_state(ctx);
+    if (ws) return ws;
+    ws = calloc(1, sizeof *ws);
+    if (!ws) return NULL;
+    pthread_mutex_init(&ws->m, NULL); pthread_cond_init(&ws->cv, NULL);
+    cgx__set_host_state(ctx, ws);
+    return ws;
 }
-static void pin_prepare_start(cgx_ctx *ctx) {
-    if (g_pin_state) return;
-    pin_bytes_init();
-    g_pin_state = pthread_create(&g_pin_thread, NULL, pin_prepare_main, ctx) ? 2 : 1;
+int cgx__host_busy(cgx_ctx *ctx) { wstate *ws = cgx__get_host_state(ctx); return ws ? ws->n : 0; }
+static int pinned_reserve(void **p, uint64_t *cap, uint64_t need, size_t elem) {
+    if (need <= *cap) return 0;
+    uint64_t nc = need + need / 4 + 1024;
+    void *np = cgx_pinned_alloc((size_t)nc * elem);
+    if (!np) return -1;
+    cgx_pinned_free(*p); *p = np; *cap = nc;
+    return 0;
 }
-static void pin_prepare_join(void) { if (g_pin_state == 1) { pthread_join(g_pin_thread, NULL); g_pin_state = 2; } }
-/* The text of a batch is one byte stream (query after query).  Writers claim fixed PIN_BYTES pieces of the
- * STREAM, not files: every D2H copy is large whatever the file sizes are, and a piece is then scattered
- * into the files it overlaps with pwrite (a file cut by a piece boundary is completed by two writers). */
-static int write_piece(devjob *w, int64_t pc, const char *src) {
-    const uint64_t lo = (uint64_t)pc * PIN_BYTES, total = w->qtext[w->nq], hi = lo + PIN_BYTES < total ? lo + PIN_BYTES : total;
-    int32_t a = 0, b = w->nq;                               /* first query whose text ends after lo */
-    while (a < b) { int32_t m = (a + b) / 2; if (w->qtext[m + 1] <= lo) a = m + 1; else b = m; }
-    char fn[4096];
-    for (int32_t q = a; q < w->nq && w->qtext[q] < hi; q++) {
-        const uint64_t qs = w->qtext[q], qe = w->qtext[q + 1];
-        const uint64_t s = qs > lo ? qs : lo, e = qe < hi ? qe : hi;
-        if (qe == qs) continue;                            /* empty files were created up front */
-        snprintf(fn, sizeof fn, "%s/grammar.%d.s", w->outdir, w->first + q);
-        int fd = open(fn, O_WRONLY | O_CREAT, 0644);
-        if (fd < 0) return CGX_ERR_IO;
-        int bad = 0;
-        for (uint64_t k = s; k < e && !bad;) { ssize_t r = pwrite(fd, src + (k - lo), e - k, (off_t)(k - qs)); if (r <= 0) bad = 1; else k += (uint64_t)r; }
-        if (!bad && e == qe && ftruncate(fd, (off_t)(qe - qs))) bad = 1;   /* whoever writes the last byte sets the length (in-place overwrite of an older, longer file) */
-        close(fd);
-        if (bad) return CGX_ERR_IO;
-    }
-    return CGX_OK;
-}
-/* Writer threads copy 30+ GB per batch between the page-locked staging buffers and the page cache: keep them on
+/* Writer threads copy 30+ GB per batch from the page-locked unique text into the page cache: keep them on
  * the CPUs of the GPU's NUMA node, where the DMA lands.  Best effort (the list comes from sysfs). */
 static void pin_to_device_node(cgx_ctx *ctx) {
     if (!cgx__option(ctx, "numa_pin")) return;
@@ -1115,75 +1118,84 @@ static void pin_to_device_node(cgx_ctx *ctx) {
     }
     if (any) (void)pthread_setaffinity_np(pthread_self(), sizeof set, &set);
 }
-static void *dev_write_worker(void *arg) {
-    devjob *w = arg; w->rc = CGX_OK;
-    w->wait_ms = w->write_ms = 0; w->t_start = now_ms(); w->t_first = 0;
-    if (w->tid > 0) pin_to_device_node(w->ctx);               /* thread 0 may be the caller's own thread: left alone */
-    for (int k = 0; k < PIN_RING; k++) { if (!g_pin[w->tid][k]) g_pin[w->tid][k] = cgx_pinned_alloc(PIN_BYTES); if (!g_pin[w->tid][k]) { w->rc = CGX_ERR_NOMEM; return NULL; } }
-    const uint64_t total = w->qtext[w->nq];
-    int64_t ring[PIN_RING]; int head = 0, count = 0, more = 1;
-    for (;;) {
-        while (more && count < PIN_RING && w->rc == CGX_OK) {  /* top up the ring */
-            int64_t pc = __atomic_fetch_add(w->next, 1, __ATOMIC_RELAXED);
-            if (pc >= w->npieces) { more = 0; break; }
-            int k = (head + count) % PIN_RING;
-            uint64_t lo = (uint64_t)pc * PIN_BYTES, n = total - lo < PIN_BYTES ? total - lo : PIN_BYTES;
-            if (cgx_text_read_begin(w->ctx, w->slot, lo, n, g_pin[w->tid][k], w->tid * PIN_RING + k) != CGX_OK) w->rc = CGX_ERR_HIP;
-            ring[k] = pc; count++;
+typedef struct {
+    cgx_ctx *ctx; int tid, rc; int32_t nq, first; const char *outdir; int32_t *next_q;
+    const char *utext; const uint64_t *qseg, *seg_off; const uint32_t *seg_len;
+    double file_ms; uint64_t calls;
+} devjob;
+static int write_one_file(devjob *w, int32_t q, struct iovec *iov) {
+    char fn[4096];
+    snprintf(fn, sizeof fn, "%s/grammar.%d.s", w->outdir, w->first + q);
+    const uint64_t s0 = w->qseg[q], s1 = w->qseg[q + 1];
+    /* overwrite in place and cut to length: same bytes as fopen(fn,"w"), but an existing file keeps its pages */
+    int fd = open(fn, s0 == s1 ? O_WRONLY | O_CREAT | O_TRUNC : O_WRONLY | O_CREAT, 0644);
+    if (fd < 0) return CGX_ERR_IO;
+    int bad = 0; uint64_t pos = 0;
+    for (uint64_t s = s0; s < s1 && !bad;) {
+        int n = 0; uint64_t want = 0;
+        for (; s < s1 && n < IOV_MAX; s++, n++) { iov[n].iov_base = (void *)(w->utext + w->seg_off[s]); iov[n].iov_len = w->seg_len[s]; want += w->seg_len[s]; }
+        uint64_t done = 0; int k = 0;
+        while (done < want && !bad) {                       /* a short write resumes in the middle of a piece */
+            ssize_t r = pwritev(fd, iov + k, n - k, (off_t)(pos + done)); w->calls++;
+            if (r <= 0) { bad = 1; break; }
+            done += (uint64_t)r;
+            while (k < n && (uint64_t)r >= iov[k].iov_len) { r -= (ssize_t)iov[k].iov_len; k++; }
+            if (k < n && r > 0) { iov[k].iov_base = (char *)iov[k].iov_base + r; iov[k].iov_len -= (size_t)r; }
         }
-        if (!count) break;
-        double t0 = now_ms();
-        if (cgx_text_read_wait(w->ctx, w->tid * PIN_RING + head) != CGX_OK && w->rc == CGX_OK) w->rc = CGX_ERR_HIP;
-        double t1 = now_ms(); w->wait_ms += t1 - t0; if (w->t_first == 0) w->t_first = t1;
-        if (w->rc == CGX_OK) w->rc = write_piece(w, ring[head], g_pin[w->tid][head]);
-        w->write_ms += now_ms() - t1;
-        head = (head + 1) % PIN_RING; count--;
-        if (w->rc != CGX_OK) more = 0;                      /* on error: stop claiming, but drain the copies in flight before the buffers go away */
+        pos += want;
     }
-    w->t_end = now_ms();
+    if (!bad && s0 != s1 && ftruncate(fd, (off_t)pos)) bad = 1;   /* an older, longer file of the same name is cut to the new length */
+    close(fd);
+    return bad ? CGX_ERR_IO : CGX_OK;
+}
+static void *dev_write_worker(void *arg) {
+    devjob *w = arg; w->rc = CGX_OK; w->file_ms = 0; w->calls = 0;
+    cgx__bind_thread(w->ctx);
+    if (w->tid > 0) pin_to_device_node(w->ctx);               /* thread 0 is the batch's writer thread itself: already placed */
+    struct iovec *iov = malloc(sizeof(struct iovec) * IOV_MAX);
+    if (!iov) { w->rc = CGX_ERR_NOMEM; return NULL; }
+    double t0 = now_ms();
+    for (;;) {
+        int32_t q = __atomic_fetch_add(w->next_q, 1, __ATOMIC_RELAXED);
+        if (q >= w->nq) break;
+        int rc = write_one_file(w, q, iov);
+        if (rc != CGX_OK) { w->rc = rc; break; }
+    }
+    w->file_ms = now_ms() - t0;
+    free(iov);
     return NULL;
 }
-/* queries without any text still get their (empty) file */
-static int write_empty_files(const uint64_t *qtext, int32_t nq, const char *outdir, int32_t first) {
-    char fn[4096];
-    for (int32_t q = 0; q < nq; q++) if (qtext[q + 1] == qtext[q]) {
-        snprintf(fn, sizeof fn, "%s/grammar.%d.s", outdir, first + q);
-        int fd = open(fn, O_WRONLY | O_CREAT | O_TRUNC, 0644);
-        if (fd < 0) return CGX_ERR_IO;
-        close(fd);
+/* phase 1, called by the thread that submits the batch: sizes the host buffers and enqueues every copy */
+static int dev_copy_begin(pending *pw) {
+    cgx_ctx *ctx = pw->ctx; hostbuf *hb = &pw->ws->hb[pw->hb]; int rc;
+    if ((rc = cgx_text_info(ctx, pw->slot, &pw->ubytes, &pw->nseg, &pw->fbytes)) != CGX_OK) return rc;
+    if (pinned_reserve((void **)&hb->utext, &hb->utext_cap, pw->ubytes + 64, 1) || pinned_reserve((void **)&hb->qseg, &hb->qseg_cap, (uint64_t)pw->nq + 2, 8) ||
+        pinned_reserve((void **)&hb->segoff, &hb->segoff_cap, pw->nseg + 1, 8) || pinned_reserve((void **)&hb->seglen, &hb->seglen_cap, pw->nseg + 1, 4)) return CGX_ERR_NOMEM;
+    const int r0 = pw->slot * READERS_PER_SLOT;
+    const int64_t npieces = (int64_t)((pw->ubytes + COPY_PIECE - 1) / COPY_PIECE);
+    for (int64_t pc = 0; pc < npieces; pc++) {
+        const uint64_t lo = (uint64_t)pc * COPY_PIECE, n = pw->ubytes - lo < COPY_PIECE ? pw->ubytes - lo : COPY_PIECE;
+        if ((rc = cgx_text_read_begin(ctx, pw->slot, lo, n, hb->utext + lo, r0 + (int)(pc % 3))) != CGX_OK) return rc;
     }
-    return CGX_OK;
+    return cgx_text_segments_begin(ctx, pw->slot, hb->qseg, hb->segoff, hb->seglen, r0 + 3);
 }
-static int write_from_device_locked(cgx_ctx *ctx, int slot, const uint64_t *qtext, int32_t nq, const char *outdir, int32_t first, double *wait_ms, double *file_ms) {
-    int rc = write_empty_files(qtext, nq, outdir, first);
-    if (rc != CGX_OK) return rc;
-    *wait_ms = *file_ms = 0;
-    const uint64_t total = qtext[nq];
-    pin_bytes_init(); pin_prepare_join();
-    int64_t npieces = (int64_t)((total + PIN_BYTES - 1) / PIN_BYTES), next = 0;
-    if (!npieces) return CGX_OK;
-    int nt = nthreads_host(); if (nt > MAX_WRITERS) nt = MAX_WRITERS; if (nt > npieces) nt = (int)npieces;
-    devjob jobs[MAX_WRITERS]; pthread_t th[MAX_WRITERS];
-    for (int t = 0; t < nt; t++) { jobs[t].ctx = ctx; jobs[t].slot = slot; jobs[t].qtext = qtext; jobs[t].nq = nq; jobs[t].first = first; jobs[t].outdir = outdir; jobs[t].next = &next; jobs[t].npieces = npieces; jobs[t].tid = t; jobs[t].rc = CGX_OK; }
-    for (int t = 1; t < nt; t++) if (pthread_create(&th[t], NULL, dev_write_worker, &jobs[t])) return CGX_ERR_NOMEM;
+/* phase 2 (after the copies have landed and the previous batch's files are complete) */
+static int dev_write_files(pending *pw) {
+    cgx_ctx *ctx = pw->ctx; const hostbuf *hb = &pw->ws->hb[pw->hb]; const int32_t nq = pw->nq;
+    int nt = nthreads_host(); if (nt > MAX_WRITERS) nt = MAX_WRITERS; if (nt > nq) nt = nq > 0 ? nq : 1;
+    devjob jobs[MAX_WRITERS]; pthread_t th[MAX_WRITERS]; int started[MAX_WRITERS]; int32_t next = 0; int rc = CGX_OK;
+    for (int t = 0; t < nt; t++) { memset(&jobs[t], 0, sizeof jobs[t]); jobs[t].ctx = ctx; jobs[t].tid = t; jobs[t].nq = nq; jobs[t].first = pw->first; jobs[t].outdir = pw->outdir; jobs[t].next_q = &next;
+                                   jobs[t].utext = hb->utext; jobs[t].qseg = hb->qseg; jobs[t].seg_off = hb->segoff; jobs[t].seg_len = hb->seglen; jobs[t].rc = CGX_OK; }
+    started[0] = 1;
+    for (int t = 1; t < nt; t++) started[t] = !pthread_create(&th[t], NULL, dev_write_worker, &jobs[t]);   /* a thread that cannot start: the others take its share */
     dev_write_worker(&jobs[0]);
-    for (int t = 1; t < nt; t++) pthread_join(th[t], NULL);
-    double wait = 0, wr = 0;
-    if (getenv("CGX_TRACE")) {
-        double tb = jobs[0].t_start, first = 0, end_min = 1e300, end_max = 0, start_max = 0;
-        for (int t = 0; t < nt; t++) { if (jobs[t].t_start - tb > start_max) start_max = jobs[t].t_start - tb; if (jobs[t].t_first - tb > first) first = jobs[t].t_first - tb; if (jobs[t].t_end - tb < end_min) end_min = jobs[t].t_end - tb; if (jobs[t].t_end - tb > end_max) end_max = jobs[t].t_end - tb; }
-        fprintf(stderr, "cgx writer: %d threads, %lld pieces, %.1f GB: last thread started at %.1f ms, last first-piece at %.1f ms, threads ended between %.1f and %.1f ms (%.1f GB/s overall); per thread: waiting for copies %.0f ms, writing files %.0f ms\n", nt, (long long)npieces, total / 1e9, start_max, first, end_min, end_max, total / 1e6 / end_max, jobs[nt > 1 ? 1 : 0].wait_ms, jobs[nt > 1 ? 1 : 0].write_ms);
-    }
-    for (int t = 0; t < nt; t++) { if (jobs[t].rc != CGX_OK) return jobs[t].rc; wait += jobs[t].wait_ms; wr += jobs[t].write_ms; }
-    *wait_ms = wait / nt; *file_ms = wr / nt;                /* per-thread averages; reported by the caller's thread */
-    return CGX_OK;
-}
-/* The staging buffers belong to the process, not to a context: writers of two contexts in one process take turns. */
-static pthread_mutex_t g_writer_lock = PTHREAD_MUTEX_INITIALIZER;
-static int write_from_device(cgx_ctx *ctx, int slot, const uint64_t *qtext, int32_t nq, const char *outdir, int32_t first, double *wait_ms, double *file_ms) {
-    pthread_mutex_lock(&g_writer_lock);
-    int rc = write_from_device_locked(ctx, slot, qtext, nq, outdir, first, wait_ms, file_ms);
-    pthread_mutex_unlock(&g_writer_lock);
+    for (int t = 1; t < nt; t++) if (started[t]) pthread_join(th[t], NULL);
+    double wr = 0; uint64_t calls = 0; int ran = 0;
+    for (int t = 0; t < nt; t++) if (started[t]) { if (jobs[t].rc != CGX_OK && rc == CGX_OK) rc = jobs[t].rc; wr += jobs[t].file_ms; calls += jobs[t].calls; ran++; }
+    pw->file_ms = wr / (ran ? ran : 1);
+    if (getenv("CGX_TRACE"))
+        fprintf(stderr, "cgx writer: unique text %.2f GB + %llu pieces on the host after %.1f ms; %d threads assembled %.2f GB of files in %.1f ms per thread (%.1f GB/s), %llu pwritev calls\n",
+                pw->ubytes / 1e9, (unsigned long long)pw->nseg, pw->wait_ms, ran, pw->fbytes / 1e9, pw->file_ms, pw->fbytes / 1e6 / (pw->file_ms > 0 ? pw->file_ms : 1), (unsigned long long)calls);
     return rc;
 }
 
@@ -1198,14 +1210,57 @@ static uint64_t count_lines(const batch *b) {
     }
     return n;
 }
-typedef struct { batch *b; char *outdir; int32_t first; pthread_t th; int active, rc; uint64_t lines; double ms, wait_ms, file_ms;
-                 cgx_ctx *ctx; int dev, slot; uint64_t *qtext; int32_t nq; } pending;
 static void *pending_main(void *arg) {
-    pending *pw = arg; double t = now_ms();
-    if (pw->dev) pin_to_device_node(pw->ctx);                 /* this background thread doubles as writer 0 */
-    pw->rc = pw->dev ? write_from_device(pw->ctx, pw->slot, pw->qtext, pw->nq, pw->outdir, pw->first, &pw->wait_ms, &pw->file_ms) : write_grammars(pw->b, pw->outdir, pw->first, &pw->lines);
-    pw->ms = now_ms() - t;
+    pending *pw = arg; wstate *ws = pw->ws; double t = now_ms(); int rc = CGX_OK;
+    cgx__bind_thread(pw->ctx); pin_to_device_node(pw->ctx);  /* this background thread doubles as writer 0 */
+    if (pw->dev) {                                            /* phase 1 was enqueued by the submitter: wait for the DMA */
+        for (int r = 0; r < READERS_PER_SLOT; r++) { int rw = cgx_text_read_wait(pw->ctx, pw->slot * READERS_PER_SLOT + r); if (rc == CGX_OK) rc = rw; }
+        pw->wait_ms = now_ms() - t;
+    }
+    pthread_mutex_lock(&ws->m);                               /* the files of the previous batch first */
+    while (ws->done_seq + 1 < pw->seq) pthread_cond_wait(&ws->cv, &ws->m);
+    pthread_mutex_unlock(&ws->m);
+    if (rc == CGX_OK) rc = pw->dev ? dev_write_files(pw) : write_grammars(pw->b, pw->outdir, pw->first, &pw->lines);
+    pw->rc = rc; pw->ms = now_ms() - t;
+    pthread_mutex_lock(&ws->m); ws->done_seq = pw->seq; pthread_cond_broadcast(&ws->cv); pthread_mutex_unlock(&ws->m);
     return NULL;
+}
+/* waits for the oldest batch in flight; its error, if any, is returned */
+static int join_oldest(cgx_ctx *ctx, wstate *ws) {
+    if (!ws || !ws->n) return CGX_OK;
+    pending *pw = ws->inflight[0];
+    pthread_join(pw->th, NULL);
+    int rc = pw->rc;
+    cgx__set_host_ms(ctx, "write", pw->ms);
+    if (pw->dev) { cgx__set_host_ms(ctx, "write_wait_d2h", pw->wait_ms); cgx__set_host_ms(ctx, "write_file", pw->file_ms); }
+    ws->inflight[0] = ws->inflight[1]; ws->inflight[1] = NULL; ws->n--;
+    if (pw->b) { batch_free(pw->b); free(pw->b); }
+    free(pw->outdir); free(pw);
+    return rc;
+}
+/* hands a finished batch to the writer: device text in `slot` (dev) or the host formatter on batch b */
+static int submit_output(cgx_ctx *ctx, batch *b, int dev, int slot, int32_t nq, const char *outdir, int32_t first) {
+    wstate *ws = get_wstate(ctx); int rc = CGX_OK;
+    if (!ws) return CGX_ERR_NOMEM;
+    while (ws->n >= 2) { int r = join_oldest(ctx, ws); if (rc == CGX_OK) rc = r; }      /* at most two batches in flight: one copying, one writing */
+    if (rc != CGX_OK) return rc;
+    pending *pw = calloc(1, sizeof *pw);
+    if (!pw) return CGX_ERR_NOMEM;
+    pw->ws = ws; pw->ctx = ctx; pw->b = b; pw->dev = dev; pw->slot = slot; pw->nq = nq; pw->first = first; pw->outdir = strdup(outdir);
+    pw->hb = ws->n && ws->inflight[0]->hb == 0 ? 1 : 0;      /* the buffer set the batch still in flight does not use */
+    if (!pw->outdir) { free(pw); return CGX_ERR_NOMEM; }
+    if (dev && (rc = dev_copy_begin(pw)) != CGX_OK) {         /* copies already enqueued target buffers that stay allocated: drain them */
+        for (int r = 0; r < READERS_PER_SLOT; r++) (void)cgx_text_read_wait(ctx, slot * READERS_PER_SLOT + r);
+        free(pw->outdir); free(pw); return rc;
+    }
+    pw->seq = ++ws->next_seq;
+    if (pthread_create(&pw->th, NULL, pending_main, pw)) {
+        for (int r = 0; dev && r < READERS_PER_SLOT; r++) (void)cgx_text_read_wait(ctx, slot * READERS_PER_SLOT + r);
+        pthread_mutex_lock(&ws->m); ws->next_seq--; pthread_mutex_unlock(&ws->m);
+        free(pw->outdir); free(pw); return CGX_ERR_NOMEM;
+    }
+    ws->inflight[ws->n++] = pw;
+    return CGX_OK;
 }
 
 static int run_batch(cgx_ctx *ctx, const cgx_corpus *c, batch *b, const char *outdir, int32_t first, uint64_t *nrules, int *handed_off) {
@@ -1224,7 +1279,6 @@ static int run_batch(cgx_ctx *ctx, const cgx_corpus *c, batch *b, const char *ou
     }
     LAP("blocks");
     const int devfmt = outdir && cgx__option(ctx, "device_format");
-    if (devfmt) pin_prepare_start(ctx);
     if (devfmt && (rc = ensure_vocab(ctx, c)) != CGX_OK) return rc;
     LAP("qblocks");
     if ((rc = cgx_gappy_search(ctx)) != CGX_OK) return rc;
@@ -1251,28 +1305,12 @@ static int run_batch(cgx_ctx *ctx, const cgx_corpus *c, batch *b, const char *ou
         rc = cgx_format(ctx, &bytes, &nl, &slot);
         LAP("format");
         if (rc == CGX_OK) {
-            uint64_t *qtext = malloc(((size_t)b->nq + 2) * 8);
-            if (!qtext) return CGX_ERR_NOMEM;
-            if ((rc = cgx_text_offsets(ctx, slot, qtext)) != CGX_OK) { free(qtext); return rc; }
             if (nrules) *nrules = nl;
             fprintf(stderr, "Start Printing Gappy Phrases...\n");
-            if (cgx__option(ctx, "async_write")) {
-                LAP("offsets");
-                if ((rc = cgx_flush(ctx)) != CGX_OK) { free(qtext); return rc; }
-                LAP("flush_wait");
-                pending *pw = calloc(1, sizeof *pw);
-                if (!pw) { free(qtext); return CGX_ERR_NOMEM; }
-                pw->dev = 1; pw->ctx = ctx; pw->slot = slot; pw->qtext = qtext; pw->nq = b->nq; pw->outdir = strdup(outdir); pw->first = first; pw->active = 1;
-                if (pthread_create(&pw->th, NULL, pending_main, pw)) { free(qtext); free(pw->outdir); free(pw); return CGX_ERR_NOMEM; }
-                cgx__set_host_state(ctx, pw);
-            } else {
-                t = now_ms();
-                double wm = 0, fm = 0;
-                rc = write_from_device(ctx, slot, qtext, b->nq, outdir, first, &wm, &fm);
-                free(qtext);
-                cgx__set_host_ms(ctx, "write", now_ms() - t); cgx__set_host_ms(ctx, "write_wait_d2h", wm); cgx__set_host_ms(ctx, "write_file", fm);
-                if (rc != CGX_OK) return rc;
-            }
+            t = now_ms();
+            if ((rc = submit_output(ctx, NULL, 1, slot, b->nq, outdir, first)) != CGX_OK) return rc;
+            LAP("flush_wait");
+            if (!cgx__option(ctx, "async_write") && (rc = cgx_flush(ctx)) != CGX_OK) return rc;
             cgx__set_host_ms(ctx, "lists", 0); cgx__set_host_ms(ctx, "lexicon", 0);
             cgx__set_host_ms(ctx, "total", now_ms() - t0);
             return CGX_OK;
@@ -1352,13 +1390,8 @@ static int run_batch(cgx_ctx *ctx, const cgx_corpus *c, batch *b, const char *ou
     if (nrules) *nrules = lines;
     if (outdir && cgx__option(ctx, "async_write")) {
         /* hand the finished batch to a background writer; the GPU is free for the next batch */
-        if ((rc = cgx_flush(ctx)) != CGX_OK) return rc;
-        pending *pw = calloc(1, sizeof *pw);
-        if (!pw) return CGX_ERR_NOMEM;
-        pw->b = b; pw->outdir = strdup(outdir); pw->first = first; pw->active = 1;
         fprintf(stderr, "Start Printing Gappy Phrases...\n");
-        if (pthread_create(&pw->th, NULL, pending_main, pw)) { free(pw->outdir); free(pw); return CGX_ERR_NOMEM; }
-        cgx__set_host_state(ctx, pw);
+        if ((rc = submit_output(ctx, b, 0, 0, b->nq, outdir, first)) != CGX_OK) return rc;
         *handed_off = 1;
         cgx__set_host_ms(ctx, "total", now_ms() - t0);
         return CGX_OK;
@@ -1374,21 +1407,22 @@ static int run_batch(cgx_ctx *ctx, const cgx_corpus *c, batch *b, const char *ou
     return CGX_OK;
 }
 
-/* waits for the background writer of the previous batch (async_write); its error, if any, is returned here */
+/* waits for every batch handed to the writer (async_write); the first error, if any, is returned here */
 int cgx_flush(cgx_ctx *ctx) {
     if (!ctx) return CGX_ERR_ARG;
-    pending *pw = cgx__get_host_state(ctx);
-    if (!pw) return CGX_OK;
-    pthread_join(pw->th, NULL);
-    int rc = pw->rc;
-    cgx__set_host_ms(ctx, "write", pw->ms);
-    if (pw->dev) { cgx__set_host_ms(ctx, "write_wait_d2h", pw->wait_ms); cgx__set_host_ms(ctx, "write_file", pw->file_ms); }
-    cgx__set_host_state(ctx, NULL);
-    if (pw->b) { batch_free(pw->b); free(pw->b); }
-    free(pw->qtext); free(pw->outdir); free(pw);
+    wstate *ws = cgx__get_host_state(ctx); int rc = CGX_OK;
+    while (ws && ws->n) { int r = join_oldest(ctx, ws); if (rc == CGX_OK) rc = r; }
     return rc;
 }
-void cgx__host_release(cgx_ctx *ctx) { (void)cgx_flush(ctx); }
+void cgx__host_release(cgx_ctx *ctx) {
+    (void)cgx_flush(ctx);
+    wstate *ws = cgx__get_host_state(ctx);
+    if (!ws) return;
+    cgx__bind_thread(ctx);
+    for (int k = 0; k < 2; k++) { cgx_pinned_free(ws->hb[k].utext); cgx_pinned_free(ws->hb[k].segoff); cgx_pinned_free(ws->hb[k].seglen); cgx_pinned_free(ws->hb[k].qseg); }
+    pthread_mutex_destroy(&ws->m); pthread_cond_destroy(&ws->cv);
+    free(ws); cgx__set_host_state(ctx, NULL);
+}
 
 static int extract_ids_once(cgx_ctx *ctx, const cgx_corpus *c, const int32_t *qoff, int32_t nq, const int32_t *qtok, int32_t ntok,
                             const char *outdir, int32_t first, uint64_t *nrules) {

@@ -108,10 +108,16 @@ int cgx_lex_features(cgx_ctx *ctx, const cgx_lextask *tasks, uint32_t ntask, uin
 int cgx_upload_vocab(cgx_ctx *ctx, const char *spool, const uint32_t *soff, uint32_t ns, const char *tpool, const uint32_t *toff, uint32_t nt);
 int cgx_upload_score_tables(cgx_ctx *ctx, const float *aa, const float *bb, const float *fs);
 int cgx_set_query_blocks(cgx_ctx *ctx, const uint32_t *off, const uint32_t *ids);    /* CSR over the batch's queries */
-int cgx_format(cgx_ctx *ctx, uint64_t *total_bytes, uint64_t *total_lines, int *slot); /* after cgx_lexicon; two text slots alternate; slot == NULL: only count the rule lines (total_lines), lay out no text */
-int cgx_text_offsets(cgx_ctx *ctx, int slot, uint64_t *qtext);                       /* nq+1 byte offsets of the queries' text in that slot */
+int cgx_format(cgx_ctx *ctx, uint64_t *total_bytes, uint64_t *total_lines, int *slot); /* after cgx_lexicon; two text slots alternate; total_bytes = size of all grammar files together; slot == NULL: only count the rule lines (total_lines), lay out no text */
+/* What a slot holds: the UNIQUE text of the batch (every lexicon line formatted once, `unique_bytes`), and the files as lists of
+ * pieces of it: piece s = bytes [seg_off[s], seg_off[s] + seg_len[s]) of the unique text; the file of query q is the concatenation of
+ * pieces qseg[q] .. qseg[q+1]-1 in that order (PrintResults.c:451-570 emission order) and is qtext[q+1] - qtext[q] bytes long. */
+int cgx_text_info(cgx_ctx *ctx, int slot, uint64_t *unique_bytes, uint64_t *nseg, uint64_t *file_bytes);
+int cgx_text_segments(cgx_ctx *ctx, int slot, uint64_t *qseg /* nq+1 */, uint64_t *seg_off /* nseg */, uint32_t *seg_len /* nseg */);
+int cgx_text_segments_begin(cgx_ctx *ctx, int slot, uint64_t *qseg, uint64_t *seg_off, uint32_t *seg_len, int reader); /* the same copies, only enqueued on side stream `reader`; cgx_text_read_wait(reader) waits for them */
+int cgx_text_offsets(cgx_ctx *ctx, int slot, uint64_t *qtext);                       /* nq+1 cumulative file sizes: file q has qtext[q+1] - qtext[q] bytes */
 #define CGX_MAX_READERS 64
-int cgx_text_read(cgx_ctx *ctx, int slot, uint64_t off, uint64_t bytes, void *dst, int reader); /* D2H on side stream `reader` (0..CGX_MAX_READERS-1), thread safe per reader */
+int cgx_text_read(cgx_ctx *ctx, int slot, uint64_t off, uint64_t bytes, void *dst, int reader); /* D2H of unique-text bytes on side stream `reader` (0..CGX_MAX_READERS-1), thread safe per reader */
 int cgx_text_read_begin(cgx_ctx *ctx, int slot, uint64_t off, uint64_t bytes, void *dst, int reader); /* the same copy, only enqueued */
 int cgx_text_read_wait(cgx_ctx *ctx, int reader);                                                      /* wait for everything enqueued on `reader` */
 void *cgx_pinned_alloc(size_t bytes);

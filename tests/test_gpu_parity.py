@@ -272,7 +272,10 @@ def test_ngram_tables_do_not_change_intervals(cgx, oracle_bin, fixtures_dir, tmp
         for a, b in zip((ex.fetch("lm"), ex.fetch("up"), ex.fetch("down")), want):
             assert np.array_equal(a, b), maxl
         assert ex.stage_ms("sa_probe_lookups") == int(want[0].sum())
-        assert (ex.stage_ms("sa_probe_search") == 0) == (maxl == 5 or int((want[0] > maxl).sum()) == 0)
+        if maxl == 5:
+            assert ex.stage_ms("sa_probe_search") == 0
+        elif int((want[0] > maxl).sum()):
+            assert ex.stage_ms("sa_probe_search") > 0
         assert (ex.stage_ms("sa_probe_slots") > 0) == (maxl >= 2)
     ex.set_option("use_bigrams", 0); ex.set_option("count_probes", 0); ex.sa_lookup()      # round-1 option name: no tables at all
     assert np.array_equal(ex.fetch("up"), want[1])
