@@ -32,6 +32,7 @@
 #include <unistd.h>
 #include <fcntl.h>
 #include <sys/types.h>
+#include <sys/stat.h>
 
 #define SAMPLER 300
 #define LONGEST_SRC 5
@@ -76,6 +77,7 @@ struct cgx_corpus {
     struct wslot { uint8_t len; char s[15]; } *svslot, *tvslot;   /* words of <= 15 bytes packed in 16-byte slots: one cache line serves four words */
     wordmap smap, tmap;
     cgx_lexkey *lexk; cgx_lexval *lexv; uint32_t nlex;
+    uint64_t src_size[4], src_mtime[4];                   /* the four text files the corpus was parsed from (0: unknown), kept in the cache header */
 };
 
 static char *slurp(const char *path, size_t *len) {
@@ -469,6 +471,10 @@ cgx_corpus *cgx_corpus_load(const char *src, const char *tgt, const char *align,
     for (int32_t i = 2; i < c->nsvocab; i++) { c->svlen[i] = (uint32_t)strlen(c->svocab[i]); if (c->svlen[i] > c->maxword) c->maxword = c->svlen[i]; }
     for (int32_t i = 2; i < c->ntvocab; i++) { c->tvlen[i] = (uint32_t)strlen(c->tvocab[i]); if (c->tvlen[i] > c->maxword) c->maxword = c->tvlen[i]; }
     if (build_word_slots(c)) goto bad;
+    {
+        const char *files[4] = {src, tgt, align, lex}; struct stat sb;
+        for (int k = 0; k < 4; k++) if (!stat(files[k], &sb)) { c->src_size[k] = (uint64_t)sb.st_size; c->src_mtime[k] = (uint64_t)sb.st_mtime; }
+    }
     return c;
 bad:
     cgx_corpus_free(c);
@@ -512,15 +518,21 @@ cgx_corpus *cgx_corpus_from_ids(const int32_t *str, uint32_t n, const int32_t *s
  * commented out, SuffixArray.c:208-230).  Native byte order; the header carries every count and the
  * loader checks the file size against them. */
 /* ------------------------------------------------------------------ */
-typedef struct { char magic[8]; uint64_t checksum; uint32_t n, nt, nsent, nlex, nsvocab, ntvocab, maxword, reserved; uint64_t sbytes, tbytes; } cachehdr;
-static const char CACHE_MAGIC[8] = {'C', 'G', 'X', 'C', 'O', 'R', 'P', '1'};
+typedef struct { char magic[8]; uint64_t checksum; uint32_t n, nt, nsent, nlex, nsvocab, ntvocab, maxword, reserved; uint64_t sbytes, tbytes; uint64_t src_size[4], src_mtime[4]; } cachehdr;
+static const char CACHE_MAGIC[8] = {'C', 'G', 'X', 'C', 'O', 'R', 'P', '2'};
 int cgx_corpus_save(const cgx_corpus *c, const char *path) {
     if (!c || !path || !c->rlp || !c->svocab || !c->tvocab) return CGX_ERR_ARG;
-    FILE *f = fopen(path, "wb");
-    if (!f) return CGX_ERR_IO;
+    /* written under a private name and renamed into place: a reader (another --shard process started at the same time)
+     * sees either no cache or a complete one, never a file with holes */
+    size_t pl = strlen(path); char *tmp = malloc(pl + 40);
+    if (!tmp) return CGX_ERR_NOMEM;
+    snprintf(tmp, pl + 40, "%s.tmp.%ld", path, (long)getpid());
+    FILE *f = fopen(tmp, "wb");
+    if (!f) { free(tmp); return CGX_ERR_IO; }
     cachehdr h; memset(&h, 0, sizeof h); memcpy(h.magic, CACHE_MAGIC, 8);
     h.checksum = cgx_corpus_checksum(c); h.n = c->n; h.nt = c->nt; h.nsent = (uint32_t)c->nsent; h.nlex = c->nlex;
     h.nsvocab = (uint32_t)c->nsvocab; h.ntvocab = (uint32_t)c->ntvocab; h.maxword = c->maxword;
+    memcpy(h.src_size, c->src_size, sizeof h.src_size); memcpy(h.src_mtime, c->src_mtime, sizeof h.src_mtime);
     for (int32_t i = 0; i < c->nsvocab; i++) h.sbytes += c->svocab[i] ? c->svlen[i] : 0;
     for (int32_t i = 0; i < c->ntvocab; i++) h.tbytes += c->tvocab[i] ? c->tvlen[i] : 0;
     int ok = fwrite(&h, sizeof h, 1, f) == 1;
@@ -534,7 +546,11 @@ int cgx_corpus_save(const cgx_corpus *c, const char *path) {
     for (int32_t i = 0; ok && i < c->nsvocab; i++) if (c->svocab[i]) PUT(c->svocab[i], c->svlen[i], 1);
     for (int32_t i = 0; ok && i < c->ntvocab; i++) if (c->tvocab[i]) PUT(c->tvocab[i], c->tvlen[i], 1);
 #undef PUT
+    if (ok && (fflush(f) || fsync(fileno(f)))) ok = 0;
     if (fclose(f)) ok = 0;
+    if (ok && rename(tmp, path)) ok = 0;
+    if (!ok) (void)unlink(tmp);
+    free(tmp);
     return ok ? CGX_OK : CGX_ERR_IO;
 }
 static int cache_words(FILE *f, int32_t nv, char ***voc_out, uint32_t **len_out) {
@@ -577,9 +593,32 @@ cgx_corpus *cgx_corpus_load_cache(const char *path, char *err, size_t errcap) {
         }
     }
     fclose(f);
+    memcpy(c->src_size, h.src_size, sizeof c->src_size); memcpy(c->src_mtime, h.src_mtime, sizeof c->src_mtime);
+    /* the content is not trusted: ids index the vocabularies and the lexical table on the device, so they are range-checked,
+     * the sentence tables must be monotone, and the whole corpus must hash to the checksum the writer stored */
+    if (ok) {
+        const char *what = NULL;
+        if (c->nsvocab < 2 || c->ntvocab < 2 || c->nsent < 0 || (uint64_t)c->nsent + 2 > c->n) what = "counts";
+        for (uint32_t i = 0; !what && i < c->n; i++) if (c->str[i] < 1 || c->str[i] > c->nsvocab) what = "source token id";
+        for (uint32_t i = 0; !what && i < c->nt; i++) if (c->tstr[i] < 1 || c->tstr[i] > c->ntvocab) what = "target token id";
+        if (!what && (c->sentind[0] != 0 || c->tsentind[0] != 0)) what = "sentence table";
+        for (int32_t q = 0; !what && q < c->nsent; q++) if (c->sentind[q + 1] <= c->sentind[q] || (uint32_t)c->sentind[q + 1] > c->n || c->tsentind[q + 1] <= c->tsentind[q] || (uint32_t)c->tsentind[q + 1] > c->nt) what = "sentence table";
+        for (uint32_t i = 0; !what && i < c->nlex; i++) if (c->lexk[i].src < -1 || c->lexk[i].src >= c->nsvocab || c->lexk[i].tgt < -1 || c->lexk[i].tgt >= c->ntvocab) what = "lexical table id";
+        if (!what && cgx_corpus_checksum(c) != h.checksum) what = "checksum";
+        if (what) { snprintf(err, errcap, "corpus cache \"%s\" is corrupt (%s)", path, what); ok = 0; }
+    }
     if (ok && build_word_slots(c)) ok = 0;
     if (!ok) { if (!err[0]) snprintf(err, errcap, "cannot read corpus cache \"%s\"", path); cgx_corpus_free(c); return NULL; }
     return c;
+}
+/* 1 when the corpus (as loaded from a cache) was parsed from exactly these four files as they are now (size and
+ * modification time), 0 when one of them has changed or is unknown to the cache, -1 when one cannot be examined */
+int cgx_corpus_matches_sources(const cgx_corpus *c, const char *src, const char *tgt, const char *align, const char *lex) {
+    if (!c) return -1;
+    const char *files[4] = {src, tgt, align, lex}; struct stat sb[4];
+    for (int k = 0; k < 4; k++) if (!files[k] || stat(files[k], &sb[k])) return -1;
+    for (int k = 0; k < 4; k++) if (!c->src_size[k] || c->src_size[k] != (uint64_t)sb[k].st_size || c->src_mtime[k] != (uint64_t)sb[k].st_mtime) return 0;
+    return 1;
 }
 
 int cgx_corpus_upload(cgx_ctx *ctx, const cgx_corpus *c) {

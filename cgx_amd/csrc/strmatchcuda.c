@@ -54,6 +54,10 @@ int main(int argc, char **argv) {
 
     char err[512];
     cgx_corpus *corpus = cache ? cgx_corpus_load_cache(cache, err, sizeof err) : NULL;
+    if (cache && corpus && cgx_corpus_matches_sources(corpus, src, tgt, ali, lex) == 0) {   /* a text file changed since the cache was written: parse again */
+        fprintf(stderr, "strmatchcuda: corpus cache %s is older than the text files, rebuilding it\n", cache);
+        cgx_corpus_free(corpus); corpus = NULL;
+    }
     if (cache && corpus) fprintf(stderr, "strmatchcuda: corpus read from cache %s\n", cache);
     if (!corpus) {
         corpus = cgx_corpus_load(src, tgt, ali, lex, err, sizeof err);

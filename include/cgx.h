@@ -142,7 +142,8 @@ cgx_corpus *cgx_corpus_load(const char *src, const char *tgt, const char *align,
 void cgx_corpus_free(cgx_corpus *c);
 uint64_t cgx_corpus_checksum(const cgx_corpus *c);               /* FNV-1a over every array and spelling of the loaded corpus */
 int cgx_corpus_save(const cgx_corpus *c, const char *path);      /* the parsed corpus as one binary file (the reference's own index cache is commented out, SuffixArray.c:208-230) */
-cgx_corpus *cgx_corpus_load_cache(const char *path, char *err, size_t errcap);   /* reads a file written by cgx_corpus_save; NULL + message if it is missing, truncated or of another version */
+cgx_corpus *cgx_corpus_load_cache(const char *path, char *err, size_t errcap);   /* reads a file written by cgx_corpus_save; NULL + message if it is missing, truncated, of another version, fails its checksum or holds ids out of range */
+int cgx_corpus_matches_sources(const cgx_corpus *c, const char *src, const char *tgt, const char *align, const char *lex);   /* 1: the cache was made from these four files as they are now (size, mtime); 0: stale; -1: a file cannot be examined */
 int cgx_corpus_upload(cgx_ctx *ctx, const cgx_corpus *c);
 /* runs lookup -> gappy search -> extraction -> features for the query file and writes
  * <outdir>/grammar.<q>.s; queries [q_begin, q_end) only (q_end < 0: all) for query sharding */

@@ -83,3 +83,34 @@ def test_corpus_cache_round_trip(name, cgx, fixtures_dir, tmp_path):
         cgx.Corpus.load_cache(path)
     with pytest.raises(cgx.CgxError, match="cannot open"):
         cgx.Corpus.load_cache(str(tmp_path / "missing.cgx"))
+
+
+def test_corpus_cache_is_not_trusted(cgx, fixtures_dir, tmp_path):
+    """A cache of the right size but with flipped bytes fails its checksum or its range checks; a cache whose text files
+    changed afterwards is reported stale; the file appears under its final name only when complete (no .tmp left behind)."""
+    import ctypes as C
+    fx = make_fixture("tiny", fixtures_dir); d = tmp_path / "fx"; shutil.copytree(fx, d); f = op.fixture_args(str(d))
+    c = cgx.Corpus.load(f[0], f[2], f[3], f[4])
+    path = str(tmp_path / "corpus.cgx"); c.save(path); c.close()
+    assert [n for n in os.listdir(tmp_path) if ".tmp." in n] == []
+    lib = cgx.load_library()
+    lib.cgx_corpus_matches_sources.argtypes = [C.c_void_p] + [C.c_char_p] * 4
+    c2 = cgx.Corpus.load_cache(path)
+    args = [f[0].encode(), f[2].encode(), f[3].encode(), f[4].encode()]
+    assert lib.cgx_corpus_matches_sources(c2.h, *args) == 1
+    with open(f[0], "a") as fh:
+        fh.write("one more sentence\n")
+    assert lib.cgx_corpus_matches_sources(c2.h, *args) == 0            # stale: the CLI reparses
+    os.remove(f[2])
+    assert lib.cgx_corpus_matches_sources(c2.h, *args) == -1           # the text files are gone: the cache is all there is
+    c2.close()
+    blob = bytearray(open(path, "rb").read())
+    hdr = 8 + 8 + 8 * 4 + 16 + 64                                      # magic, checksum, eight counts, two byte totals, source fingerprint
+    bad = bytearray(blob); bad[hdr + 4 * 5] ^= 0x01                    # a source token id changes: the checksum no longer matches
+    open(path, "wb").write(bad)
+    with pytest.raises(cgx.CgxError, match="corrupt"):
+        cgx.Corpus.load_cache(path)
+    bad = bytearray(blob); bad[hdr + 4 * 5 + 3] = 0x7F                 # ... to a value outside the vocabulary: refused by the range check
+    open(path, "wb").write(bad)
+    with pytest.raises(cgx.CgxError, match="source token id"):
+        cgx.Corpus.load_cache(path)
