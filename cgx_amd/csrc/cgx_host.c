@@ -1502,15 +1502,15 @@ int cgx_extract_grammars_ids(cgx_ctx *ctx, const cgx_corpus *c, const int32_t *q
     return CGX_OK;
 }
 
-int cgx_extract_grammars(cgx_ctx *ctx, const cgx_corpus *c, const char *qryfile, const char *outdir, int32_t q_begin, int32_t q_end, uint64_t *nrules) {
-    if (!ctx || !c || !qryfile) return CGX_ERR_ARG;
+/* constructQryIndex (Start.cu:74-111): query lines [q_begin, q_end) (q_end < 0: to the end) as token ids, OOV = -1 */
+static int load_queries(const cgx_corpus *c, const char *qryfile, int32_t q_begin, int32_t q_end, int32_t **off_out, int32_t *nq_out, int32_t **tok_out, int32_t *ntok_out) {
     size_t len; char *buf = slurp(qryfile, &len);
     if (!buf) return CGX_ERR_IO;
-    int32_t *off = NULL, *tok = NULL; size_t no = 0, co = 0, nt = 0, ct = 0; size_t i = 0; int32_t line = 0;
-    while (i < len) {                                     /* constructQryIndex, Start.cu:74-111 */
+    int32_t *off = NULL, *tok = NULL; size_t no = 0, co = 0, nt = 0, ct = 0; size_t i = 0; int32_t line = 0; int rc = CGX_OK;
+    while (i < len && rc == CGX_OK) {
         size_t e = i; while (e < len && buf[e] != '\n') e++;
         int take = line >= q_begin && (q_end < 0 || line < q_end);
-        if (take) { if (no == co) { co = co ? co * 2 : 256; off = realloc(off, co * 4); if (!off) return CGX_ERR_NOMEM; } off[no++] = (int32_t)nt; }
+        if (take) { if (no == co) { co = co ? co * 2 : 256; int32_t *n = realloc(off, co * 4); if (!n) { rc = CGX_ERR_NOMEM; break; } off = n; } off[no++] = (int32_t)nt; }
         size_t p = i;
         for (; take;) {
             while (p < e && buf[p] == ' ') p++;
@@ -1518,14 +1518,53 @@ int cgx_extract_grammars(cgx_ctx *ctx, const cgx_corpus *c, const char *qryfile,
             size_t q = p; while (q < e && buf[q] != ' ') q++;
             if (isspace((unsigned char)buf[p])) break;
             int32_t id = wordmap_get(&c->smap, buf + p, q - p);
-            if (nt == ct) { ct = ct ? ct * 2 : 1024; tok = realloc(tok, ct * 4); if (!tok) return CGX_ERR_NOMEM; }
+            if (nt == ct) { ct = ct ? ct * 2 : 1024; int32_t *n = realloc(tok, ct * 4); if (!n) { rc = CGX_ERR_NOMEM; break; } tok = n; }
             tok[nt++] = id < 0 ? -1 : id;
             p = q;
         }
         line++; i = e + 1;
     }
     free(buf);
-    int rc = cgx_extract_grammars_ids(ctx, c, off, (int32_t)no, tok, (int32_t)nt, outdir, q_begin > 0 ? q_begin : 0, nrules);
+    if (rc != CGX_OK) { free(off); free(tok); return rc; }
+    *off_out = off; *nq_out = (int32_t)no; *tok_out = tok; *ntok_out = (int32_t)nt;
+    return CGX_OK;
+}
+int cgx_extract_grammars(cgx_ctx *ctx, const cgx_corpus *c, const char *qryfile, const char *outdir, int32_t q_begin, int32_t q_end, uint64_t *nrules) {
+    if (!ctx || !c || !qryfile) return CGX_ERR_ARG;
+    int32_t *off = NULL, *tok = NULL, nq = 0, ntok = 0;
+    int rc = load_queries(c, qryfile, q_begin, q_end, &off, &nq, &tok, &ntok);
+    if (rc != CGX_OK) return rc;
+    rc = cgx_extract_grammars_ids(ctx, c, off, nq, tok, ntok, outdir, q_begin > 0 ? q_begin : 0, nrules);
     free(off); free(tok);
+    return rc;
+}
+/* Query sharding policy (one process per GPU): contiguous query ranges with about equal TOKEN counts -- shard r ends
+ * with the first query whose last token reaches r+1 shares of the tokens.  The same arithmetic as cgx_amd/shard.py
+ * (bench.py); bounds[0] = 0, bounds[world] = nq. */
+int cgx_shard_bounds(const int32_t *qoff, int32_t nq, int64_t ntok, int32_t world, int32_t *bounds) {
+    if (nq < 0 || ntok < 0 || world < 1 || !bounds || (nq && !qoff)) return CGX_ERR_ARG;
+    bounds[0] = 0; bounds[world] = nq;
+    for (int32_t r = 1; r < world; r++) {
+        const int64_t target = (int64_t)r * ntok / world;
+        int32_t a = 0, z = nq;                                /* first query whose end offset is >= target */
+        while (a < z) { int32_t m = a + (z - a) / 2; int64_t end = m + 1 < nq ? qoff[m + 1] : ntok; if (end < target) a = m + 1; else z = m; }
+        bounds[r] = a > bounds[r - 1] ? a : bounds[r - 1];
+    }
+    return CGX_OK;
+}
+int cgx_extract_grammars_shard(cgx_ctx *ctx, const cgx_corpus *c, const char *qryfile, const char *outdir, int32_t shard, int32_t nshard, uint64_t *nrules) {
+    if (!ctx || !c || !qryfile || nshard < 1 || shard < 0 || shard >= nshard) return CGX_ERR_ARG;
+    int32_t *off = NULL, *tok = NULL, nq = 0, ntok = 0;
+    int rc = load_queries(c, qryfile, 0, -1, &off, &nq, &tok, &ntok);
+    if (rc != CGX_OK) return rc;
+    int32_t *b = malloc(((size_t)nshard + 1) * sizeof *b);
+    if (!b) { free(off); free(tok); return CGX_ERR_NOMEM; }
+    rc = cgx_shard_bounds(off, nq, ntok, nshard, b);
+    if (rc == CGX_OK) {
+        const int32_t q0 = b[shard], q1 = b[shard + 1];
+        const int32_t t0 = q0 < nq ? off[q0] : ntok, t1 = q1 < nq ? off[q1] : ntok;
+        rc = cgx_extract_grammars_ids(ctx, c, off + q0, q1 - q0, tok, t1 - t0, outdir, q0, nrules);   /* offsets stay absolute: the callee rebases on off[q0] */
+    }
+    free(b); free(off); free(tok);
     return rc;
 }

@@ -48,8 +48,6 @@ int main(int argc, char **argv) {
 
     FILE *qf = fopen(qry, "r");
     if (!qf) { fprintf(stderr, "Can not open query file \"%s\"\n", qry); return 0; }   /* diskInit failure: start() returns (Start.cu:528) */
-    int32_t nlines = 0; for (int c; (c = fgetc(qf)) != EOF;) if (c == '\n') nlines++;
-    fseek(qf, -1, SEEK_END); if (ftell(qf) >= 0 && fgetc(qf) != '\n') nlines++;
     fclose(qf);
 
     char err[512];
@@ -77,10 +75,10 @@ int main(int argc, char **argv) {
     if (!ctx) { fprintf(stderr, "strmatchcuda: no usable MI355X/HIP device %d\n", device); return 2; }
     int rc = cgx_corpus_upload(ctx, corpus);
     if (rc != CGX_OK) { fprintf(stderr, "strmatchcuda: %s\n", cgx_last_error(ctx)); return 2; }
-    int32_t qb = (int32_t)((int64_t)nlines * shard / nshard), qe = (int32_t)((int64_t)nlines * (shard + 1) / nshard);
     uint64_t nrules = 0;
     (void)cgx_set_option(ctx, "async_write", 1);             /* large query files run as several internal batches: write batch k while batch k+1 is on the GPU */
-    rc = cgx_extract_grammars(ctx, corpus, qry, out, qb, nshard == 1 ? -1 : qe, &nrules);
+    rc = nshard == 1 ? cgx_extract_grammars(ctx, corpus, qry, out, 0, -1, &nrules)
+                     : cgx_extract_grammars_shard(ctx, corpus, qry, out, shard, nshard, &nrules);   /* contiguous shards balanced by token count */
     if (rc == CGX_OK) rc = cgx_flush(ctx);                   /* every file is on disk (or its error reported) before the summary */
     if (rc != CGX_OK) { fprintf(stderr, "strmatchcuda: %s (%d)\n", cgx_last_error(ctx), rc); return rc == CGX_ERR_IO ? 0 : 2; }
     fprintf(stderr, "strmatchcuda: %llu rules | index: suffix array %.1f ms, frequent pairs %.1f ms | last batch: lookup %.3f, blocks %.3f, gappy %.3f, extract %.3f, lexicon %.3f, text layout %.3f ms | files written in %.1f ms\n",

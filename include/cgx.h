@@ -149,6 +149,10 @@ int cgx_corpus_upload(cgx_ctx *ctx, const cgx_corpus *c);
  * <outdir>/grammar.<q>.s; queries [q_begin, q_end) only (q_end < 0: all) for query sharding */
 int cgx_extract_grammars(cgx_ctx *ctx, const cgx_corpus *c, const char *qryfile, const char *outdir,
                          int32_t q_begin, int32_t q_end, uint64_t *nrules);
+/* query sharding, one process per GPU: shard `shard` of `nshard` contiguous query ranges balanced by token count (cgx_shard_bounds:
+ * bounds[r] .. bounds[r+1]-1 are the queries of shard r; qoff = start offset of every query in the token array, ntok tokens in all) */
+int cgx_shard_bounds(const int32_t *qoff, int32_t nq, int64_t ntok, int32_t world, int32_t *bounds /* world+1 */);
+int cgx_extract_grammars_shard(cgx_ctx *ctx, const cgx_corpus *c, const char *qryfile, const char *outdir, int32_t shard, int32_t nshard, uint64_t *nrules);
 /* same on an id-level batch (bench / tests): corpus may have no spellings, words print as s<id>/t<id> */
 int cgx_extract_grammars_ids(cgx_ctx *ctx, const cgx_corpus *c, const int32_t *qoff, int32_t nq, const int32_t *qtok,
                              int32_t ntok, const char *outdir, int32_t first_query_index, uint64_t *nrules);

@@ -1,7 +1,9 @@
-"""Full-size GPU checks (BASELINE configs[2]: 10 M sentence pairs, 2.6e8 source tokens).  The oracle cannot run at
-this size, so the HIP path is checked through properties that do not depend on size: the suffix array is a sorted
-permutation, every reported interval is exactly the set of suffixes that start with the phrase, and the grammar
-files do not depend on how the batch is split or scheduled."""
+"""Full-size GPU checks at the corpus sizes of BASELINE configs[2] (10 M sentence pairs, 2.6e8 source tokens), configs[3]
+(Europarl scale, 5.5e7 source tokens) and configs[4] (1e8 source tokens).  The oracle cannot run at these sizes, so the HIP
+path is checked through properties that do not depend on size: the suffix array is a sorted permutation, every reported
+interval is exactly the set of suffixes that start with the phrase, the grammar files do not depend on how the batch is
+split or scheduled, and (cfg4) two contexts that each take half of the queries against their own replica of the index
+write the files one context writes."""
 import hashlib
 import os
 import shutil
@@ -12,16 +14,18 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 PAIRS = int(os.environ.get("CGX_FULLSIZE_PAIRS", "10000000"))
+SIZES = {"cfg3": (PAIRS, 200000), "cfg5": (int(os.environ.get("CGX_CFG5_PAIRS", "3846000")), 200000)}
 
 
-@pytest.fixture(scope="module")
-def world():
+@pytest.fixture(scope="module", params=sorted(SIZES))
+def world(request):
+    pairs, vocab = SIZES[request.param]
     import torch
     torch.zeros(1, device="cuda:0")
     import cgx_amd
     from cgx_amd import synth
     cgx_amd.load_library()
-    corpus = synth.make_corpus(PAIRS, 200000, 1)
+    corpus = synth.make_corpus(pairs, vocab, 1)
     host = cgx_amd.Corpus.from_ids(corpus["str"], corpus["sentind"], corpus["tstr"], corpus["tsentind"], corpus["lsrc"], corpus["rsrc"],
                                    corpus["ltar"], corpus["rtar"], corpus["lexk"], corpus["lexv"])
     ex = cgx_amd.Extractor(0)
@@ -135,3 +139,69 @@ def test_grammar_files_do_not_depend_on_batching(world):
         assert n3 == n_all and _sha_dir(dirs[2], nq) == ref
     finally:
         shutil.rmtree(out, ignore_errors=True)
+
+
+def test_cfg4_two_contexts_split_equals_one(tmp_path):
+    """BASELINE configs[3] on one card: Europarl-scale corpus (about 2.1 M sentence pairs, N = 5.5e7), one batch of queries
+    (a) on the context that built the index, (b) split by token count (cgx_amd.shard, the policy of bench.py and of
+    strmatchcuda --shard) over that context and a second one holding a replica received buffer by buffer: the union of the
+    two shards' files equals (a), and the rule counts add up."""
+    import torch
+    torch.zeros(1, device="cuda:0")
+    import cgx_amd
+    from cgx_amd import synth, shard
+    pairs = int(os.environ.get("CGX_CFG4_PAIRS", "2115000"))
+    corpus = synth.make_corpus(pairs, 150000, 4)
+    assert 5.0e7 < len(corpus["str"]) < 6.0e7 or pairs != 2115000
+    host = cgx_amd.Corpus.from_ids(corpus["str"], corpus["sentind"], corpus["tstr"], corpus["tsentind"], corpus["lsrc"], corpus["rsrc"],
+                                   corpus["ltar"], corpus["rtar"], corpus["lexk"], corpus["lexv"])
+    root = cgx_amd.Extractor(0); root.upload_corpus(host)
+    rep = cgx_amd.Extractor(0); rep.index_alloc(root.index_shape())
+    for i, (name, nbytes) in enumerate(root.index_buffers()):
+        if nbytes:
+            stage = torch.empty(nbytes, dtype=torch.uint8, device="cuda:0")
+            root.index_d2d(i, stage.data_ptr(), 0); torch.cuda.synchronize()
+            rep.index_d2d(i, stage.data_ptr(), 1); torch.cuda.synchronize()
+            del stage
+    rep.index_finalize()
+    nq = 1500
+    qoff, qtok = synth.make_queries(corpus, nq, 8)
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    out = tempfile.mkdtemp(prefix="cgx_cfg4_", dir=base)
+    try:
+        a, b = os.path.join(out, "a"), os.path.join(out, "b"); os.mkdir(a); os.mkdir(b)
+        n_all = root.extract_grammars_ids(host, qoff, qtok, a, 0)
+        total = 0
+        for r, ex in enumerate((root, rep)):
+            first, so, st = shard.take_shard(qoff, qtok, r, 2)
+            assert len(so) > 0
+            ex.set_option("async_write", 1)
+            total += ex.extract_grammars_ids(host, so, st, b, first)
+        root.flush(); rep.flush()
+        assert total == n_all and n_all > 0 and _sha_dir(a, nq) == _sha_dir(b, nq)
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+        rep.close(); root.close(); host.close()
+
+
+def test_bench_contract_small(tmp_path):
+    """bench.py end to end on a small corpus with the cfg5 mechanics (strong scaling, several spool chunks per step that
+    reuse the file slots): one JSON line with the contract's fields, an honest roofline block and a CPU baseline."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "cfg5", "--pairs", "60000", "--queries", "2500", "--chunk-queries", "1000", "--steps", "2",
+                        "--warmup", "1", "--cpu-pairs", "20000", "--cpu-seconds", "1.5"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["vs_baseline"] is None
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and 0 < rf["frac"] <= 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert d["config"]["grammar_files_written"] and "3 chunk(s)" in d["config"]["outdir_mode"]
+    cb = d["cpu_baseline"]
+    assert cb.get("kind") == "port" and cb["one_core"]["value"] > 0 and cb["all_cores"]["cores"] >= 1 and cb["value"] > 0

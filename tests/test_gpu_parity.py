@@ -79,6 +79,18 @@ def test_cli_is_a_drop_in(cgx, oracle_bin, fixtures_dir, tmp_path):
     assert r.returncode == 0 and "It is not valid" in r.stderr          # PrintResults.c:443-446
 
 
+def test_cli_query_shards_union_is_the_whole(cgx, fixtures_dir, tmp_path):
+    """strmatchcuda --shard i/n (one process per GPU; contiguous shards balanced by token count): the union of the shards'
+    files is the single-process output."""
+    fx = make_fixture("mid", fixtures_dir); out = tmp_path / "sh"; out.mkdir(); exe = os.path.join(ROOT, "bin", "strmatchcuda")
+    for i in range(3):
+        r = subprocess.run([exe, "--shard", "%d/3" % i] + op.fixture_args(fx) + [str(out)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+    nq = META["mid"]["spec"][2]
+    assert sorted(os.listdir(out)) == sorted("grammar.%d.s" % q for q in range(nq))
+    assert op.sha_dir(str(out), nq) == META["mid"]["grammar"]
+
+
 @pytest.mark.parametrize("name", ["tiny", "mid"])
 def test_every_stage_matches_the_oracle(name, cgx, oracle_bin, fixtures_dir, tmp_path):
     fx = make_fixture(name, fixtures_dir); dump = str(tmp_path / "d.bin")

@@ -71,3 +71,22 @@ def test_two_gloo_ranks_reproduce_the_single_process_files(oracle_bin, tmp_path)
             assert p.returncode == 0, o
         outs[world] = op.sha_dir(str(out), 9)
     assert outs[1] == outs[2]
+
+
+def test_c_and_python_shard_policies_agree():
+    """strmatchcuda --shard i/n (cgx_shard_bounds, host C) and bench.py (cgx_amd.shard) must cut a query list at the same places."""
+    import ctypes as C
+    import cgx_amd
+    from cgx_amd import shard
+    lib = cgx_amd.load_library()
+    lib.cgx_shard_bounds.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p]
+    rng = np.random.default_rng(5)
+    for trial in range(200):
+        nq = int(rng.integers(0, 40)); lens = rng.integers(0, 30, nq) * (rng.random(nq) < 0.8)
+        qoff = np.concatenate(([0], np.cumsum(lens)))[:-1].astype(np.int32) if nq else np.zeros(0, np.int32)
+        ntok = int(lens.sum())
+        for world in (1, 2, 3, 8, 17):
+            got = np.zeros(world + 1, np.int32)
+            assert lib.cgx_shard_bounds(qoff.ctypes.data_as(C.c_void_p) if nq else None, nq, ntok, world, got.ctypes.data_as(C.c_void_p)) == 0
+            want = shard.shard_bounds(qoff, ntok, world) if nq else np.zeros(world + 1, np.int64)
+            assert np.array_equal(got, want), (trial, world, qoff, got, want)
