@@ -30,6 +30,7 @@ struct cgx_ctx {
     int32_t *d_str = nullptr, *d_sa = nullptr, *d_tstr = nullptr;
     uint32_t *d_rlp = nullptr;
     uint8_t *d_ltar = nullptr, *d_rtar = nullptr;
+    cgx_tok8 *d_tok8 = nullptr; uint8_t *d_lr16 = nullptr;   // derived layouts (cgx_rules.h), built by build_layouts
     uint64_t *d_lexkey = nullptr; float *d_lexv1 = nullptr, *d_lexv2 = nullptr, *d_lexn1 = nullptr, *d_lexn2 = nullptr;
     uint32_t *d_lexrow = nullptr; int32_t *d_lexnullt = nullptr; uint32_t lex_nrow = 0, lex_ntgt = 0;
     cgx_lexslot *d_lexslot = nullptr; cgx_lexnull *d_lexnullv = nullptr;
@@ -37,6 +38,7 @@ struct cgx_ctx {
     int32_t *d_tokstart = nullptr; int8_t *d_tokrank = nullptr; int32_t *d_freq = nullptr;
     uint32_t *d_pidx = nullptr; int32_t *d_miss = nullptr; uint32_t *d_phit_start = nullptr; uint8_t *d_phit_len = nullptr;
     cgx_ngslot *d_ng[4] = {nullptr, nullptr, nullptr, nullptr}; uint32_t ng_cap[4] = {0, 0, 0, 0}; unsigned ng_shift[4] = {0, 0, 0, 0};   // l-gram (l = 2..5) -> SA interval
+    bool use_layouts = true;            // test hook: 0 = window kernels read the plain str / rlp / ltar / rtar arrays (round-1 access pattern)
     int ngram_max = 5;                  // longest phrase answered from the l-gram tables (1: none, every l >= 2 by binary search)
     bool count_probes = false;          // cgx_sa_lookup also runs the probe-counting variant of its kernel (untimed; "sa_probe_*")
     bool prealloc_text = false;         // allocate both text slots at the first batch (set when more batches will follow)

@@ -34,13 +34,20 @@
 #define CGX_SAMPLER_TWOGAP 70
 #define CGX_MAXSCORE 99.0f
 
+struct cgx_tok8 { int32_t tok; uint32_t rlp; };   // one corpus position: token id and its alignment word, side by side
 struct cgx_view {            // read-only index arrays (device pointers on the GPU)
     const int32_t *str;      // source tokens
     const uint32_t *rlp;     // (L<<24)|(R<<16)|(P<<8) per source token; delimiter slot = target offset of next sentence
     const uint8_t *ltar;     // per target token: min aligned source position (in sentence), 255 = none
     const uint8_t *rtar;
     uint32_t n;
+    // derived device-only layouts (built after upload, rebuilt on replicas):
+    const cgx_tok8 *tok8;    // str and rlp interleaved: a 16-token window is ONE 128-byte run instead of two 64-byte runs in two arrays
+    const uint8_t *lr16;     // ltar/rtar in blocks of 16 target words: 16 L bytes, then their 16 R bytes -- the back-projection test
+                             // of a <= 16-word span reads one 64..96-byte run instead of two runs in two arrays
 };
+// address of the dword holding the L bytes of target words w..w+3 (w a multiple of 4) in the lr16 layout; the R bytes sit 16 bytes further
+CGX_HD uint32_t cgx_lr16_off(uint32_t w) { return ((w >> 4) << 5) | (w & 15u); }
 
 // running min/max of aligned target positions over a set of source tokens
 struct cgx_span {
@@ -72,10 +79,15 @@ CGX_HD bool cgx_tight(const cgx_view &v, int ts, int te, int s_chk, int e_chk, i
     // both byte tables are read with five aligned dword loads each (they are padded) instead of a byte load per
     // word -- the extraction kernels were bound by the number of L1 requests, most of them issued here.
     if (te - ts < 16) {
-        const uint32_t *pl = (const uint32_t *)(v.ltar + (ts & ~3)), *pr = (const uint32_t *)(v.rtar + (ts & ~3));
         uint32_t a[5], b[5];
-        CGX_UNROLL
-        for (int i = 0; i < 5; i++) { a[i] = pl[i]; b[i] = pr[i]; }
+        if (v.lr16) {
+            CGX_UNROLL
+            for (int i = 0; i < 5; i++) { const uint32_t o = cgx_lr16_off((uint32_t)(ts & ~3) + 4u * (uint32_t)i); a[i] = *(const uint32_t *)(v.lr16 + o); b[i] = *(const uint32_t *)(v.lr16 + o + 16); }
+        } else {
+            const uint32_t *pl = (const uint32_t *)(v.ltar + (ts & ~3)), *pr = (const uint32_t *)(v.rtar + (ts & ~3));
+            CGX_UNROLL
+            for (int i = 0; i < 5; i++) { a[i] = pl[i]; b[i] = pr[i]; }
+        }
         const unsigned sh = (unsigned)ts & 3u; const int last = te - ts;
         CGX_UNROLL
         for (int i = 0; i < 4; i++) {
