@@ -3,8 +3,9 @@
  * bin/strmatchcuda (Main.c:29-86):
  *   strmatchcuda [-h] [-l minmatchlen] [-t fingerlen] [-s timefile] <src> <query> <tgt> <align> <lex> <outdir>
  * Extra, optional: --device N (default 0), --shard i/n (this process handles the i-th of n
- * contiguous query shards; one process per GPU), --index-cache FILE (load the parsed corpus from
- * FILE if it exists, otherwise parse the four text files and write FILE for the next run).
+ * contiguous query shards balanced by token count; one process per GPU), --index-cache FILE (load the parsed
+ * corpus from FILE and the built index -- suffix array, frequent-pair lists, tables -- from FILE.idx if they exist and
+ * still match the text files; otherwise parse / build and write them for the next run).
  */
 #include "../../include/cgx.h"
 #include <stdio.h>
@@ -73,8 +74,18 @@ int main(int argc, char **argv) {
     }
     cgx_ctx *ctx = cgx_create(device);
     if (!ctx) { fprintf(stderr, "strmatchcuda: no usable MI355X/HIP device %d\n", device); return 2; }
-    int rc = cgx_corpus_upload(ctx, corpus);
-    if (rc != CGX_OK) { fprintf(stderr, "strmatchcuda: %s\n", cgx_last_error(ctx)); return 2; }
+    int rc = CGX_ERR_IO; char *idx = NULL;
+    if (cache) {                                             /* the built index next to the parsed corpus: <cache>.idx */
+        idx = malloc(strlen(cache) + 8); sprintf(idx, "%s.idx", cache);
+        rc = cgx_index_load(ctx, idx, cgx_corpus_checksum(corpus));
+        if (rc == CGX_OK) fprintf(stderr, "strmatchcuda: index read from cache %s\n", idx);
+    }
+    if (rc != CGX_OK) {
+        rc = cgx_corpus_upload(ctx, corpus);
+        if (rc != CGX_OK) { fprintf(stderr, "strmatchcuda: %s\n", cgx_last_error(ctx)); return 2; }
+        if (idx && cgx_index_save(ctx, idx, cgx_corpus_checksum(corpus)) != CGX_OK) fprintf(stderr, "strmatchcuda: could not write the index cache %s\n", idx);
+    }
+    free(idx);
     uint64_t nrules = 0;
     (void)cgx_set_option(ctx, "async_write", 1);             /* large query files run as several internal batches: write batch k while batch k+1 is on the GPU */
     rc = nshard == 1 ? cgx_extract_grammars(ctx, corpus, qry, out, 0, -1, &nrules)

@@ -88,6 +88,11 @@ int cgx_index_nbuffers(cgx_ctx *ctx);
 int cgx_index_buffer(cgx_ctx *ctx, int i, const char **name, uint64_t *nbytes);
 int cgx_index_d2d(cgx_ctx *ctx, int i, void *dptr, int dir);
 int cgx_index_finalize(cgx_ctx *ctx);                           /* after the last d2d on a replica */
+/* the built index as one file (what a replica receives; derived tables are rebuilt on load): a later start with the same corpus
+ * (cgx_corpus_checksum) skips cgx_upload_index / cgx_build_sa / cgx_precompute.  The reference's own cache is commented out (SuffixArray.c:208-230).
+ * cgx_index_load: CGX_ERR_IO if the file is missing / unreadable / fails its content check, CGX_ERR_STATE if it is of another version or corpus. */
+int cgx_index_save(cgx_ctx *ctx, const char *path, uint64_t corpus_checksum);
+int cgx_index_load(cgx_ctx *ctx, const char *path, uint64_t corpus_checksum);
 /* one-time broadcast of every index buffer from rank `root` over an existing RCCL communicator */
 int cgx_broadcast_index(cgx_ctx *ctx, void *nccl_comm, int root, int rank);
 

@@ -53,19 +53,38 @@ def test_grammar_files_bit_exact(name, device_format, cgx, oracle_bin, fixtures_
 
 
 def test_corpus_cache_gives_the_same_files(cgx, fixtures_dir, tmp_path):
-    """--index-cache: the first run parses the text files and writes the cache, the second reads only the cache
-    (the text corpus is gone by then); both produce the golden grammar files."""
+    """--index-cache: the first run parses the text files, builds the index and writes both caches (parsed corpus, built
+    index); the second reads only the caches (the text corpus is gone by then; no suffix-array construction, no
+    frequent-pair precomputation); a damaged index cache is detected and rebuilt.  All runs produce the golden files."""
     fx = make_fixture("toy", fixtures_dir); d = tmp_path / "fx"; shutil.copytree(fx, d)
     cache = str(tmp_path / "toy.cgx"); exe = os.path.join(ROOT, "bin", "strmatchcuda")
-    for run in (0, 1):
+    for run in (0, 1, 2):
         out = tmp_path / ("o%d" % run); out.mkdir()
         r = subprocess.run([exe, "--index-cache", cache] + op.fixture_args(str(d)) + [str(out)], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr
-        assert ("corpus read from cache" in r.stderr) == (run == 1)
+        assert ("corpus read from cache" in r.stderr) == (run >= 1)
+        assert ("index read from cache" in r.stderr) == (run == 1), r.stderr
+        assert ("suffix array 0.0 ms, frequent pairs 0.0 ms" in r.stderr) == (run == 1)
         assert op.sha_dir(str(out), 7) == META["toy"]["grammar"]
         if run == 0:
             for n in ("corpus.f", "corpus.e", "corpus.a", "lex.txt"):
                 os.remove(d / n)
+        if run == 1:                                             # flip one byte in the middle of the index cache
+            blob = bytearray(open(cache + ".idx", "rb").read()); blob[len(blob) // 2] ^= 0x40
+            open(cache + ".idx", "wb").write(blob)
+    # library level: a second context loads the file instead of building, a wrong corpus checksum is refused
+    files = op.fixture_args(fx)
+    corpus = cgx.Corpus.load(files[0], files[2], files[3], files[4]); ck = corpus.checksum()
+    ex = cgx.Extractor(0); ex.upload_corpus(corpus); path = str(tmp_path / "lib.idx"); ex.index_save(path, ck)
+    ex2 = cgx.Extractor(0)
+    with pytest.raises(cgx.CgxError, match="another corpus"):
+        ex2.index_load(path, ck ^ 1)
+    ex2.index_load(path, ck)
+    assert np.array_equal(ex2.fetch("sa"), ex.fetch("sa")) and np.array_equal(ex2.fetch("phit_start"), ex.fetch("phit_start"))
+    out = tmp_path / "lib"; out.mkdir()
+    ex2.extract_grammars(corpus, files[1], str(out))
+    assert op.sha_dir(str(out), 7) == META["toy"]["grammar"]
+    ex.close(); ex2.close(); corpus.close()
 
 
 def test_cli_is_a_drop_in(cgx, oracle_bin, fixtures_dir, tmp_path):
