@@ -43,42 +43,53 @@ static int fail(cgx_ctx *c, int code, const char *what, hipError_t e) {
 // sizes again.  One pool per device (a block is only ever reused on the device it came from), one lock for all of
 // them (contexts on different devices may be driven from different threads).
 #include <mutex>
+// A freed block may still be in use by kernels queued on the stream of the context that freed it.  Reuse by the SAME
+// stream is ordered behind them; a block handed to a context with another stream (two contexts on one device) first
+// waits for the stream it was last used on.
 struct DevPool {
-    struct blk { size_t bytes; const void *owner; };          // owner != null: a temporary of that context (see dalloc)
+    struct blk { size_t bytes; const void *owner; hipStream_t stream; };   // owner != null: a temporary of that context (see dalloc)
+    struct idle { void *p; hipStream_t stream; };
     std::unordered_map<void *, blk> live;
-    std::multimap<size_t, void *> cached;
+    std::multimap<size_t, idle> cached;
     size_t cached_bytes = 0;
-    void *get(size_t bytes, const void *owner) {
+    void *get(size_t bytes, const void *owner, hipStream_t stream) {
         auto it = cached.lower_bound(bytes);
-        if (it != cached.end() && it->first <= bytes * 2 + (1u << 20)) { void *p = it->second; live[p] = blk{it->first, owner}; cached_bytes -= it->first; cached.erase(it); return p; }
+        if (it != cached.end() && it->first <= bytes * 2 + (1u << 20)) {
+            idle e = it->second; const size_t have = it->first;
+            cached_bytes -= have; cached.erase(it);
+            if (e.stream && e.stream != stream) (void)hipStreamSynchronize(e.stream);
+            live[e.p] = blk{have, owner, stream};
+            return e.p;
+        }
         void *p = nullptr;
         if (hipMalloc(&p, bytes) != hipSuccess) { trim(); (void)hipGetLastError(); if (hipMalloc(&p, bytes) != hipSuccess) return nullptr; }
-        live[p] = blk{bytes, owner};
+        live[p] = blk{bytes, owner, stream};
         return p;
     }
     bool put(void *p) {
         auto it = live.find(p);
         if (it == live.end()) return false;
-        cached.insert({it->second.bytes, p}); cached_bytes += it->second.bytes; live.erase(it);
+        cached.insert({it->second.bytes, idle{p, it->second.stream}}); cached_bytes += it->second.bytes; live.erase(it);
         return true;
     }
     size_t sweep(const void *owner) {                         // temporaries a failed call of `owner` left behind
         size_t n = 0;
         for (auto it = live.begin(); it != live.end();) {
-            if (it->second.owner == owner) { cached.insert({it->second.bytes, it->first}); cached_bytes += it->second.bytes; it = live.erase(it); n++; }
+            if (it->second.owner == owner) { cached.insert({it->second.bytes, idle{it->first, it->second.stream}}); cached_bytes += it->second.bytes; it = live.erase(it); n++; }
             else ++it;
         }
         return n;
     }
-    void trim() { for (auto &kv : cached) (void)hipFree(kv.second); cached.clear(); cached_bytes = 0; }
+    void forget(hipStream_t stream) { for (auto &kv : cached) if (kv.second.stream == stream) kv.second.stream = nullptr; }   // the stream is about to be destroyed (already synchronised)
+    void trim() { for (auto &kv : cached) (void)hipFree(kv.second.p); cached.clear(); cached_bytes = 0; }
 };
 #define CGX_MAX_DEVICES 64
 static DevPool g_pools[CGX_MAX_DEVICES];
 static std::mutex g_pool_lock;
 static DevPool &pool_of(int device) { return g_pools[device < 0 || device >= CGX_MAX_DEVICES ? 0 : device]; }
-static void *pool_get(int device, size_t bytes, const void *owner) {
+static void *pool_get(int device, size_t bytes, const void *owner, hipStream_t stream) {
     std::lock_guard<std::mutex> g(g_pool_lock);
-    return pool_of(device).get(bytes, owner);                 // the caller has made `device` current
+    return pool_of(device).get(bytes, owner, stream);         // the caller has made `device` current
 }
 static void pool_put(void *p) {
     std::lock_guard<std::mutex> g(g_pool_lock);
@@ -102,7 +113,7 @@ template <class T> static int dalloc(cgx_ctx *ctx, T **p, size_t count) {
     bytes = (bytes + 255) & ~(size_t)255;
     const bool member = (const char *)p >= (const char *)ctx && (const char *)p < (const char *)(ctx + 1);
     if (ctx->fault_inject > 0 && --ctx->fault_inject == 0) { *p = nullptr; return fail(ctx, CGX_ERR_NOMEM, "device allocation (injected fault)", hipErrorOutOfMemory); }
-    *p = (T *)pool_get(ctx->device, bytes, member ? nullptr : (const void *)ctx);
+    *p = (T *)pool_get(ctx->device, bytes, member ? nullptr : (const void *)ctx, ctx->stream);
     if (!*p) return fail(ctx, CGX_ERR_NOMEM, "device allocation", hipErrorOutOfMemory);
     return CGX_OK;
 }
@@ -363,6 +374,7 @@ extern "C" void cgx_destroy(cgx_ctx *c) {
     for (int r = 0; r < CGX_MAX_READERS; r++) if (c->copy_done[r]) (void)hipEventDestroy(c->copy_done[r]);
     (void)hipStreamSynchronize(c->stream);
     stage_enter(c);
+    { std::lock_guard<std::mutex> g(g_pool_lock); pool_of(c->device).forget(c->stream); }
     pool_trim(c->device);
     (void)hipStreamDestroy(c->stream);
     delete c;
