@@ -131,6 +131,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; nccl (= RCCL over xGMI) for real runs, gloo only to rehearse N>1 on a one-GPU box")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--bcast", choices=("torch", "c"), default="torch", help="index broadcast: torch = torch.distributed.broadcast (RCCL) on a staging tensor per buffer; c = the library's own cgx_broadcast_index on an RCCL communicator made here (what a C host would call)")
     ap.add_argument("--sub-batch", type=int, default=0, help="queries per internal batch inside one call (0 = automatic)")
     ap.add_argument("--no-numa-pin", action="store_true", help="do not bind the writer threads to the GPU's NUMA node")
     ap.add_argument("--sync-write", action="store_true", help="write each chunk's files before starting the next chunk")
@@ -207,21 +208,46 @@ def main():
         dist.broadcast_object_list(meta, src=0)
         if rank != 0:
             ex.index_alloc(meta[0])
-        torch.cuda.synchronize(); dist.barrier(); tb = time.perf_counter()
-        for i, (name, nbytes) in enumerate(ex.index_buffers()):
-            if nbytes == 0:
-                continue
-            stage = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
-            if rank == 0:
-                ex.index_d2d(i, stage.data_ptr(), 0)
-            dist.broadcast(stage, src=0)
-            torch.cuda.synchronize()
+        bcast_bytes = sum(nb for _, nb in ex.index_buffers())
+        if args.bcast == "c":
+            # the C path of INTEGRATION.md: an RCCL communicator of our own (unique id passed through the process group), then ONE call
+            import ctypes as C
+            try:
+                rccl = C.CDLL("librccl.so", mode=C.RTLD_GLOBAL)
+            except OSError:
+                rccl = C.CDLL("librccl.so.1", mode=C.RTLD_GLOBAL)
+            class UniqueId(C.Structure):
+                _fields_ = [("internal", C.c_char * 128)]
+            uid = UniqueId()
+            if rank == 0 and rccl.ncclGetUniqueId(C.byref(uid)) != 0:
+                raise SystemExit("ncclGetUniqueId failed")
+            box = [bytes(uid.internal)] if rank == 0 else [None]
+            dist.broadcast_object_list(box, src=0)
+            C.memmove(C.byref(uid), box[0], 128)
+            comm = C.c_void_p()
+            rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+            if rccl.ncclCommInitRank(C.byref(comm), world, uid, rank) != 0:
+                raise SystemExit("ncclCommInitRank failed")
+            torch.cuda.synchronize(); dist.barrier(); tb = time.perf_counter()
+            ex._chk(ex.lib.cgx_broadcast_index(ex.h, comm, 0, rank), "cgx_broadcast_index")     # non-root ranks finalize inside
+            torch.cuda.synchronize(); dist.barrier(); t_bcast = time.perf_counter() - tb
+            rccl.ncclCommDestroy.argtypes = [C.c_void_p]; rccl.ncclCommDestroy(comm)
+        else:
+            torch.cuda.synchronize(); dist.barrier(); tb = time.perf_counter()
+            for i, (name, nbytes) in enumerate(ex.index_buffers()):
+                if nbytes == 0:
+                    continue
+                stage = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+                if rank == 0:
+                    ex.index_d2d(i, stage.data_ptr(), 0)
+                dist.broadcast(stage, src=0)
+                torch.cuda.synchronize()
+                if rank != 0:
+                    ex.index_d2d(i, stage.data_ptr(), 1)
+                del stage
+            torch.cuda.synchronize(); dist.barrier(); t_bcast = time.perf_counter() - tb
             if rank != 0:
-                ex.index_d2d(i, stage.data_ptr(), 1)
-            del stage; bcast_bytes += nbytes
-        torch.cuda.synchronize(); dist.barrier(); t_bcast = time.perf_counter() - tb
-        if rank != 0:
-            ex.index_finalize()
+                ex.index_finalize()
         torch.cuda.synchronize(); dist.barrier()
     t_index = time.perf_counter() - t0
 
@@ -372,7 +398,7 @@ def report(ex, args, cfg, L):
     out = {
         "config": {"workload": cfg["what"], "name": args.config, "sentence_pairs": cfg["pairs"], "source_tokens": n_src, "vocab": cfg["vocab"],
                    "queries_per_step_this_rank": int(nq), "query_tokens_per_step_this_rank": int(len(qtok)), "global_queries_per_step": int(L["global_q"]),
-                   "parallelism": "query-shard x%d, index replicated (one RCCL broadcast)" % world,
+                   "parallelism": "query-shard x%d, index replicated (one RCCL broadcast, %s)" % (world, "cgx_broadcast_index" if args.bcast == "c" else "torch.distributed"),
                    "grammar_files_written": bool(L["write"]), "grammar_bytes_per_spool_fill": int(L["spool_bytes"][0]),
                    "writer": None if not L["write"] else ("sync" if args.sync_write else "async (host threads overlap the next chunk; flushed before the clock stops)"),
                    "outdir": L["base"] if L["write"] else None,

@@ -702,10 +702,11 @@ static int fetch_host_blocks(cgx_ctx *ctx, batch *b) {
 static int pattern_lists(batch *b, const uint32_t *pid, const int32_t *tokpos, uint32_t n, const int32_t *tok2q, idlist **out) {
     idlist *l = calloc((size_t)b->nq + 1, sizeof *l);
     int64_t *seen = malloc(((size_t)b->nq + 1) * 8);
-    if (!l || !seen) return CGX_ERR_NOMEM;
+    if (!l || !seen) { free(l); free(seen); return CGX_ERR_NOMEM; }
+    *out = l;                                                 /* owned by the batch from here on (batch_free releases the lists) */
     for (int32_t q = 0; q < b->nq; q++) seen[q] = -1;
-    for (uint32_t i = 0; i < n; i++) { int32_t q = tok2q[tokpos[i]]; if (seen[q] != (int64_t)pid[i]) { seen[q] = pid[i]; if (idlist_push(&l[q], pid[i])) return CGX_ERR_NOMEM; } }
-    free(seen); *out = l;
+    for (uint32_t i = 0; i < n; i++) { int32_t q = tok2q[tokpos[i]]; if (seen[q] != (int64_t)pid[i]) { seen[q] = pid[i]; if (idlist_push(&l[q], pid[i])) { free(seen); return CGX_ERR_NOMEM; } } }
+    free(seen);
     return CGX_OK;
 }
 
@@ -1361,21 +1362,23 @@ static int run_batch(cgx_ctx *ctx, const cgx_corpus *c, batch *b, const char *ou
     uint32_t *pid1 = NULL, *pid2 = NULL; cgx_gappy *g1 = NULL; cgx_twogappy *g2 = NULL; uint32_t counts[16];
     if (cgx_fetch(ctx, "counts", counts, sizeof counts) < 0) return CGX_ERR_HIP;
     b->d1 = counts[1]; b->d2 = counts[4]; b->sep1 = counts[10]; b->sep2a = counts[11]; b->sep2b = counts[12];
-    if ((rc = fetch_alloc(ctx, "pid1", (void **)&pid1, 4, &b->e1)) || (rc = fetch_alloc(ctx, "g1", (void **)&g1, sizeof *g1, NULL)) ||
-        (rc = fetch_alloc(ctx, "pid2", (void **)&pid2, 4, &b->e2)) || (rc = fetch_alloc(ctx, "g2", (void **)&g2, sizeof *g2, NULL)) ||
-        (rc = fetch_alloc(ctx, "p1d", (void **)&b->p1d, sizeof *b->p1d, NULL)) || (rc = fetch_alloc(ctx, "c2d", (void **)&b->c2d, 4, NULL)) ||
-        (rc = fetch_alloc(ctx, "one2", (void **)&b->one2, 4, NULL))) return rc;
     t = now_ms();
-    {   /* per-query pattern lists */
-        int32_t *tok2q = malloc(((size_t)b->ntok + 1) * 4), *pos1 = malloc(((size_t)b->e1 + 1) * 4), *pos2 = malloc(((size_t)b->e2 + 1) * 4);
-        if (!tok2q || !pos1 || !pos2) return CGX_ERR_NOMEM;
+    {   /* per-query pattern lists; the scratch arrays of this block are released on every path out of it */
+        int32_t *tok2q = NULL, *pos1 = NULL, *pos2 = NULL;
+        if ((rc = fetch_alloc(ctx, "pid1", (void **)&pid1, 4, &b->e1)) || (rc = fetch_alloc(ctx, "g1", (void **)&g1, sizeof *g1, NULL)) ||
+            (rc = fetch_alloc(ctx, "pid2", (void **)&pid2, 4, &b->e2)) || (rc = fetch_alloc(ctx, "g2", (void **)&g2, sizeof *g2, NULL)) ||
+            (rc = fetch_alloc(ctx, "p1d", (void **)&b->p1d, sizeof *b->p1d, NULL)) || (rc = fetch_alloc(ctx, "c2d", (void **)&b->c2d, 4, NULL)) ||
+            (rc = fetch_alloc(ctx, "one2", (void **)&b->one2, 4, NULL))) goto lists_done;
+        tok2q = malloc(((size_t)b->ntok + 1) * 4); pos1 = malloc(((size_t)b->e1 + 1) * 4); pos2 = malloc(((size_t)b->e2 + 1) * 4);
+        if (!tok2q || !pos1 || !pos2) { rc = CGX_ERR_NOMEM; goto lists_done; }
         for (int32_t q = 0; q < b->nq; q++) for (int32_t k = b->qoff[q]; k < b->qoff[q + 1]; k++) tok2q[k] = q;
         for (uint32_t i = 0; i < b->e1; i++) pos1[i] = g1[i].qrystart;
         for (uint32_t i = 0; i < b->e2; i++) pos2[i] = (int32_t)g2[i].gap2;
-        if ((rc = pattern_lists(b, pid1, pos1, b->e1, tok2q, &b->qone)) || (rc = pattern_lists(b, pid2, pos2, b->e2, tok2q, &b->qtwo))) return rc;
-        free(tok2q); free(pos1); free(pos2);
+        if ((rc = pattern_lists(b, pid1, pos1, b->e1, tok2q, &b->qone)) == CGX_OK) rc = pattern_lists(b, pid2, pos2, b->e2, tok2q, &b->qtwo);
+    lists_done:
+        free(tok2q); free(pos1); free(pos2); free(pid1); free(pid2); free(g1); free(g2);
+        if (rc != CGX_OK) return rc;
     }
-    free(pid1); free(pid2); free(g1); free(g2);
     cgx__set_host_ms(ctx, "lists", now_ms() - t);
     t = now_ms();
     score_tables();
@@ -1401,11 +1404,11 @@ static int run_batch(cgx_ctx *ctx, const cgx_corpus *c, batch *b, const char *ou
             (rc = fetch_alloc(ctx, "pidx", (void **)&b->pidx, 4, NULL)) || (rc = fetch_alloc(ctx, "miss", (void **)&b->miss, 4, NULL))) return rc;
         if ((rc = build_lexicons(b)) != CGX_OK) return rc;
         float *fe = malloc(((size_t)b->ntask + 1) * 4), *ef = malloc(((size_t)b->ntask + 1) * 4);
-        if (!fe || !ef) return CGX_ERR_NOMEM;
-        if ((rc = cgx_lex_features(ctx, b->tasks, b->ntask, b->nl1, b->nl2, fe, ef)) != CGX_OK) return rc;
+        if (!fe || !ef) { free(fe); free(ef); return CGX_ERR_NOMEM; }
+        if ((rc = cgx_lex_features(ctx, b->tasks, b->ntask, b->nl1, b->nl2, fe, ef)) != CGX_OK) { free(fe); free(ef); return rc; }
         nl0 = b->nl0; nl1 = b->nl1; nl2 = b->nl2;
         b->L0 = calloc((size_t)nl0 + 1, sizeof *b->L0); b->L1 = calloc((size_t)nl1 + 1, sizeof *b->L1); b->L2 = calloc((size_t)nl2 + 1, sizeof *b->L2);
-        if (!b->L0 || !b->L1 || !b->L2) return CGX_ERR_NOMEM;
+        if (!b->L0 || !b->L1 || !b->L2) { free(fe); free(ef); return CGX_ERR_NOMEM; }   /* the L* that were allocated belong to the batch and go with it */
         for (uint32_t i = 0; i < b->ntask; i++) {
             int kind = i < nl1 ? 1 : i < nl1 + nl2 ? 2 : 0; uint32_t k = b->tasks[i].lexid;
             const lexent *e = kind == 1 ? &b->lex1[k] : kind == 2 ? &b->lex2[k] : &b->lex0[k];

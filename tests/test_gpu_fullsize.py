@@ -205,3 +205,29 @@ def test_bench_contract_small(tmp_path):
     assert d["config"]["grammar_files_written"] and "3 chunk(s)" in d["config"]["outdir_mode"]
     cb = d["cpu_baseline"]
     assert cb.get("kind") == "port" and cb["one_core"]["value"] > 0 and cb["all_cores"]["cores"] >= 1 and cb["value"] > 0
+
+
+@pytest.mark.parametrize("bcast", ["torch", "c"])
+def test_two_gpu_bench_broadcast_paths(bcast):
+    """N = 2 on real hardware (skipped on a one-GPU box): bench.py under torchrun, index broadcast through torch.distributed
+    and through the library's own cgx_broadcast_index on an RCCL communicator; both must report the same rule count per
+    step as a single rank processing the same global batch."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--config", "cfg4", "--pairs", "60000", "--queries", "2000", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
+    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, capture_output=True, text=True, timeout=900)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    one = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][0])
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                         os.path.join(root, "bench.py"), "--gpus", "2", "--bcast", bcast] + common, capture_output=True, text=True, timeout=900)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    two = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][0])
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["index"]["broadcast_bytes"] > 0
+    assert round(two["rules_per_s"] * two["ms_per_step"]) == round(one["rules_per_s"] * one["ms_per_step"])     # same rules per step
