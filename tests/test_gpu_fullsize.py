@@ -230,4 +230,5 @@ def test_two_gpu_bench_broadcast_paths(bcast):
     assert r2.returncode == 0, r2.stderr[-2000:]
     two = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][0])
     assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["index"]["broadcast_bytes"] > 0
-    assert round(two["rules_per_s"] * two["ms_per_step"]) == round(one["rules_per_s"] * one["ms_per_step"])     # same rules per step
+    a, b = two["rules_per_s"] * two["ms_per_step"], one["rules_per_s"] * one["ms_per_step"]                     # rules per step x 1000, from rounded fields
+    assert abs(a - b) <= 1e-4 * b and two["counts"]["grammar_lines"] > 0
