@@ -386,6 +386,7 @@ extern "C" int cgx_set_option(cgx_ctx *c, const char *name, int64_t value) {
     if (!strcmp(name, "device_format")) { c->device_format = value != 0; return CGX_OK; }
     if (!strcmp(name, "use_bigrams")) { c->ngram_max = value != 0 ? 5 : 1; return CGX_OK; }       /* round-1 name: 0 = every l >= 2 by binary search */
     if (!strcmp(name, "ngram_tables")) { if (value < 1 || value > 5) return CGX_ERR_ARG; c->ngram_max = (int)value; return CGX_OK; }
+    if (!strcmp(name, "gz_level")) { if (value < 0 || value > 9) return CGX_ERR_ARG; c->gz_level = (int)value; return CGX_OK; }
     if (!strcmp(name, "use_layouts")) { c->use_layouts = value != 0; return CGX_OK; }
     if (!strcmp(name, "count_probes")) { c->count_probes = value != 0; return CGX_OK; }
     if (!strcmp(name, "numa_pin")) { c->numa_pin = value != 0; return CGX_OK; }
@@ -412,6 +413,7 @@ extern "C" int64_t cgx__option(cgx_ctx *c, const char *name) {
     if (!strcmp(name, "sub_batch")) return c->sub_batch;
     if (!strcmp(name, "auto_batch_tokens")) return c->auto_batch_tokens;
     if (!strcmp(name, "numa_pin")) return (int64_t)c->numa_pin;
+    if (!strcmp(name, "gz_level")) return (int64_t)c->gz_level;
     return 0;
 }
 // "local_cpulist" of the GPU's PCI function (the CPUs of its NUMA node), or an empty string

@@ -33,6 +33,7 @@
 #include <fcntl.h>
 #include <sys/types.h>
 #include <sys/stat.h>
+#include <zlib.h>
 
 #define SAMPLER 300
 #define LONGEST_SRC 5
@@ -1018,7 +1019,7 @@ static int emit_range(sbuf *s, const batch *b, int kind, const cgx_lexent *lex, 
     return 0;
 }
 static int g_diag_format_only;
-typedef struct { const batch *b; const char *outdir; int32_t first; int32_t *next; uint64_t lines; int rc; } writejob;
+typedef struct { const batch *b; const char *outdir; int32_t first; int32_t *next; uint64_t lines; int rc, gz; } writejob;
 static void *write_worker(void *arg) {
     writejob *w = arg; const batch *b = w->b;
     const uint32_t G = b->g, D1 = b->d1, D2 = b->d2;
@@ -1043,6 +1044,14 @@ static void *write_worker(void *arg) {
         snprintf(fn, sizeof fn, "%s/grammar.%d.s", w->outdir, w->first + q);
         /* overwrite in place and cut to length: same bytes as fopen(fn,"w"), but an existing file keeps its pages */
         if (g_diag_format_only) continue;                   /* diagnostic (CGX_DIAG_FORMAT_ONLY=1): measure formatting without the file system */
+        if (w->gz) {
+            char mode[8]; snprintf(mode, sizeof mode, "wb%d", w->gz); strcat(fn, ".gz");
+            gzFile f = gzopen(fn, mode);
+            int bad_gz = !f || (s.n && gzwrite(f, s.p, (unsigned)s.n) != (int)s.n);
+            if (f && gzclose(f) != Z_OK) bad_gz = 1;
+            if (bad_gz) { w->rc = CGX_ERR_IO; break; }
+            continue;
+        }
         int fd = open(fn, O_WRONLY | O_CREAT, 0644);
         if (fd < 0) { w->rc = CGX_ERR_IO; break; }
         size_t off = 0; int bad_io = 0;
@@ -1055,11 +1064,12 @@ static void *write_worker(void *arg) {
     return NULL;
 }
 /* one file per query (PrintResults.c:434-446); queries are independent, so a pool of host threads formats them */
+static int g_gz_level_host;                               /* set by run_batch before the host formatter path runs */
 static int write_grammars(const batch *b, const char *outdir, int32_t first, uint64_t *lines) {
     int nt = nthreads_host(); if (nt > b->nq) nt = b->nq > 0 ? b->nq : 1;
     { const char *e = getenv("CGX_DIAG_FORMAT_ONLY"); g_diag_format_only = e && *e == '1'; }
     writejob jobs[64]; pthread_t th[64]; int32_t next = 0;
-    for (int t = 0; t < nt; t++) { jobs[t].b = b; jobs[t].outdir = outdir; jobs[t].first = first; jobs[t].next = &next; jobs[t].lines = 0; jobs[t].rc = CGX_OK; }
+    for (int t = 0; t < nt; t++) { jobs[t].b = b; jobs[t].outdir = outdir; jobs[t].first = first; jobs[t].next = &next; jobs[t].lines = 0; jobs[t].rc = CGX_OK; jobs[t].gz = g_gz_level_host; }
     for (int t = 1; t < nt; t++) if (pthread_create(&th[t], NULL, write_worker, &jobs[t])) return CGX_ERR_NOMEM;
     write_worker(&jobs[0]);
     for (int t = 1; t < nt; t++) pthread_join(th[t], NULL);
@@ -1161,9 +1171,22 @@ static void pin_to_device_node(cgx_ctx *ctx) {
 typedef struct {
     cgx_ctx *ctx; int tid, rc; int32_t nq, first; const char *outdir; int32_t *next_q;
     const char *utext; const uint64_t *qseg, *seg_off; const uint32_t *seg_len;
-    double file_ms; uint64_t calls;
+    double file_ms; uint64_t calls; int gz;
 } devjob;
+/* optional gzip output (option "gz_level" 1..9): grammar.<q>.s.gz, the same bytes through zlib's deflate */
+static int write_one_file_gz(devjob *w, int32_t q) {
+    char fn[4096], mode[8];
+    snprintf(fn, sizeof fn, "%s/grammar.%d.s.gz", w->outdir, w->first + q); snprintf(mode, sizeof mode, "wb%d", w->gz);
+    gzFile f = gzopen(fn, mode);
+    if (!f) return CGX_ERR_IO;
+    (void)gzbuffer(f, 1u << 18);
+    int bad = 0;
+    for (uint64_t s = w->qseg[q]; s < w->qseg[q + 1] && !bad; s++) if (gzwrite(f, w->utext + w->seg_off[s], w->seg_len[s]) != (int)w->seg_len[s]) bad = 1;
+    if (gzclose(f) != Z_OK) bad = 1;
+    return bad ? CGX_ERR_IO : CGX_OK;
+}
 static int write_one_file(devjob *w, int32_t q, struct iovec *iov) {
+    if (w->gz) return write_one_file_gz(w, q);
     char fn[4096];
     snprintf(fn, sizeof fn, "%s/grammar.%d.s", w->outdir, w->first + q);
     const uint64_t s0 = w->qseg[q], s1 = w->qseg[q + 1];
@@ -1225,7 +1248,7 @@ static int dev_write_files(pending *pw) {
     int nt = nthreads_host(); if (nt > MAX_WRITERS) nt = MAX_WRITERS; if (nt > nq) nt = nq > 0 ? nq : 1;
     devjob jobs[MAX_WRITERS]; pthread_t th[MAX_WRITERS]; int started[MAX_WRITERS]; int32_t next = 0; int rc = CGX_OK;
     for (int t = 0; t < nt; t++) { memset(&jobs[t], 0, sizeof jobs[t]); jobs[t].ctx = ctx; jobs[t].tid = t; jobs[t].nq = nq; jobs[t].first = pw->first; jobs[t].outdir = pw->outdir; jobs[t].next_q = &next;
-                                   jobs[t].utext = hb->utext; jobs[t].qseg = hb->qseg; jobs[t].seg_off = hb->segoff; jobs[t].seg_len = hb->seglen; jobs[t].rc = CGX_OK; }
+                                   jobs[t].utext = hb->utext; jobs[t].qseg = hb->qseg; jobs[t].seg_off = hb->segoff; jobs[t].seg_len = hb->seglen; jobs[t].rc = CGX_OK; jobs[t].gz = (int)cgx__option(ctx, "gz_level"); }
     started[0] = 1;
     for (int t = 1; t < nt; t++) started[t] = !pthread_create(&th[t], NULL, dev_write_worker, &jobs[t]);   /* a thread that cannot start: the others take its share */
     dev_write_worker(&jobs[0]);
@@ -1319,6 +1342,7 @@ static int run_batch(cgx_ctx *ctx, const cgx_corpus *c, batch *b, const char *ou
     }
     LAP("blocks");
     const int devfmt = outdir && cgx__option(ctx, "device_format");
+    g_gz_level_host = (int)cgx__option(ctx, "gz_level");
     if (devfmt && (rc = ensure_vocab(ctx, c)) != CGX_OK) return rc;
     LAP("qblocks");
     if ((rc = cgx_gappy_search(ctx)) != CGX_OK) return rc;

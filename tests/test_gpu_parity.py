@@ -98,6 +98,23 @@ def test_cli_is_a_drop_in(cgx, oracle_bin, fixtures_dir, tmp_path):
     assert r.returncode == 0 and "It is not valid" in r.stderr          # PrintResults.c:443-446
 
 
+@pytest.mark.parametrize("device_format", [1, 0])
+def test_gzip_output_holds_the_same_bytes(device_format, cgx, fixtures_dir, tmp_path):
+    """Option gz_level / strmatchcuda --gz N: grammar.<q>.s.gz, whose content is the golden file (both writers)."""
+    import gzip
+    import hashlib
+    fx = make_fixture("toy", fixtures_dir)
+    ex, corpus, n = run_product(cgx, fx, str(tmp_path / "z"), gz_level=6, device_format=device_format)
+    got = [hashlib.sha256(gzip.open(tmp_path / "z" / ("grammar.%d.s.gz" % q), "rb").read()).hexdigest() for q in range(7)]
+    assert got == META["toy"]["grammar"] and not os.path.exists(tmp_path / "z" / "grammar.0.s")
+    ex.close(); corpus.close()
+    if device_format:
+        out = tmp_path / "cli"; out.mkdir()
+        r = subprocess.run([os.path.join(ROOT, "bin", "strmatchcuda"), "--gz", "1"] + op.fixture_args(fx) + [str(out)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        assert [hashlib.sha256(gzip.open(out / ("grammar.%d.s.gz" % q), "rb").read()).hexdigest() for q in range(7)] == META["toy"]["grammar"]
+
+
 def test_cli_query_shards_union_is_the_whole(cgx, fixtures_dir, tmp_path):
     """strmatchcuda --shard i/n (one process per GPU; contiguous shards balanced by token count): the union of the shards'
     files is the single-process output."""
