@@ -352,6 +352,7 @@ def report(ex, args, cfg, L):
     stage, hoststage = L["stage"], L["hoststage"]
     free_b, total_b = torch.cuda.mem_get_info()                # after the timed steps: index + cached batch buffers + both text slots
     c = ex.counts(); w1, w2 = ex.stage_ms("look1_items"), ex.stage_ms("look2_items")     # of the last batch, before the extra lookup below resets them
+    nch = len(L["chunks"])
     # ---- the batched SA interval search, priced by the probes it executes (counted by the kernel itself, untimed launch) ----
     kms = float(np.mean(L["kernel_ms"])) if L["kernel_ms"] else 0.0
     a, b = L["chunks"][-1]
@@ -386,14 +387,26 @@ def report(ex, args, cfg, L):
                 "target_60pct_met": bool(ach / 8000.0 >= 0.6),
                 "note": "achieved = bytes of the probes the kernel executed (counted by the kernel) / its event-timed duration; a dependent-probe kernel over %d query tokens is latency-bound, not bandwidth-bound" % T}
     # ---- the kernels that take the most time per step, priced per corpus occurrence they visit ----
-    nch = len(L["chunks"])
     k1, k2 = stage["look1_kernel"] / steps / nch, stage["look2_kernel"] / steps / nch
     by_time = []
+    try:                                                        # counter traffic of the same kernels on the same workload (committed PMC passes) and the card's random-read rate
+        pk = json.load(open(os.path.join(ROOT, "profiles", "pmc_lookup_kernels.json")))
+        pc = pk["config"]
+        if (pc["pairs"], pc["queries"], pc["seed"], pc["vocab"]) != (cfg["pairs"], nq, args.seed, cfg["vocab"]) or nch != 1:
+            pk = None
+    except Exception:
+        pk = None
     for name, w, per, hits, ms in (("k_look1 (one-gap corpus lookups)", w1, ex.stage_ms("look1_bytes_per_item"), c["h1"], k1), ("k_look2 (two-gap corpus lookups)", w2, ex.stage_ms("look2_bytes_per_item"), c["h2"], k2)):
         if w > 0 and ms > 0 and per > 0:
             ab = w * per + hits * 8
-            by_time.append({"kernel": name, "bound": "hbm", "occurrences_per_launch": int(w), "bytes_per_occurrence": per, "algorithmic_bytes_per_launch": int(ab), "ms_per_launch": round(ms, 3),
-                            "achieved": round(ab / (ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ab / (ms * 1e-3) / 1e9 / 8000.0, 4)})
+            e = {"kernel": name, "bound": "hbm", "occurrences_per_launch": int(w), "bytes_per_occurrence": per, "algorithmic_bytes_per_launch": int(ab), "ms_per_launch": round(ms, 3),
+                 "achieved": round(ab / (ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ab / (ms * 1e-3) / 1e9 / 8000.0, 4), "traffic": None}
+            kk = pk["kernels"].get(name.split(" ")[0]) if pk else None
+            if kk:                                               # these kernels gather 64-byte sectors at random: the card's measured random-read rate is the bound that applies
+                tr = (kk["TCC_EA0_RDREQ_per_launch"] + kk["TCC_EA0_WRREQ_per_launch"]) * 64.0
+                e.update(traffic=int(tr), traffic_GBps=round(tr / (ms * 1e-3) / 1e9, 1), sectors_per_occurrence=round(kk["TCC_EA0_RDREQ_per_launch"] / w, 2),
+                         random_read_peak_GBps=pk["random_read_peak"]["GBps_64B"], frac_of_random_read_peak=round(kk["TCC_EA0_RDREQ_per_launch"] * 64.0 / (ms * 1e-3) / 1e9 / pk["random_read_peak"]["GBps_64B"], 3))
+            by_time.append(e)
     div = steps * 1.0
     out = {
         "config": {"workload": cfg["what"], "name": args.config, "sentence_pairs": cfg["pairs"], "source_tokens": n_src, "vocab": cfg["vocab"],
