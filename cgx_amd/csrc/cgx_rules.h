@@ -46,6 +46,9 @@ struct cgx_view {            // read-only index arrays (device pointers on the G
     const uint8_t *lr16;     // ltar/rtar in blocks of 16 target words: 16 L bytes, then their 16 R bytes -- the back-projection test
                              // of a <= 16-word span reads one 64..96-byte run instead of two runs in two arrays
 };
+// token / alignment word of corpus position k: from the interleaved array where it exists (one sector serves both), else from the two plain arrays
+CGX_HD int32_t cgx_tok(const cgx_view &v, int64_t k) { return v.tok8 ? v.tok8[k].tok : v.str[k]; }
+CGX_HD uint32_t cgx_rlpw(const cgx_view &v, int64_t k) { return v.tok8 ? v.tok8[k].rlp : v.rlp[k]; }
 // address of the dword holding the L bytes of target words w..w+3 (w a multiple of 4) in the lr16 layout; the R bytes sit 16 bytes further
 CGX_HD uint32_t cgx_lr16_off(uint32_t w) { return ((w >> 4) << 5) | (w & 15u); }
 
@@ -67,7 +70,7 @@ CGX_HD bool cgx_unaligned(uint32_t w) { return cgx_L(w) == 255 || cgx_R(w) == 25
 CGX_HD int cgx_sentence(const cgx_view &v, int k, uint32_t w, int *src0) {
     int prev_delim = k - cgx_P(w) - 1;
     *src0 = prev_delim + 1;
-    return prev_delim == -1 ? 0 : (int)v.rlp[prev_delim];
+    return prev_delim == -1 ? 0 : (int)cgx_rlpw(v, prev_delim);
 }
 
 // Does the target span [ts,te] project back exactly onto source [s_chk,e_chk]?  Unaligned
@@ -114,7 +117,7 @@ CGX_HD bool cgx_tight(const cgx_view &v, int ts, int te, int s_chk, int e_chk, i
 CGX_HD bool cgx_edge_span(const cgx_view &v, uint32_t start, uint32_t ender, cgx_span *sp, int *src0, int *tb) {
     sp->reset(); *src0 = 0; *tb = -1;
     for (uint32_t k = start; k <= ender; k++) {
-        uint32_t w = v.rlp[k];
+        uint32_t w = cgx_rlpw(v, k);
         bool un = cgx_unaligned(w);
         if (un && (k == start || k == ender)) return false;
         if (un) continue;
@@ -138,7 +141,7 @@ CGX_HD bool cgx_gap_ok(const cgx_view &v, uint32_t start, uint32_t ender) {
 CGX_HD int cgx_span_code(const cgx_view &v, uint32_t start, uint32_t ender, uint32_t *ts, uint32_t *te) {
     int lo = 255, hi = 0, src0 = 0, tb = -1, wrong = 0;
     for (uint32_t k = start; k <= ender; k++) {
-        uint32_t w = v.rlp[k];
+        uint32_t w = cgx_rlpw(v, k);
         bool un = cgx_unaligned(w);
         if (un && (k == start || k == ender)) {
             if (start == ender && wrong == 0) wrong = 4;
@@ -188,7 +191,7 @@ CGX_HD bool cgx_extract_contig(const cgx_view &v, int32_t bnum, int32_t G, int l
     cgx_span body; body.reset();
     bool abX = true, Xab = true, XabX = true, ab = true, XabOpen = true, abXOpen = true;
     for (int k = cur; k <= ender; k++) {
-        uint32_t w = v.rlp[k];
+        uint32_t w = cgx_rlpw(v, k);
         if (k == cur) tb = cgx_sentence(v, k, w, &src0);
         if (cgx_unaligned(w)) {
             if (k == cur || k == ender) { ab = false; if (k == cur) abXOpen = false; else XabOpen = false; }
@@ -204,9 +207,9 @@ CGX_HD bool cgx_extract_contig(const cgx_view &v, int32_t bnum, int32_t G, int l
     int leftLen = 0, rightLen = 0;                 // XabCount / abXCount: widest tight gap seen so far on each side
     uint32_t gs = 0, ge = 0, ts = 0, te = 0;
     for (int i = 1; lm + i <= CGX_MAX_SPAN && (abXOpen || XabOpen || XabX); i++) {
-        if (Xab && cur - i >= 0 && v.str[cur - i] >= 2) {                // widen the left gap by one token
+        if (Xab && cur - i >= 0 && cgx_tok(v, cur - i) >= 2) {                // widen the left gap by one token
             bool next = true;
-            uint32_t w = v.rlp[cur - i];
+            uint32_t w = cgx_rlpw(v, cur - i);
             if (cgx_unaligned(w)) { next = false; if (i == 1) { Xab = false; XabX = false; } }
             else left.add(cgx_L(w), cgx_R(w));
             if (next && left.empty()) return true;
@@ -226,9 +229,9 @@ CGX_HD bool cgx_extract_contig(const cgx_view &v, int32_t bnum, int32_t G, int l
             }
         } else Xab = false;
 
-        if (abX && v.str[ender + i] >= 2) {                              // widen the right gap by one token
+        if (abX && cgx_tok(v, ender + i) >= 2) {                              // widen the right gap by one token
             bool next = true;
-            uint32_t w = v.rlp[ender + i];
+            uint32_t w = cgx_rlpw(v, ender + i);
             if (cgx_unaligned(w)) { next = false; if (i == 1) { abX = false; XabX = false; } }
             else right.add(cgx_L(w), cgx_R(w));
             if (next && right.empty()) return true;
@@ -254,7 +257,7 @@ CGX_HD bool cgx_extract_contig(const cgx_view &v, int32_t bnum, int32_t G, int l
                 for (int ic = 1; XabX && ic <= rightLen; ic++) {
                     bool next = true;
                     if (ic + leftLen + lm <= CGX_MAX_SPAN) {
-                        uint32_t w = v.rlp[ender + ic];
+                        uint32_t w = cgx_rlpw(v, ender + ic);
                         if (cgx_unaligned(w)) { next = false; if (i == 1) return true; }
                         else other.add(cgx_L(w), cgx_R(w));
                     } else { next = false; ic = rightLen + 1; }
@@ -281,7 +284,7 @@ CGX_HD bool cgx_extract_contig(const cgx_view &v, int32_t bnum, int32_t G, int l
                 for (int ic = 1; XabX && ic <= leftLen; ic++) {
                     bool next = true;
                     if (ic + rightLen + lm <= CGX_MAX_SPAN) {
-                        uint32_t w = v.rlp[cur - ic];
+                        uint32_t w = cgx_rlpw(v, cur - ic);
                         if (cgx_unaligned(w)) { next = false; if (i == 1) return true; }
                         else other.add(cgx_L(w), cgx_R(w));
                     } else { ic = leftLen + 1; next = false; }
@@ -345,9 +348,9 @@ CGX_HD bool cgx_extract_onegap(const cgx_view &v, int32_t id, int32_t D1, int a_
     if (a_len + b_len + 2 > CGX_MAX_SYMBOLS) return false;
     cgx_span L, R; L.reset(); R.reset();
     for (int i = 1; firstEnd + 1 + i <= CGX_MAX_SPAN && (left || right); i++) {
-        if (left && (int)(cur - (uint32_t)i) >= 0 && v.str[cur - i] >= 2) {
+        if (left && (int)(cur - (uint32_t)i) >= 0 && cgx_tok(v, cur - i) >= 2) {
             bool next = true;
-            uint32_t w = v.rlp[cur - i];
+            uint32_t w = cgx_rlpw(v, cur - i);
             if (cgx_unaligned(w)) { next = false; if (i == 1) left = false; }
             else L.add(cgx_L(w), cgx_R(w));
             if (next && L.empty()) return true;
@@ -362,9 +365,9 @@ CGX_HD bool cgx_extract_onegap(const cgx_view &v, int32_t id, int32_t D1, int a_
             }
             if (next) { cgx_put2(o_XaXb, id, ts, te, gs, ge, g0s, g0e); left = false; }
         } else left = false;
-        if (right && v.str[ender + i] >= 2) {
+        if (right && cgx_tok(v, ender + i) >= 2) {
             bool next = true;
-            uint32_t w = v.rlp[ender + i];
+            uint32_t w = cgx_rlpw(v, ender + i);
             if (cgx_unaligned(w)) { next = false; if (i == 1) right = false; }
             else R.add(cgx_L(w), cgx_R(w));
             if (next && R.empty()) return true;
