@@ -17,8 +17,9 @@ split over the ranks: strong scaling), cfg5 (1e8 source tokens, 1 M queries spli
 
 Host memory is bounded whatever --steps/--warmup say: the grammar files of a step go into ONE
 spool directory per rank that every step rewrites in place (sized against the memory this
-process may really use: MemAvailable and the cgroup limit, not the tmpfs mount size); when one
-step's files do not fit, the step is cut into chunks that reuse the same file slots.
+process may really use: MemAvailable and the cgroup limit, not the tmpfs mount size, and counting
+the writer's page-locked buffers as well); when one step's files do not fit, the step is cut into
+chunks that reuse the same file slots.
 """
 import argparse
 import json
@@ -123,7 +124,7 @@ def main():
     ap.add_argument("--queries", type=int, default=None, help="query sentences per step: per GPU with --scaling weak, in all with --scaling strong")
     ap.add_argument("--scaling", choices=("weak", "strong"), default=None, help="weak: every rank gets --queries per step; strong: --queries are split over the ranks")
     ap.add_argument("--outdir", default=None, help="parent of the spool directory (default: /dev/shm, else $TMPDIR)")
-    ap.add_argument("--spool-fraction", type=float, default=0.30, help="share of the usable host memory the grammar files of all ranks may take")
+    ap.add_argument("--mem-fraction", type=float, default=0.80, help="share of the usable host memory (MemAvailable, cgroup headroom) this job may take: per rank a fixed part, the spool files and the writer's page-locked buffers (1.6x the spool)")
     ap.add_argument("--chunk-queries", type=int, default=0, help="queries per spool chunk (0: as many as fit the spool budget, at most one step)")
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--cpu-pairs", type=int, default=200000, help="sentence pairs of the CPU baseline's sample corpus")
@@ -263,8 +264,10 @@ def main():
             shutil.rmtree(share, ignore_errors=True)            # every rank holds its own copy now
 
     # ---- spool: one directory per rank, rewritten in place; sized against the memory really available ----
+    # per rank: ~12 GB fixed (host corpus copy, torch, staging) + the spool (one chunk's files) + the writer's two page-locked
+    # buffer sets (unique text of a chunk x 1.25 x 2 = about 1.6x the chunk's files)
     budget, mem_avail, mem_cgroup = memory_budget()
-    per_rank = args.spool_fraction * budget / max(local_world, 1)
+    per_rank = max(0.0, args.mem_fraction * budget / max(local_world, 1) - 12e9) / 2.6
     cands = [args.outdir] if args.outdir else [d for d in ("/dev/shm", tempfile.gettempdir()) if os.path.isdir(d) and os.access(d, os.W_OK)]
     base = None
     for d in cands:

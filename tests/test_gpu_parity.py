@@ -344,6 +344,23 @@ def test_async_writer_gives_the_same_files(cgx, fixtures_dir, tmp_path):
     ex.close(); corpus.close()
 
 
+def test_writer_errors_surface_and_the_context_survives(cgx, fixtures_dir, tmp_path):
+    """A batch whose output directory does not exist: the background writer's I/O error comes back from cgx_flush (or from
+    the call itself in synchronous mode), nothing hangs, and the same context then writes the golden files."""
+    fx = make_fixture("toy", fixtures_dir); files = op.fixture_args(fx)
+    corpus = cgx.Corpus.load(files[0], files[2], files[3], files[4])
+    for async_write in (1, 0):
+        ex = cgx.Extractor(0); ex.set_option("async_write", async_write); ex.upload_corpus(corpus)
+        with pytest.raises(cgx.CgxError):
+            ex.extract_grammars(corpus, files[1], str(tmp_path / "does" / "not" / "exist"))
+            ex.flush()
+        out = tmp_path / ("ok%d" % async_write); out.mkdir()
+        ex.extract_grammars(corpus, files[1], str(out)); ex.flush()
+        assert op.sha_dir(str(out), 7) == META["toy"]["grammar"]
+        ex.close()
+    corpus.close()
+
+
 _EXTRA = [tuple(int(x) for x in os.environ["CGX_BIG_PARITY"].split(","))] if os.environ.get("CGX_BIG_PARITY") else []   # e.g. 1000000,200000,60 (minutes of oracle time)
 
 
