@@ -370,12 +370,13 @@ def report(ex, args, cfg, L):
     # 16 B per l-gram slot, 8 B per search probe (SA entry + corpus token), 44 B of results per token
     exec_bytes = T * (4 + 12 + 44) + 4 * pb + 16 * ps + 8 * pq
     sv_bytes, lookups = survey_bytes(n_src, lm)
-    traffic = None
+    traffic = None; requests = None; rr16 = None
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_k_sa_lookup.json")))
         pc = pmc["config"]
         if (pc["pairs"], pc["queries"], pc["seed"], pc["vocab"]) == (cfg["pairs"], nq, args.seed, cfg["vocab"]) and len(L["chunks"]) == 1:
-            traffic = int(pmc["traffic_bytes"])
+            traffic = int(pmc["traffic_bytes"]); requests = float(pmc["TCC_EA0_RDREQ_per_launch"])
+            rr16 = json.load(open(os.path.join(ROOT, "profiles", "pmc_lookup_kernels.json")))["random_read_peak"]["reads_per_s_16B"]
     except Exception:
         traffic = None
     ach = exec_bytes / (kms_last * 1e-3) / 1e9 if kms_last > 0 else 0.0
@@ -387,8 +388,10 @@ def report(ex, args, cfg, L):
                 "traffic_GBps": (round(traffic / (kms_last * 1e-3) / 1e9, 1) if traffic and kms_last > 0 else None),
                 "survey_8d_formula": {"bytes": int(sv_bytes), "GBps": round(sv_bytes / (kms_last * 1e-3) / 1e9, 1) if kms_last > 0 else None,
                                       "note": "what the reference's full-depth binary search would touch for the same lookups (SURVEY 8d); not a fraction of anything this kernel moves"},
+                "random_read_requests_per_launch": requests, "random_read_peak_per_s_16B": rr16,
+                "frac_of_random_read_peak": (round(requests / (kms_last * 1e-3) / rr16, 3) if requests and rr16 and kms_last > 0 else None),
                 "target_60pct_met": bool(ach / 8000.0 >= 0.6),
-                "note": "achieved = bytes of the probes the kernel executed (counted by the kernel) / its event-timed duration; a dependent-probe kernel over %d query tokens is latency-bound, not bandwidth-bound" % T}
+                "note": "achieved = bytes of the probes the kernel executed (counted by the kernel) / its event-timed duration, against the 8 TB/s streaming peak (target 0.6: see target_60pct_met); the probes are scattered 16-byte reads, so the bound that applies is the card's random-read request rate (tools/micro/gather_bw): frac_of_random_read_peak"}
     # ---- the kernels that take the most time per step, priced per corpus occurrence they visit ----
     k1, k2 = stage["look1_kernel"] / steps / nch, stage["look2_kernel"] / steps / nch
     by_time = []
