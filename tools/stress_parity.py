@@ -24,6 +24,7 @@ SHAPES = [  # pairs, vocab, queries, seed, lo, hi, options
     (15000, 300, 100, 107, 2, 12, {"device_format": 0}),      # short sentences, host formatter
     (2500, 101, 40, 108, 20, 80, {"use_bigrams": 0}),         # long sentences, hardly more than the 100 frequent tokens
     (5000, 200, 90, 109, 3, 20, {"auto_batch_tokens": 64, "async_write": 1}),   # automatic internal batches of a few queries each
+    (9000, 130, 80, 110, 4, 30, {"ngram_tables": 3, "use_layouts": 0}),         # l = 4, 5 by nested search; plain ltar / rtar tables in the tightness test
 ]
 
 
@@ -75,7 +76,7 @@ def main():
         import random
         r = random.Random(args.seed); shapes = []
         menu = {"pool_cap": [1, 7, 64], "look_rec_cap": [0, 1, 5, 40], "sub_batch": [1, 13, 50], "async_write": [1], "chunk_items": [1024, 4096, 1 << 16],
-                "use_lex_hash": [0], "append_guess_milli": [1, 300], "append_slack": [0, 5], "wide_hits2": [1], "device_format": [0], "use_bigrams": [0], "k1_limit": [128], "auto_batch_tokens": [40, 300]}
+                "use_lex_hash": [0], "append_guess_milli": [1, 300], "append_slack": [0, 5], "wide_hits2": [1], "device_format": [0], "use_bigrams": [0], "ngram_tables": [1, 2, 3, 4], "use_layouts": [0], "k1_limit": [128], "auto_batch_tokens": [40, 300]}
         for i in range(args.fuzz):
             lo = r.choice([1, 2, 4, 8, 15]); hi = lo + r.choice([3, 10, 25, 60])
             opts = {k: r.choice(v) for k, v in menu.items() if r.random() < 0.25}
