@@ -1409,6 +1409,10 @@ static int run_batch(cgx_ctx *ctx, const cgx_corpus *c, batch *b, const char *ou
     uint32_t nl0 = 0, nl1 = 0, nl2 = 0;
     if (!exact_host) {
         int64_t by1 = 0, by2 = 0, by0 = 0;
+        /* the lexicon lines go to one of TWO page-locked arenas that alternate between batches, and the host formatter of a
+         * batch reads its arena until its files are written: the batch before the previous one must be finished before its
+         * arena is filled again (up to two batches can be in flight) */
+        { wstate *ws = cgx__get_host_state(ctx); while (ws && ws->n > 1) { int r = join_oldest(ctx, ws); if (r != CGX_OK) return r; } }
         cgx_pinned_next_batch(ctx);
         if (cgx_fetch_pinned(ctx, "lex2", (void **)&b->L2, &by2) == CGX_OK && cgx_fetch_pinned(ctx, "lex1", (void **)&b->L1, &by1) == CGX_OK &&
             cgx_fetch_pinned(ctx, "lex0", (void **)&b->L0, &by0) == CGX_OK) {

@@ -25,6 +25,8 @@ SHAPES = [  # pairs, vocab, queries, seed, lo, hi, options
     (2500, 101, 40, 108, 20, 80, {"use_bigrams": 0}),         # long sentences, hardly more than the 100 frequent tokens
     (5000, 200, 90, 109, 3, 20, {"auto_batch_tokens": 64, "async_write": 1}),   # automatic internal batches of a few queries each
     (9000, 130, 80, 110, 4, 30, {"ngram_tables": 3, "use_layouts": 0}),         # l = 4, 5 by nested search; plain ltar / rtar tables in the tightness test
+    (25000, 101, 130, 41001, 15, 18, {"async_write": 1, "device_format": 0, "auto_batch_tokens": 40, "pool_cap": 64, "look_rec_cap": 5}),   # host formatter, many tiny batches in flight:
+                                                                                # caught the page-locked lexicon arena of batch k being refilled by batch k+2 while k was still being written
 ]
 
 
