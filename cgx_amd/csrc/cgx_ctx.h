@@ -38,7 +38,6 @@ struct cgx_ctx {
     int32_t *d_tokstart = nullptr; int8_t *d_tokrank = nullptr; int32_t *d_freq = nullptr;
     uint32_t *d_pidx = nullptr; int32_t *d_miss = nullptr; uint32_t *d_phit_start = nullptr; uint8_t *d_phit_len = nullptr;
     cgx_ngslot *d_ng[4] = {nullptr, nullptr, nullptr, nullptr}; uint32_t ng_cap[4] = {0, 0, 0, 0}; unsigned ng_shift[4] = {0, 0, 0, 0};   // l-gram (l = 2..5) -> SA interval
-    int64_t look_tile_big = 0, look_big_work = 32768, look_drain_every = 1;   // tiling / pool-drain policy of the one-gap lookup (tuning hooks)
     int gz_level = 0;                   // 1..9: grammar.<q>.s.gz through zlib instead of plain files
     bool use_layouts = true;            // test hook: 0 = window kernels read the plain str / rlp / ltar / rtar arrays (round-1 access pattern)
     int ngram_max = 5;                  // longest phrase answered from the l-gram tables (1: none, every l >= 2 by binary search)

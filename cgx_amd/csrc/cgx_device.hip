@@ -386,9 +386,6 @@ extern "C" int cgx_set_option(cgx_ctx *c, const char *name, int64_t value) {
     if (!strcmp(name, "device_format")) { c->device_format = value != 0; return CGX_OK; }
     if (!strcmp(name, "use_bigrams")) { c->ngram_max = value != 0 ? 5 : 1; return CGX_OK; }       /* round-1 name: 0 = every l >= 2 by binary search */
     if (!strcmp(name, "ngram_tables")) { if (value < 1 || value > 5) return CGX_ERR_ARG; c->ngram_max = (int)value; return CGX_OK; }
-    if (!strcmp(name, "look_tile_big")) { if (value < 0 || value % 256 || value > 65536) return CGX_ERR_ARG; c->look_tile_big = value; return CGX_OK; }
-    if (!strcmp(name, "look_big_work")) { if (value < 1) return CGX_ERR_ARG; c->look_big_work = value; return CGX_OK; }
-    if (!strcmp(name, "look_drain_every")) { if (value < 1) return CGX_ERR_ARG; c->look_drain_every = value; return CGX_OK; }
     if (!strcmp(name, "gz_level")) { if (value < 0 || value > 9) return CGX_ERR_ARG; c->gz_level = (int)value; return CGX_OK; }
     if (!strcmp(name, "use_layouts")) { c->use_layouts = value != 0; return CGX_OK; }
     if (!strcmp(name, "count_probes")) { c->count_probes = value != 0; return CGX_OK; }
