@@ -278,6 +278,50 @@ class Extractor:
         self._chk(self.lib.cgx_lex_features(self.h, _ptr(tasks), len(tasks), n_onegap, n_twogap, _ptr(fe), _ptr(ef)), "cgx_lex_features")
         return fe, ef
 
+    # ---- grammar text on the device (what cgx_extract_grammars* does internally) ----
+    def upload_vocab(self, swords, twords):
+        """swords / twords: spelling (bytes) of every source / target id, b"" for ids without one"""
+        def pool(words):
+            off = np.zeros(len(words) + 1, np.uint32); off[1:] = np.cumsum([len(w) for w in words])
+            return b"".join(words), off
+        sp, so = pool(swords); tp, to = pool(twords)
+        self.lib.cgx_upload_vocab.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint32, C.c_char_p, C.c_void_p, C.c_uint32]
+        self._chk(self.lib.cgx_upload_vocab(self.h, sp, _ptr(so), len(swords), tp, _ptr(to), len(twords)), "cgx_upload_vocab")
+
+    def upload_score_tables(self, aa, bb, fs):
+        a = [_c(aa, np.float32), _c(bb, np.float32), _c(fs, np.float32)]
+        self.lib.cgx_upload_score_tables.argtypes = [C.c_void_p] * 4
+        self._chk(self.lib.cgx_upload_score_tables(self.h, _ptr(a[0]), _ptr(a[1]), _ptr(a[2])), "cgx_upload_score_tables")
+
+    def format(self):
+        """-> (bytes of all grammar files together, rule lines, text slot)"""
+        nb = C.c_uint64(); nl = C.c_uint64(); slot = C.c_int()
+        self.lib.cgx_format.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
+        self._chk(self.lib.cgx_format(self.h, C.byref(nb), C.byref(nl), C.byref(slot)), "cgx_format")
+        return int(nb.value), int(nl.value), int(slot.value)
+
+    def text(self, slot, nq):
+        """The unique text of the slot and the piece lists: (text bytes, qseg u64[nq+1], seg_off u64[nseg], seg_len u32[nseg], qtext u64[nq+1])."""
+        ub = C.c_uint64(); ns = C.c_uint64(); fb = C.c_uint64()
+        self.lib.cgx_text_info.argtypes = [C.c_void_p, C.c_int] + [C.POINTER(C.c_uint64)] * 3
+        self._chk(self.lib.cgx_text_info(self.h, slot, C.byref(ub), C.byref(ns), C.byref(fb)), "cgx_text_info")
+        qseg = np.zeros(nq + 1, np.uint64); so = np.zeros(max(int(ns.value), 1), np.uint64); sl = np.zeros(max(int(ns.value), 1), np.uint32); qtext = np.zeros(nq + 1, np.uint64)
+        self.lib.cgx_text_segments.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        self._chk(self.lib.cgx_text_segments(self.h, slot, _ptr(qseg), _ptr(so), _ptr(sl)), "cgx_text_segments")
+        self.lib.cgx_text_offsets.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        self._chk(self.lib.cgx_text_offsets(self.h, slot, _ptr(qtext)), "cgx_text_offsets")
+        self.lib.cgx_pinned_alloc.restype = C.c_void_p; self.lib.cgx_pinned_alloc.argtypes = [C.c_size_t]; self.lib.cgx_pinned_free.argtypes = [C.c_void_p]
+        n = int(ub.value); buf = self.lib.cgx_pinned_alloc(n + 64)
+        if not buf:
+            raise CgxError("cgx_pinned_alloc failed")
+        self.lib.cgx_text_read.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int]
+        try:
+            self._chk(self.lib.cgx_text_read(self.h, slot, 0, n, buf, 0), "cgx_text_read")
+            text = C.string_at(buf, n)
+        finally:
+            self.lib.cgx_pinned_free(buf)
+        return text, qseg, so[:int(ns.value)], sl[:int(ns.value)], qtext
+
     def fetch(self, name):
         nb = self.lib.cgx_fetch(self.h, name.encode(), None, 0)
         if nb < 0:

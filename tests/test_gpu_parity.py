@@ -115,6 +115,41 @@ def test_gzip_output_holds_the_same_bytes(device_format, cgx, fixtures_dir, tmp_
         assert [hashlib.sha256(gzip.open(out / ("grammar.%d.s.gz" % q), "rb").read()).hexdigest() for q in range(7)] == META["toy"]["grammar"]
 
 
+def test_staged_text_api_reassembles_the_files(cgx, oracle_bin, fixtures_dir, tmp_path):
+    """The writer's public interface, used the way INTEGRATION.md tells a binder to: stage calls up to cgx_lexicon, then
+    cgx_upload_vocab / cgx_upload_score_tables / cgx_format, the unique text and the piece lists (cgx_text_info,
+    cgx_text_segments, cgx_text_offsets, cgx_text_read) -- files reassembled here in Python are the golden files."""
+    import ctypes as C
+    import hashlib
+    fx = make_fixture("toy", fixtures_dir); dump = str(tmp_path / "d.bin")
+    op.run_oracle(oracle_bin, fx, str(tmp_path / "o"), dump)
+    d = op.read_dump(dump); h = d["hdr"]; nq = h["nq"]
+    ex = cgx.Extractor(0)
+    ex.upload_index(d["str"][:h["n"]], d["rlp"], d["tstr"][:h["nt"]], d["ltar"], d["rtar"], d["lexk"], d["lexv"])
+    ex.build_sa(); ex.precompute(); ex.upload_queries(d["qoff"][:-1], d["qtok"]); ex.sa_lookup(); ex.make_blocks(); ex.gappy_search(); ex.extract(); ex.lexicon()
+    ex.upload_vocab(d["svocab"].split(b"\0")[:-1], d["tvocab"].split(b"\0")[:-1])
+    libm = C.CDLL("libm.so.6"); libm.log10f.restype = C.c_float; libm.log10f.argtypes = [C.c_float]; libm.log10.restype = C.c_double; libm.log10.argtypes = [C.c_double]
+    N = 302                                                             # ExtractPair.c:652-656 with the host libm, as the library's own tables
+    aa = np.zeros((N, N), np.float32); bb = np.zeros(N, np.float32); fs = np.zeros(N, np.float32)
+    for p in range(N):
+        bb[p] = fs[p] = np.float32(libm.log10(float(1 + p)))
+        for f in range(1, N):
+            aa[p, f] = -libm.log10f(np.float32(np.float32(p) / np.float32(f)))
+    ex.upload_score_tables(aa, bb, fs)
+    nbytes, nlines, slot = ex.format()
+    text, qseg, seg_off, seg_len, qtext = ex.text(slot, nq)
+    assert int(qtext[nq]) == nbytes and int(qseg[nq]) == len(seg_off)
+    got = []
+    for q in range(nq):
+        body = b"".join(text[int(seg_off[s]):int(seg_off[s]) + int(seg_len[s])] for s in range(int(qseg[q]), int(qseg[q + 1])))
+        assert len(body) == int(qtext[q + 1] - qtext[q])
+        got.append(hashlib.sha256(body).hexdigest())
+    assert got == META["toy"]["grammar"]
+    assert nlines == sum(sum(1 for _ in open(tmp_path / "o" / ("grammar.%d.s" % q), "rb")) for q in range(nq))
+    assert len(text) < nbytes                                            # shared lines are stored once
+    ex.close()
+
+
 def test_cli_query_shards_union_is_the_whole(cgx, fixtures_dir, tmp_path):
     """strmatchcuda --shard i/n (one process per GPU; contiguous shards balanced by token count): the union of the shards'
     files is the single-process output."""
