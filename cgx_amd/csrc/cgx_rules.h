@@ -328,6 +328,10 @@ CGX_HD bool cgx_extract_twogap(const cgx_view &v, int32_t id, int a_len, int b_l
     return false;
 }
 
+// One sampled occurrence of aXb, second half: given the gap's target span [g0s,g0e], the whole phrase's span [ts,te] and its
+// consistency code, emits aXb, then the first consistent XaXb and aXbX (widening one token at a time on either side).
+CGX_HD bool cgx_onegap_tail(const cgx_view &v, int32_t id, int32_t D1, int a_len, int b_len, uint32_t cur, int firstEnd, uint32_t ender,
+                            int src0, int tb, uint32_t g0s, uint32_t g0e, uint32_t ts, uint32_t te, int code, cgx_r1 *o_aXb, cgx_r2 *o_XaXb, cgx_r2 *o_aXbX);
 // One sampled occurrence of aXb: emits aXb, then the first consistent XaXb and aXbX.
 CGX_HD bool cgx_extract_onegap(const cgx_view &v, int32_t id, int32_t D1, int a_len, int b_len,
                                uint32_t cur, int firstEnd, cgx_r1 *o_aXb, cgx_r2 *o_XaXb, cgx_r2 *o_aXbX) {
@@ -340,6 +344,10 @@ CGX_HD bool cgx_extract_onegap(const cgx_view &v, int32_t id, int32_t D1, int a_
     const uint32_t g0s = (uint32_t)(gap.lo + tb), g0e = (uint32_t)(gap.hi + tb);
     uint32_t ts, te;
     int code = cgx_span_code(v, cur, ender, &ts, &te);
+    return cgx_onegap_tail(v, id, D1, a_len, b_len, cur, firstEnd, ender, src0, tb, g0s, g0e, ts, te, code, o_aXb, o_XaXb, o_aXbX);
+}
+CGX_HD bool cgx_onegap_tail(const cgx_view &v, int32_t id, int32_t D1, int a_len, int b_len, uint32_t cur, int firstEnd, uint32_t ender,
+                            int src0, int tb, uint32_t g0s, uint32_t g0e, uint32_t ts, uint32_t te, int code, cgx_r1 *o_aXb, cgx_r2 *o_XaXb, cgx_r2 *o_aXbX) {
     // whole-phrase span in sentence coordinates, truncated to a byte like the reference
     int bodyLo = (int)(uint8_t)(ts - (uint32_t)tb), bodyHi = (int)(uint8_t)(te - (uint32_t)tb);
     bool left = !(code == 3 || code == 4), right = !(code == 2 || code == 4);
