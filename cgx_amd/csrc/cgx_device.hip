@@ -215,7 +215,7 @@ __device__ __forceinline__ uint32_t wave_append(unsigned int *counter, bool vali
 // A record that finds the pool full is appended directly.  The global counter keeps counting
 // past `cap`, so the host learns the exact size needed when a launch overflows and can rerun
 // it; nothing is written beyond `cap`.
-#define POOL_N 2048
+#define POOL_N 1024
 struct appender { uint64_t *out; uint64_t cap; unsigned long long *total; uint32_t pool_n; };   // pool_n <= POOL_N: pool entries in use (test hook)
 struct pool_t { uint64_t buf[POOL_N]; unsigned int n, snap; unsigned long long base; };
 __device__ __forceinline__ uint64_t lanes_reserve(unsigned long long *ctr) {        // callable from divergent code
