@@ -17,6 +17,7 @@ for grp in \
   "TCP_TCC_READ_REQ_LATENCY_sum TCP_TOTAL_ACCESSES_sum TCP_GATE_EN1_sum TCP_TCR_TCP_STALL_CYCLES_sum" \
   "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
+  if [ -n "$PMC_ONLY" ] && ! echo " $PMC_ONLY " | grep -q " $i "; then continue; fi     # PMC_ONLY="1 2": just those passes
   timeout -k 10 280 rocprofv3 --pmc $grp --kernel-include-regex "$KER" --output-format csv -d "$OUT/p$i" -- python3 "$REPO/bench.py" --no-write --no-cpu-baseline --steps 1 --warmup 0 "$@" > "$OUT/p$i.log" 2>&1 || echo "pass $i failed" >> "$OUT/fail.txt"
   f=$(find "$OUT/p$i" -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python3 "$REPO/tools/pmc_sum.py" "$f" > "$OUT/p$i.sum.txt"
