@@ -408,10 +408,11 @@ def report(ex, args, cfg, L):
             e = {"kernel": name, "bound": "hbm", "occurrences_per_launch": int(w), "bytes_per_occurrence": per, "algorithmic_bytes_per_launch": int(ab), "ms_per_launch": round(ms, 3),
                  "achieved": round(ab / (ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ab / (ms * 1e-3) / 1e9 / 8000.0, 4), "traffic": None}
             kk = pk["kernels"].get(name.split(" ")[0]) if pk else None
-            if kk:                                               # these kernels gather 64-byte sectors at random: the card's measured random-read rate is the bound that applies
-                tr = (kk["TCC_EA0_RDREQ_per_launch"] + kk["TCC_EA0_WRREQ_per_launch"]) * 64.0
-                e.update(traffic=int(tr), traffic_GBps=round(tr / (ms * 1e-3) / 1e9, 1), sectors_per_occurrence=round(kk["TCC_EA0_RDREQ_per_launch"] / w, 2),
-                         random_read_peak_GBps=pk["random_read_peak"]["GBps_64B"], frac_of_random_read_peak=round(kk["TCC_EA0_RDREQ_per_launch"] * 64.0 / (ms * 1e-3) / 1e9 / pk["random_read_peak"]["GBps_64B"], 3))
+            if kk:                                               # these kernels gather one unaligned 128-byte window per occurrence at random: the card's measured rate of random 128-byte runs is the bound that applies
+                tr = (kk["TCC_EA0_RDREQ_per_batch"] + kk["TCC_EA0_WRREQ_per_batch"]) * 64.0      # counters summed over the batch's launches of this kernel (tile chunks)
+                e.update(traffic=int(tr), traffic_GBps=round(tr / (ms * 1e-3) / 1e9, 1), sectors_per_occurrence=round(kk["TCC_EA0_RDREQ_per_batch"] / w, 2),
+                         windows_per_s=round(w / (ms * 1e-3), 1), random_128B_runs_per_s_peak=pk["random_read_peak"]["runs_per_s_128B"],
+                         frac_of_random_window_peak=round(w / (ms * 1e-3) / pk["random_read_peak"]["runs_per_s_128B"], 3))
             by_time.append(e)
     div = steps * 1.0
     out = {

@@ -18,6 +18,7 @@ struct cgx_ctx {
     int k1_limit = 128;                 // K1 launches 128 threads per query sentence (SuffixArray.cu:1374-1378)
     bool async_write = false;           // grammar files of batch k are written by host threads while the GPU runs batch k+1 (cgx_flush joins)
     void *host_state = nullptr;         // owned by the host TU
+    unsigned lex_hash_bits = 0;         // test hook: hash bits in the lexicon grouping key (0: all that fit beside the id)
     bool force_host_lexicon = false;    // test hook: take the exact host lexicon path
     uint64_t chunk_items = 1ull << 26;  // work items per lookup launch
     uint64_t append_slack = 65536;

@@ -401,6 +401,7 @@ extern "C" int cgx_set_option(cgx_ctx *c, const char *name, int64_t value) {
     if (!strcmp(name, "append_slack")) { if (value < 0) return CGX_ERR_ARG; c->append_slack = (uint64_t)value; return CGX_OK; }
     if (!strcmp(name, "append_guess_milli")) { if (value < 0) return CGX_ERR_ARG; c->look1_per_item = c->look2_per_item = (double)value / 1000.0; return CGX_OK; }
     if (!strcmp(name, "async_write")) { c->async_write = value != 0; return CGX_OK; }
+    if (!strcmp(name, "lex_hash_bits")) { if (value < 0 || value > 63) return CGX_ERR_ARG; c->lex_hash_bits = (unsigned)value; return CGX_OK; }
     if (!strcmp(name, "force_host_lexicon")) { c->force_host_lexicon = value != 0; return CGX_OK; }
     if (!strcmp(name, "chunk_items")) { if (value < 1024) return CGX_ERR_ARG; c->chunk_items = (uint64_t)value; return CGX_OK; }
     snprintf(c->err, sizeof c->err, "unknown option %s", name);

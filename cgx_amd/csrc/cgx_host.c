@@ -1353,6 +1353,7 @@ static int run_batch(cgx_ctx *ctx, const cgx_corpus *c, batch *b, const char *ou
     int exact_host = 0;
     rc = cgx_lexicon(ctx);
     if (rc == CGX_ERR_STATE && strstr(cgx_last_error(ctx), "hash collision")) exact_host = 1; else if (rc != CGX_OK) return rc;
+    cgx__set_host_ms(ctx, "exact_host_lexicon", exact_host);  /* 1: this batch took the exact host lexicon */
     LAP("lexicon");
     if (!outdir && !exact_host && cgx__option(ctx, "device_format")) {     /* nothing to write: only the number of rules is wanted */
         uint64_t nl = 0;

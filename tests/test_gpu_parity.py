@@ -295,6 +295,24 @@ def test_lookup_output_sizing_paths(opts, cgx, fixtures_dir, tmp_path):
     ex.close(); corpus.close()
 
 
+def test_lexicon_hash_collisions_are_survived(cgx, fixtures_dir, tmp_path):
+    """The device lexicon groups rules by (id, hash bits of the target side).  With few hash bits two different target
+    sides of one id collide: the device notices (neighbours of a run are compared symbol by symbol) and regroups under
+    another seed; when every seed collides the exact host lexicon takes over.  Same files either way; the sweep must
+    show both outcomes."""
+    fx = make_fixture("toy", fixtures_dir)
+    seen = set()
+    for bits in (2, 12, 16, 18, 20, 22, 24, 26, 28):
+        out = str(tmp_path / ("b%d" % bits))
+        ex, corpus, n = run_product(cgx, fx, out, lex_hash_bits=bits)
+        assert op.sha_dir(out, 7) == META["toy"]["grammar"], bits
+        if ex.host_ms("exact_host_lexicon") >= 1: seen.add("host")
+        elif ex.stage_ms("lex_rehash") >= 1: seen.add("rehash")
+        ex.close(); corpus.close()
+        if seen == {"host", "rehash"}: break
+    assert seen == {"host", "rehash"}, seen
+
+
 def test_index_replica_gives_the_same_files(cgx, fixtures_dir, tmp_path):
     """Multi-GPU layout on one card: a second context receives the index buffer by buffer (what bench.py does over
     RCCL and cgx_broadcast_index does in C), rebuilds the derived tables in cgx_index_finalize and must produce the
