@@ -289,9 +289,21 @@ def main():
     whole = len(chunks) == 1
     spool_bytes = [0]
 
+    stage_names = ("sa_lookup", "blocks", "gappy", "extract", "lexicon", "format", "fmt_count", "fmt_write", "look1_kernel", "look2_kernel")
+    host_names = ("write", "write_wait_d2h", "write_file", "total", "t_upload_sa", "t_blocks", "t_gappy", "t_extract", "t_lexicon", "t_format", "t_flush_wait")
+    acc = {"on": False, "kernel_ms": [], "stage": {k: 0.0 for k in stage_names}, "host": {k: 0.0 for k in host_names},
+           "look1_items": 0.0, "look2_items": 0.0, "h1": 0, "h2": 0, "batches": 0}      # summed over every batch (chunk) of the timed steps
+
     def run_chunk(a, b):
         t0_, t1_ = int(qoff[a]), (int(qoff[b]) if b < nq else len(qtok))
-        return ex.extract_grammars_ids(host, (qoff[a:b] - t0_).astype(np.int32), qtok[t0_:t1_], spool, first + a if whole else 0)
+        n = ex.extract_grammars_ids(host, (qoff[a:b] - t0_).astype(np.int32), qtok[t0_:t1_], spool, first + a if whole else 0)
+        if acc["on"]:                                         # the per-batch timers and tallies of the library hold the batch that just ran
+            acc["kernel_ms"].append(ex.stage_ms("sa_lookup_kernel"))
+            for k in stage_names: acc["stage"][k] += max(ex.stage_ms(k), 0.0)
+            for k in host_names: acc["host"][k] += max(ex.host_ms(k), 0.0)
+            cc = ex.counts(); acc["look1_items"] += max(ex.stage_ms("look1_items"), 0.0); acc["look2_items"] += max(ex.stage_ms("look2_items"), 0.0)
+            acc["h1"] += cc["h1"]; acc["h2"] += cc["h2"]; acc["batches"] += 1
+        return n
 
     def step():
         n = 0
@@ -312,18 +324,15 @@ def main():
     ex.flush()
     if write:
         spool_bytes[0] = sum(e.stat().st_size for e in os.scandir(spool) if e.is_file())
-    stage_names = ("sa_lookup", "blocks", "gappy", "extract", "lexicon", "format", "fmt_count", "fmt_write", "look1_kernel", "look2_kernel")
-    host_names = ("write", "write_wait_d2h", "write_file", "total", "t_upload_sa", "t_blocks", "t_gappy", "t_extract", "t_lexicon", "t_format", "t_flush_wait")
-    kernel_ms = []; stage = {k: 0.0 for k in stage_names}; hoststage = {k: 0.0 for k in host_names}
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter(); rules = 0
+    acc["on"] = True
     for _ in range(steps):
         rules += step()
-        kernel_ms.append(ex.stage_ms("sa_lookup_kernel"))
-        for k in stage: stage[k] += max(ex.stage_ms(k), 0.0)
-        for k in hoststage: hoststage[k] += max(ex.host_ms(k), 0.0)
+    acc["on"] = False
+    kernel_ms, stage, hoststage = acc["kernel_ms"], acc["stage"], acc["host"]
     ex.flush()                                # every grammar file of every timed step is on disk before the clock stops
     torch.cuda.synchronize()
     if world > 1:
@@ -354,8 +363,9 @@ def report(ex, args, cfg, L):
     steps, world, nq, qtok, n_src = L["steps"], L["world"], L["nq"], L["qtok"], L["n_src_tokens"]
     stage, hoststage = L["stage"], L["hoststage"]
     free_b, total_b = torch.cuda.mem_get_info()                # after the timed steps: index + cached batch buffers + both text slots
-    c = ex.counts(); w1, w2 = ex.stage_ms("look1_items"), ex.stage_ms("look2_items")     # of the last batch, before the extra lookup below resets them
-    nch = len(L["chunks"])
+    c = ex.counts()                                            # of the last batch, before the extra lookup below resets them
+    nch = len(L["chunks"]); acc = L["acc"]; nb = max(acc["batches"], 1)
+    w1, w2 = acc["look1_items"] / nb, acc["look2_items"] / nb  # occurrences walked, hits appended and kernel time: means over the batches of the timed steps
     # ---- the batched SA interval search, priced by the probes it executes (counted by the kernel itself, untimed launch) ----
     kms = float(np.mean(L["kernel_ms"])) if L["kernel_ms"] else 0.0
     a, b = L["chunks"][-1]
@@ -393,7 +403,7 @@ def report(ex, args, cfg, L):
                 "target_60pct_met": bool(ach / 8000.0 >= 0.6),
                 "note": "achieved = bytes of the probes the kernel executed (counted by the kernel) / its event-timed duration, against the 8 TB/s streaming peak (target 0.6: see target_60pct_met); the probes are scattered 16-byte reads, so the bound that applies is the card's random-read request rate (tools/micro/gather_bw): frac_of_random_read_peak"}
     # ---- the kernels that take the most time per step, priced per corpus occurrence they visit ----
-    k1, k2 = stage["look1_kernel"] / steps / nch, stage["look2_kernel"] / steps / nch
+    k1, k2 = stage["look1_kernel"] / nb, stage["look2_kernel"] / nb
     by_time = []
     try:                                                        # counter traffic of the same kernels on the same workload (committed PMC passes) and the card's random-read rate
         pk = json.load(open(os.path.join(ROOT, "profiles", "pmc_lookup_kernels.json")))
@@ -402,7 +412,7 @@ def report(ex, args, cfg, L):
             pk = None
     except Exception:
         pk = None
-    for name, w, per, hits, ms in (("k_look1 (one-gap corpus lookups)", w1, ex.stage_ms("look1_bytes_per_item"), c["h1"], k1), ("k_look2 (two-gap corpus lookups)", w2, ex.stage_ms("look2_bytes_per_item"), c["h2"], k2)):
+    for name, w, per, hits, ms in (("k_look1 (one-gap corpus lookups)", w1, ex.stage_ms("look1_bytes_per_item"), acc["h1"] / nb, k1), ("k_look2 (two-gap corpus lookups)", w2, ex.stage_ms("look2_bytes_per_item"), acc["h2"] / nb, k2)):
         if w > 0 and ms > 0 and per > 0:
             ab = w * per + hits * 8
             e = {"kernel": name, "bound": "hbm", "occurrences_per_launch": int(w), "bytes_per_occurrence": per, "algorithmic_bytes_per_launch": int(ab), "ms_per_launch": round(ms, 3),
@@ -411,8 +421,8 @@ def report(ex, args, cfg, L):
             if kk:                                               # these kernels gather one unaligned 128-byte window per occurrence at random: the card's measured rate of random 128-byte runs is the bound that applies
                 tr = (kk["TCC_EA0_RDREQ_per_batch"] + kk["TCC_EA0_WRREQ_per_batch"]) * 64.0      # counters summed over the batch's launches of this kernel (tile chunks)
                 e.update(traffic=int(tr), traffic_GBps=round(tr / (ms * 1e-3) / 1e9, 1), sectors_per_occurrence=round(kk["TCC_EA0_RDREQ_per_batch"] / w, 2),
-                         windows_per_s=round(w / (ms * 1e-3), 1), random_128B_runs_per_s_peak=pk["random_read_peak"]["runs_per_s_128B"],
-                         frac_of_random_window_peak=round(w / (ms * 1e-3) / pk["random_read_peak"]["runs_per_s_128B"], 3))
+                         traffic_frac_of_peak=round(tr / (ms * 1e-3) / 1e9 / 8000.0, 4),     # what the HBM actually moved for this kernel, as a fraction of 8 TB/s
+                         windows_per_s=round(w / (ms * 1e-3), 1), microbench_random_128B_runs_per_s=pk["random_read_peak"]["runs_per_s_128B"])   # tools/micro/gather_bw on the same card: a comparison, not a bound (neighbouring occurrences share sectors in the L2)
             by_time.append(e)
     div = steps * 1.0
     out = {
