@@ -1,7 +1,10 @@
 /* file_assemble -- how fast can T host threads assemble many files (a few MB each) from ~1.5 KB pieces of a large
  * in-memory text?  Three ways: (A) pwritev of <= 1024 pieces per call (what the writer does), (B) pieces memcpy'd into a
  * per-thread buffer, one pwrite per file, (C) mmap(MAP_SHARED|MAP_POPULATE) of the (existing) file + memcpy.
- * usage: file_assemble <dir> <threads> <files> <file_MB> [source_GB]     (files are written twice: fresh, then in place) */
+ * usage: file_assemble <dir> <threads> <files> <file_MB> [source_GB] [methods-mask] [stride]
+ *   (files are written three times: fresh, then twice in place; methods-mask bit m enables method m, default 7;
+ *    stride > 0 pins thread t to CPU t*stride -- e.g. 4 on a 64-core socket puts 16 threads on 16 different core pairs / 8 CCDs;
+ *    the process CPU time is printed so that bytes per CPU-second can be compared under a cgroup CPU quota) */
 #define _GNU_SOURCE
 #include <fcntl.h>
 #include <pthread.h>
@@ -9,15 +12,19 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sched.h>
 #include <sys/mman.h>
+#include <sys/resource.h>
 #include <sys/uio.h>
 #include <time.h>
 #include <unistd.h>
 static double now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + t.tv_nsec * 1e-9; }
 static char *src; static uint64_t src_bytes; static uint64_t *seg_off; static uint32_t *seg_len; static uint64_t *fseg; static int nfiles; static const char *dir; static int method; static int next_file;
 static uint64_t rnd(uint64_t *s) { *s ^= *s << 13; *s ^= *s >> 7; *s ^= *s << 17; return *s; }
+static int stride;
 static void *worker(void *arg) {
-    (void)arg; struct iovec iov[1024]; char fn[512]; char *buf = NULL; size_t cap = 0;
+    if (stride > 0) { cpu_set_t cs; CPU_ZERO(&cs); CPU_SET((int)(intptr_t)arg * stride, &cs); (void)pthread_setaffinity_np(pthread_self(), sizeof cs, &cs); }
+    struct iovec iov[1024]; char fn[512]; char *buf = NULL; size_t cap = 0;
     for (;;) {
         int f = __atomic_fetch_add(&next_file, 1, __ATOMIC_RELAXED);
         if (f >= nfiles) break;
@@ -49,19 +56,21 @@ static void *worker(void *arg) {
 }
 int main(int argc, char **argv) {
     if (argc < 5) { fprintf(stderr, "usage: file_assemble <dir> <threads> <files> <file_MB> [source_GB]\n"); return 2; }
-    dir = argv[1]; int T = atoi(argv[2]); nfiles = atoi(argv[3]); double fmb = atof(argv[4]); double sgb = argc > 5 ? atof(argv[5]) : 2.0;
+    dir = argv[1]; int T = atoi(argv[2]); nfiles = atoi(argv[3]); double fmb = atof(argv[4]); double sgb = argc > 5 ? atof(argv[5]) : 2.0; int mask = argc > 6 ? atoi(argv[6]) : 7; stride = argc > 7 ? atoi(argv[7]) : 0;
     src_bytes = (uint64_t)(sgb * (1 << 30)); src = malloc(src_bytes); memset(src, 'x', src_bytes);
     uint64_t per = (uint64_t)(fmb * 1e6), nseg_est = (uint64_t)nfiles * (per / 1000 + 2), ns = 0, st = 88172645463325252ull;
     seg_off = malloc(nseg_est * 8); seg_len = malloc(nseg_est * 4); fseg = malloc(((size_t)nfiles + 1) * 8);
     for (int f = 0; f < nfiles; f++) { fseg[f] = ns; for (uint64_t b = 0; b < per;) { uint32_t l = 200 + (uint32_t)(rnd(&st) % 2800); seg_len[ns] = l; seg_off[ns] = rnd(&st) % (src_bytes - 4096); ns++; b += l; } }
     fseg[nfiles] = ns;
     const char *names[3] = {"pwritev(1024 pieces)", "memcpy+pwrite", "mmap(MAP_POPULATE)+memcpy"};
-    for (method = 0; method < 3; method++) for (int pass = 0; pass < 3; pass++) {
+    for (method = 0; method < 3; method++) for (int pass = 0; pass < 3 && ((mask >> method) & 1); pass++) {
         next_file = 0; pthread_t th[256]; double t0 = now();
-        for (int t = 0; t < T; t++) pthread_create(&th[t], NULL, worker, NULL);
+        struct rusage r0, r1; getrusage(RUSAGE_SELF, &r0);
+        for (int t = 0; t < T; t++) pthread_create(&th[t], NULL, worker, (void *)(intptr_t)t);
         for (int t = 0; t < T; t++) pthread_join(th[t], NULL);
-        double dt = now() - t0;
-        printf("%-28s pass %d (%s): %.2f GB in %.3f s = %.1f GB/s with %d threads, %llu pieces\n", names[method], pass, pass ? "in place" : "fresh or first rewrite", nfiles * fmb / 1e3, dt, nfiles * fmb / 1e3 / dt, T, (unsigned long long)ns);
+        double dt = now() - t0; getrusage(RUSAGE_SELF, &r1);
+        double cpu = (r1.ru_utime.tv_sec - r0.ru_utime.tv_sec) + (r1.ru_utime.tv_usec - r0.ru_utime.tv_usec) * 1e-6 + (r1.ru_stime.tv_sec - r0.ru_stime.tv_sec) + (r1.ru_stime.tv_usec - r0.ru_stime.tv_usec) * 1e-6;
+        printf("%-28s pass %d (%s): %.2f GB in %.3f s = %.1f GB/s with %d threads (stride %d), %.2f CPU-s = %.2f GB per CPU-s, %llu pieces\n", names[method], pass, pass ? "in place" : "fresh or first rewrite", nfiles * fmb / 1e3, dt, nfiles * fmb / 1e3 / dt, T, stride, cpu, nfiles * fmb / 1e3 / cpu, (unsigned long long)ns);
     }
     return 0;
 }
