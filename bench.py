@@ -285,7 +285,15 @@ def main():
             write = False                                       # no room for a useful spool: count the rules on the GPU instead (reported)
             chunk = nq
     spool = tempfile.mkdtemp(prefix="cgx_bench_r%d_" % rank, dir=base) if write else None
-    chunks = [(a, min(a + chunk, nq)) for a in range(0, nq, max(chunk, 1))] or [(0, 0)]
+    # a chunk is also at most one internal batch of the library (300 000 query tokens by default): the per-batch timers and
+    # tallies read after each chunk then describe the whole chunk, and every configuration runs the same pipeline
+    tok_cap = 300000; chunks = []; a = 0; qend = np.append(qoff[1:], len(qtok)).astype(np.int64) if nq else np.zeros(0, np.int64)
+    while a < nq:
+        b = int(np.searchsorted(qend, int(qoff[a]) + tok_cap, side="right"))     # queries a..b-1 hold <= tok_cap tokens
+        b = max(a + 1, min(b, a + max(chunk, 1), nq))
+        chunks.append((a, b)); a = b
+    chunks = chunks or [(0, 0)]
+    chunk = max(b - a for a, b in chunks)
     whole = len(chunks) == 1
     spool_bytes = [0]
 
