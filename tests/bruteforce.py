@@ -153,15 +153,18 @@ def twogap_rules(c, pid, hits, a_len, b_len):
     return sorted(out)
 
 
-def check_batch(c, sa, freq, phits, s1, p1d, hits1, s2, c2d, hits2, blocks, r0, r1, sep1, r2, sep2a, sep2b, max_patterns=None):
+def check_batch(c, sa, freq, phits, s1, p1d, hits1, s2, c2d, hits2, blocks, r0, r1, sep1, r2, sep2a, sep2b, max_patterns=None, pick=None):
     """Compares one batch's device (or oracle) results with the definitions above.  Arrays are the wire records of
     include/cgx.h (numpy structured arrays); `phits` = list of (start, len) of the whole frequent-pair table with `pidx`
-    folded in by the caller as a dict pair -> list.  Returns the number of patterns / blocks checked."""
+    folded in by the caller as a dict pair -> list.  `max_patterns`: only the first so many one-gap patterns (and the
+    two-gap patterns built on them); `pick`: only these one-gap pattern ids.  Returns the number of patterns / blocks checked."""
     freq = [int(x) for x in freq]; rank = {t: i for i, t in enumerate(freq)}
     checked = 0
     hits_of = {}
     d1 = len(s1) if max_patterns is None else min(len(s1), max_patterns)
-    for pid in range(d1):
+    pids = sorted(set(int(x) for x in pick if 0 <= int(x) < len(s1))) if pick is not None else list(range(d1))
+    chosen = set(pids)
+    for pid in pids:
         s = s1[pid]; pat = [int(x) for x in p1d[pid]["pat"][:int(p1d[pid]["number"])]]
         al, bl = int(s["a_len"]), int(s["b_len"])
         a, b = pat[:al], pat[al + 1:al + 1 + bl]
@@ -185,14 +188,14 @@ def check_batch(c, sa, freq, phits, s1, p1d, hits1, s2, c2d, hits2, blocks, r0, 
             hits_of[pid] = want
         checked += 1
     # aXb rules: r1[sep1:] holds them with id = pattern id
-    got_r1 = sorted((int(r["id"]), int(r["tstart"]), int(r["end"]), int(r["gap1"]), int(r["gap1_1"])) for r in r1[sep1:] if int(r["id"]) < d1)
-    want_r1 = sorted(sum((onegap_rules(c, pid, hits_of[pid], int(s1[pid]["a_len"]), int(s1[pid]["b_len"])) for pid in range(d1)), []))
+    got_r1 = sorted((int(r["id"]), int(r["tstart"]), int(r["end"]), int(r["gap1"]), int(r["gap1_1"])) for r in r1[sep1:] if int(r["id"]) in chosen)
+    want_r1 = sorted(sum((onegap_rules(c, pid, hits_of[pid], int(s1[pid]["a_len"]), int(s1[pid]["b_len"])) for pid in pids), []))
     assert got_r1 == want_r1, ("aXb rules", len(got_r1), len(want_r1))
     # two-gap patterns
     two_hits = {}
     for tid in range(len(s2)):
         one = int(s2[tid]["blockid"])
-        if one >= d1:
+        if one not in chosen:
             continue
         want = twogap_hits(c, hits_of[one], int(c2d[tid]))
         if int(s2[tid]["sa_start"]) == -1:
