@@ -47,6 +47,18 @@ CONFIGS = {
 EST_BYTES_PER_QUERY = 4.0e6          # grammar text per query before the first measurement (3.3e6 measured on cfg3)
 
 
+def make_chunks(qoff, ntok, max_queries, tok_cap=300000):
+    """Query ranges [a, b) of one step: at most `max_queries` sentences (what the spool holds) and at most `tok_cap` query
+    tokens (one internal batch of the library) each; a sentence longer than the cap is a chunk of its own."""
+    qoff = np.asarray(qoff, np.int64); nq = len(qoff); chunks = []; a = 0
+    qend = np.append(qoff[1:], ntok).astype(np.int64) if nq else np.zeros(0, np.int64)
+    while a < nq:
+        b = int(np.searchsorted(qend, int(qoff[a]) + tok_cap, side="right"))     # queries a..b-1 hold <= tok_cap tokens
+        b = max(a + 1, min(b, a + max(int(max_queries), 1), nq))
+        chunks.append((a, b)); a = b
+    return chunks or [(0, 0)]
+
+
 def survey_bytes(n_tokens, lm):
     """B(N,l) = 2*ceil(log2 N)*(4+4l) + 4l + 8 bytes per interval lookup (t,l), l <= 5 --
     what the REFERENCE's full-depth binary search would touch for the same lookups."""
@@ -287,12 +299,7 @@ def main():
     spool = tempfile.mkdtemp(prefix="cgx_bench_r%d_" % rank, dir=base) if write else None
     # a chunk is also at most one internal batch of the library (300 000 query tokens by default): the per-batch timers and
     # tallies read after each chunk then describe the whole chunk, and every configuration runs the same pipeline
-    tok_cap = 300000; chunks = []; a = 0; qend = np.append(qoff[1:], len(qtok)).astype(np.int64) if nq else np.zeros(0, np.int64)
-    while a < nq:
-        b = int(np.searchsorted(qend, int(qoff[a]) + tok_cap, side="right"))     # queries a..b-1 hold <= tok_cap tokens
-        b = max(a + 1, min(b, a + max(chunk, 1), nq))
-        chunks.append((a, b)); a = b
-    chunks = chunks or [(0, 0)]
+    chunks = make_chunks(qoff, len(qtok), chunk)
     chunk = max(b - a for a, b in chunks)
     whole = len(chunks) == 1
     spool_bytes = [0]

@@ -30,3 +30,21 @@ def test_presets_are_the_baseline_configs():
     assert c["cfg3"]["pairs"] == 10_000_000 and c["cfg3"]["queries"] == 10_000 and c["cfg3"]["scaling"] == "weak"
     assert c["cfg4"]["queries"] == 50_000 and c["cfg4"]["scaling"] == "strong"
     assert c["cfg5"]["queries"] == 1_000_000 and abs(c["cfg5"]["pairs"] * 26 - 1e8) < 2e6          # 26 tokens per sentence pair incl. the delimiter
+
+
+def test_chunks_respect_the_spool_and_the_internal_batch():
+    """A step is cut into chunks of at most `max_queries` sentences and at most `tok_cap` query tokens; every sentence is
+    in exactly one chunk, in order; an over-long sentence still gets a chunk."""
+    import numpy as np
+    import bench
+    rng = np.random.default_rng(5)
+    lens = rng.integers(1, 40, 1000); lens[17] = 500
+    qoff = np.concatenate([[0], np.cumsum(lens)[:-1]]); ntok = int(lens.sum())
+    for max_q, cap in ((1000, 10**9), (64, 10**9), (1000, 300), (7, 120)):
+        ch = bench.make_chunks(qoff, ntok, max_q, cap)
+        assert ch[0][0] == 0 and ch[-1][1] == 1000 and all(a[1] == b[0] for a, b in zip(ch, ch[1:]))
+        for a, b in ch:
+            assert 0 < b - a <= max_q
+            toks = int(lens[a:b].sum())
+            assert toks <= cap or b - a == 1
+    assert bench.make_chunks(np.zeros(0, np.int64), 0, 10) == [(0, 0)]
