@@ -38,7 +38,7 @@ def test_oracle_agrees_with_the_definitions(oracle_bin, fixtures_dir, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["tiny", "toy"])
+@pytest.mark.parametrize("name", ["tiny", "toy", "mid"])
 def test_hip_path_agrees_with_the_definitions(name, oracle_bin, fixtures_dir, tmp_path):
     import torch
     torch.zeros(1, device="cuda:0")
@@ -52,8 +52,10 @@ def test_hip_path_agrees_with_the_definitions(name, oracle_bin, fixtures_dir, tm
     c = bf.Corpus(d["str"][:n], d["rlp"], d["ltar"], d["rtar"]); k = ex.counts()
     # the larger fixture: the first 300 one-gap patterns and 500 drawn over the whole id range, with the two-gap patterns
     # built on them (python loops: a full sweep of toy takes minutes)
+    # mid (5 000 pairs, 40 queries, vocabulary 300): every block and 3 000 one-gap patterns drawn over the id range
     limit = None if name == "tiny" else 300
-    pick = None if name == "tiny" else sorted(set(range(300)) | set(int(x) for x in np.random.default_rng(11).integers(0, max(int(k["d1"]), 1), 500)))
+    extra = 500 if name == "toy" else 3000
+    pick = None if name == "tiny" else sorted(set(range(300)) | set(int(x) for x in np.random.default_rng(11).integers(0, max(int(k["d1"]), 1), extra)))
     done = bf.check_batch(c, ex.fetch("sa"), ex.fetch("freq"), _phits(ex.fetch("pidx"), ex.fetch("phit_start"), ex.fetch("phit_len")), ex.fetch("s1"), ex.fetch("p1d"),
                           ex.fetch("hits1"), ex.fetch("s2"), ex.fetch("c2d"), ex.fetch("hits2"), ex.fetch("blocks"), ex.fetch("r0"), ex.fetch("r1"), k["sep1"], ex.fetch("r2"), k["sep2a"], k["sep2b"], max_patterns=limit, pick=pick)
     assert done > 100 and k["guard_exits"] == 0
