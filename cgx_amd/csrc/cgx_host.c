@@ -846,9 +846,26 @@ static void fill_group_sizes(const batch *b, int kind, lexent *lex, uint32_t nl,
         i = k;
     }
 }
+/* CPUs this process may actually use: online CPUs, its affinity mask and the cgroup CPU quota (cpu.max), whichever is smallest */
+static int usable_cpus(void) {
+    long c = sysconf(_SC_NPROCESSORS_ONLN); int n = c > 0 ? (int)c : 1;
+    cpu_set_t set; if (sched_getaffinity(0, sizeof set, &set) == 0) { int k = CPU_COUNT(&set); if (k > 0 && k < n) n = k; }
+    FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r");
+    if (f) { char q[64]; long long per = 0; if (fscanf(f, "%63s %lld", q, &per) == 2 && strcmp(q, "max") && per > 0) { long long k = (atoll(q) + per - 1) / per; if (k > 0 && k < n) n = (int)k; } fclose(f); }
+    return n;
+}
 static int nthreads_host(void) {
     const char *e = getenv("CGX_THREADS"); int n = e ? atoi(e) : 0;
-    if (n <= 0) { long c = sysconf(_SC_NPROCESSORS_ONLN); n = c > 16 ? 16 : (int)c; }
+    if (n <= 0) { int c = usable_cpus(); n = c > 16 ? 16 : c; }
+    return n < 1 ? 1 : n > 64 ? 64 : n;
+}
+/* The file phase is a page-cache copy that keeps every writer thread busy.  Under a CPU quota the whole process is frozen
+ * for the rest of the scheduling period once the quota is used up -- the thread that feeds the GPU included -- so two CPUs'
+ * worth of quota are left to it and to the HIP runtime's own threads: on the 16-CPU boxes 14 writers finish a file phase in
+ * 348-357 ms, 16 in 348-394 ms with the GPU stages stretched by the freezes (tools/gpu_threads_ab.sh). */
+static int writer_threads(void) {
+    const char *e = getenv("CGX_THREADS"); int n = e ? atoi(e) : 0;
+    if (n <= 0) { int c = usable_cpus(); n = c >= 8 ? c - 2 : c; if (n > 16) n = 16; }
     return n < 1 ? 1 : n > 64 ? 64 : n;
 }
 static int build_lex_kind(batch *b, int kind, uint32_t nrules, lexent **out, uint32_t *nout, uint32_t nid, range **rng, uint32_t *taskcap) {
@@ -1245,7 +1262,7 @@ static int dev_copy_begin(pending *pw) {
 /* phase 2 (after the copies have landed and the previous batch's files are complete) */
 static int dev_write_files(pending *pw) {
     cgx_ctx *ctx = pw->ctx; const hostbuf *hb = &pw->ws->hb[pw->hb]; const int32_t nq = pw->nq;
-    int nt = nthreads_host(); if (nt > MAX_WRITERS) nt = MAX_WRITERS; if (nt > nq) nt = nq > 0 ? nq : 1;
+    int nt = writer_threads(); if (nt > MAX_WRITERS) nt = MAX_WRITERS; if (nt > nq) nt = nq > 0 ? nq : 1;
     devjob jobs[MAX_WRITERS]; pthread_t th[MAX_WRITERS]; int started[MAX_WRITERS]; int32_t next = 0; int rc = CGX_OK;
     for (int t = 0; t < nt; t++) { memset(&jobs[t], 0, sizeof jobs[t]); jobs[t].ctx = ctx; jobs[t].tid = t; jobs[t].nq = nq; jobs[t].first = pw->first; jobs[t].outdir = pw->outdir; jobs[t].next_q = &next;
                                    jobs[t].utext = hb->utext; jobs[t].qseg = hb->qseg; jobs[t].seg_off = hb->segoff; jobs[t].seg_len = hb->seglen; jobs[t].rc = CGX_OK; jobs[t].gz = (int)cgx__option(ctx, "gz_level"); }
