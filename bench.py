@@ -162,6 +162,11 @@ def main():
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     if args.single_device:
         local = 0
+    if local_world > 1 and "CGX_THREADS" not in os.environ:
+        # the ranks of one host share its CPUs (and its cgroup quota): each writer gets its share, two CPUs of it left to
+        # the thread that feeds the GPU (what the library does by itself for a single process)
+        share = usable_cpus() // local_world
+        os.environ["CGX_THREADS"] = str(max(1, min(16, share - 2 if share >= 8 else share)))
     # the CPU baseline runs first, in its own process, while this one generates the corpus: its cores are free
     # again long before the timed region starts (it is joined before the warm-up steps)
     cpu_proc = start_cpu_baseline(args, cfg) if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
