@@ -439,8 +439,15 @@ def report(ex, args, cfg, L):
                  "achieved": round(ab / (ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ab / (ms * 1e-3) / 1e9 / 8000.0, 4), "traffic": None}
             kk = pk["kernels"].get(name.split(" ")[0]) if pk else None
             if kk:                                               # these kernels gather one unaligned 128-byte window per occurrence at random: the card's measured rate of random 128-byte runs is the bound that applies
-                tr = (kk["TCC_EA0_RDREQ_per_batch"] + kk["TCC_EA0_WRREQ_per_batch"]) * 64.0      # counters summed over the batch's launches of this kernel (tile chunks)
+                # Counters summed over the batch's launches of this kernel (tile chunks).  FETCH_SIZE = read requests x 64 B, but a
+                # request is 64 or 128 bytes (calibrated on known byte counts, profiles/r2bd_fetch_size_calibration_gather.txt):
+                # `traffic` applies the request mix of this access pattern (an unaligned 128-byte window = one 128-byte and one
+                # 64-byte request), the raw counter figure and the two bounds are given beside it.
+                cal = pk.get("calibration", {}); bpr = float(cal.get("estimated_bytes_per_request", {}).get(name.split(" ")[0], 64.0))
+                raw = (kk["TCC_EA0_RDREQ_per_batch"] + kk["TCC_EA0_WRREQ_per_batch"]) * 64.0
+                tr = kk["TCC_EA0_RDREQ_per_batch"] * bpr + kk["TCC_EA0_WRREQ_per_batch"] * 64.0
                 e.update(traffic=int(tr), traffic_GBps=round(tr / (ms * 1e-3) / 1e9, 1), sectors_per_occurrence=round(kk["TCC_EA0_RDREQ_per_batch"] / w, 2),
+                         traffic_counter_raw=int(raw), traffic_bounds=[int(raw), int(kk["TCC_EA0_RDREQ_per_batch"] * 128.0 + kk["TCC_EA0_WRREQ_per_batch"] * 64.0)], bytes_per_read_request_assumed=bpr,
                          traffic_frac_of_peak=round(tr / (ms * 1e-3) / 1e9 / 8000.0, 4),     # what the HBM actually moved for this kernel, as a fraction of 8 TB/s
                          windows_per_s=round(w / (ms * 1e-3), 1), microbench_random_128B_runs_per_s=pk["random_read_peak"]["runs_per_s_128B"])   # tools/micro/gather_bw on the same card: a comparison, not a bound (neighbouring occurrences share sectors in the L2)
             by_time.append(e)
