@@ -24,6 +24,8 @@ for r in seg:
     if out and out[-1][0] == n and gap < 20000: out[-1][1] += 1; out[-1][2] += e - s; out[-1][3] += gap
     else: out.append([n, 1, e - s, gap, s - t0])
     prev_end = max(prev_end, e)
+durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows if short(r["Kernel_Name"]).startswith(first)]
+print(f"every launch of {first} in this trace, ms: " + " ".join(f"{d:.4f}" for d in durs) + f"   (median {sorted(durs)[len(durs) // 2]:.4f}; the first launches after the index build touch the tables for the first time)")
 busy = sum(o[2] for o in out); idle = sum(o[3] for o in out)
 print(f"last batch: {len(seg)} launches, busy {busy/1e6:.1f} ms, idle {idle/1e6:.1f} ms, span {(prev_end-t0)/1e6:.1f} ms")
 for n, c, d, g, at in out:
