@@ -458,6 +458,7 @@ def report(ex, args, cfg, L):
                    "parallelism": "query-shard x%d, index replicated (one RCCL broadcast, %s)" % (world, "cgx_broadcast_index" if args.bcast == "c" else "torch.distributed"),
                    "grammar_files_written": bool(L["write"]), "grammar_bytes_per_spool_fill": int(L["spool_bytes"][0]),
                    "writer": None if not L["write"] else ("sync" if args.sync_write else "async (host threads overlap the next chunk; flushed before the clock stops)"),
+                   "writer_threads": None if not L["write"] else int(max(ex.host_ms("writer_threads"), 0)),
                    "outdir": L["base"] if L["write"] else None,
                    "outdir_mode": None if not L["write"] else ("one spool directory per rank rewritten in place by every step, %d untimed priming fill(s) beyond the warm-up; %d chunk(s) of <= %d queries per step%s"
                                                                % (L["priming"], nch, L["chunk"], "" if L["whole"] else ", chunks reuse the file slots grammar.0.s .. (first_query_index = 0)")),

@@ -1263,6 +1263,7 @@ static int dev_copy_begin(pending *pw) {
 static int dev_write_files(pending *pw) {
     cgx_ctx *ctx = pw->ctx; const hostbuf *hb = &pw->ws->hb[pw->hb]; const int32_t nq = pw->nq;
     int nt = writer_threads(); if (nt > MAX_WRITERS) nt = MAX_WRITERS; if (nt > nq) nt = nq > 0 ? nq : 1;
+    cgx__set_host_ms(ctx, "writer_threads", nt);             /* reported beside the timings (bench.py) */
     devjob jobs[MAX_WRITERS]; pthread_t th[MAX_WRITERS]; int started[MAX_WRITERS]; int32_t next = 0; int rc = CGX_OK;
     for (int t = 0; t < nt; t++) { memset(&jobs[t], 0, sizeof jobs[t]); jobs[t].ctx = ctx; jobs[t].tid = t; jobs[t].nq = nq; jobs[t].first = pw->first; jobs[t].outdir = pw->outdir; jobs[t].next_q = &next;
                                    jobs[t].utext = hb->utext; jobs[t].qseg = hb->qseg; jobs[t].seg_off = hb->segoff; jobs[t].seg_len = hb->seglen; jobs[t].rc = CGX_OK; jobs[t].gz = (int)cgx__option(ctx, "gz_level"); }
