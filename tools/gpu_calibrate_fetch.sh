@@ -3,6 +3,7 @@
 # loads at a random offset): tools/micro/gather_bw reads a KNOWN number of bytes that way; the guide says a wide coalesced
 # stream is tallied at half its bytes on gfx950 and that other patterns must be calibrated.  One rocprofv3 --pmc pass per group.
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; OUT=$GRAFT_REPO_ROOT/gpurun_out/${1:-cal}; mkdir -p $OUT
+[ -x bin/gather_bw_micro ] || { mkdir -p bin && hipcc --offload-arch=gfx950 -O3 tools/micro/gather_bw.cpp -o bin/gather_bw_micro; } || exit 1
 cd /tmp && export TMPDIR=/tmp
 i=0
 for grp in "FETCH_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_REQ_sum TCC_HIT_sum"; do
