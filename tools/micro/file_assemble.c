@@ -1,7 +1,7 @@
 /* file_assemble -- how fast can T host threads assemble many files (a few MB each) from ~1.5 KB pieces of a large
  * in-memory text?  Three ways: (A) pwritev of <= 1024 pieces per call (what the writer does), (B) pieces memcpy'd into a
  * per-thread buffer, one pwrite per file, (C) mmap(MAP_SHARED|MAP_POPULATE) of the (existing) file + memcpy.
- * usage: file_assemble <dir> <threads> <files> <file_MB> [source_GB] [methods-mask] [stride] [max piece bytes, default 3000]
+ * usage: file_assemble <dir> <threads> <files> <file_MB> [source_GB] [methods-mask] [stride] [max piece bytes, default 3000] [source on huge pages 0/1]
  *   (files are written three times: fresh, then twice in place; methods-mask bit m enables method m, default 7;
  *    stride > 0 pins thread t to CPU t*stride -- e.g. 4 on a 64-core socket puts 16 threads on 16 different core pairs / 8 CCDs;
  *    the process CPU time is printed so that bytes per CPU-second can be compared under a cgroup CPU quota) */
@@ -57,7 +57,8 @@ static void *worker(void *arg) {
 int main(int argc, char **argv) {
     if (argc < 5) { fprintf(stderr, "usage: file_assemble <dir> <threads> <files> <file_MB> [source_GB]\n"); return 2; }
     dir = argv[1]; int T = atoi(argv[2]); nfiles = atoi(argv[3]); double fmb = atof(argv[4]); double sgb = argc > 5 ? atof(argv[5]) : 2.0; int mask = argc > 6 ? atoi(argv[6]) : 7; stride = argc > 7 ? atoi(argv[7]) : 0; uint32_t pmax = argc > 8 ? (uint32_t)atoi(argv[8]) : 3000;   /* pieces of 200 .. pmax bytes */
-    src_bytes = (uint64_t)(sgb * (1 << 30)); src = malloc(src_bytes); memset(src, 'x', src_bytes);
+    int thp = argc > 9 ? atoi(argv[9]) : 0;   /* 1: the source text on transparent huge pages (madvise) */
+    src_bytes = (uint64_t)(sgb * (1 << 30)); if (posix_memalign((void **)&src, 2u << 20, src_bytes)) return 1; if (thp) madvise(src, src_bytes, MADV_HUGEPAGE); memset(src, 'x', src_bytes);
     uint64_t per = (uint64_t)(fmb * 1e6), nseg_est = (uint64_t)nfiles * (per / 200 + 2), ns = 0, st = 88172645463325252ull;
     seg_off = malloc(nseg_est * 8); seg_len = malloc(nseg_est * 4); fseg = malloc(((size_t)nfiles + 1) * 8);
     for (int f = 0; f < nfiles; f++) { fseg[f] = ns; for (uint64_t b = 0; b < per;) { uint32_t l = 200 + (uint32_t)(rnd(&st) % (pmax - 200)); seg_len[ns] = l; seg_off[ns] = rnd(&st) % (src_bytes - 4096); ns++; b += l; } }
