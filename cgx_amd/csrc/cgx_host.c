@@ -474,7 +474,7 @@ cgx_corpus *cgx_corpus_load(const char *src, const char *tgt, const char *align,
     if (build_word_slots(c)) goto bad;
     {
         const char *files[4] = {src, tgt, align, lex}; struct stat sb;
-        for (int k = 0; k < 4; k++) if (!stat(files[k], &sb)) { c->src_size[k] = (uint64_t)sb.st_size; c->src_mtime[k] = (uint64_t)sb.st_mtime; }
+        for (int k = 0; k < 4; k++) if (!stat(files[k], &sb)) { c->src_size[k] = (uint64_t)sb.st_size + 1; c->src_mtime[k] = (uint64_t)sb.st_mtim.tv_sec * 1000000000ull + (uint64_t)sb.st_mtim.tv_nsec; }   /* size + 1: 0 stays "unknown", an empty file is known */
     }
     return c;
 bad:
@@ -520,7 +520,7 @@ cgx_corpus *cgx_corpus_from_ids(const int32_t *str, uint32_t n, const int32_t *s
  * loader checks the file size against them. */
 /* ------------------------------------------------------------------ */
 typedef struct { char magic[8]; uint64_t checksum; uint32_t n, nt, nsent, nlex, nsvocab, ntvocab, maxword, reserved; uint64_t sbytes, tbytes; uint64_t src_size[4], src_mtime[4]; } cachehdr;
-static const char CACHE_MAGIC[8] = {'C', 'G', 'X', 'C', 'O', 'R', 'P', '2'};
+static const char CACHE_MAGIC[8] = {'C', 'G', 'X', 'C', 'O', 'R', 'P', '3'};   /* 3: source fingerprint = size + 1 and nanosecond mtime */
 int cgx_corpus_save(const cgx_corpus *c, const char *path) {
     if (!c || !path || !c->rlp || !c->svocab || !c->tvocab) return CGX_ERR_ARG;
     /* written under a private name and renamed into place: a reader (another --shard process started at the same time)
@@ -600,8 +600,9 @@ cgx_corpus *cgx_corpus_load_cache(const char *path, char *err, size_t errcap) {
     if (ok) {
         const char *what = NULL;
         if (c->nsvocab < 2 || c->ntvocab < 2 || c->nsent < 0 || (uint64_t)c->nsent + 2 > c->n) what = "counts";
-        for (uint32_t i = 0; !what && i < c->n; i++) if (c->str[i] < 1 || c->str[i] > c->nsvocab) what = "source token id";
-        for (uint32_t i = 0; !what && i < c->nt; i++) if (c->tstr[i] < 1 || c->tstr[i] > c->ntvocab) what = "target token id";
+        /* valid ids are < nsvocab; only the closing sentinel (the last token, one past the newest word, Start.cu:321-327) may equal it */
+        for (uint32_t i = 0; !what && i < c->n; i++) if (c->str[i] < 1 || c->str[i] > c->nsvocab || (c->str[i] == c->nsvocab && i + 1 != c->n)) what = "source token id";
+        for (uint32_t i = 0; !what && i < c->nt; i++) if (c->tstr[i] < 1 || c->tstr[i] > c->ntvocab || (c->tstr[i] == c->ntvocab && i + 1 != c->nt)) what = "target token id";
         if (!what && (c->sentind[0] != 0 || c->tsentind[0] != 0)) what = "sentence table";
         for (int32_t q = 0; !what && q < c->nsent; q++) if (c->sentind[q + 1] <= c->sentind[q] || (uint32_t)c->sentind[q + 1] > c->n || c->tsentind[q + 1] <= c->tsentind[q] || (uint32_t)c->tsentind[q + 1] > c->nt) what = "sentence table";
         for (uint32_t i = 0; !what && i < c->nlex; i++) if (c->lexk[i].src < -1 || c->lexk[i].src >= c->nsvocab || c->lexk[i].tgt < -1 || c->lexk[i].tgt >= c->ntvocab) what = "lexical table id";
@@ -618,7 +619,7 @@ int cgx_corpus_matches_sources(const cgx_corpus *c, const char *src, const char 
     if (!c) return -1;
     const char *files[4] = {src, tgt, align, lex}; struct stat sb[4];
     for (int k = 0; k < 4; k++) if (!files[k] || stat(files[k], &sb[k])) return -1;
-    for (int k = 0; k < 4; k++) if (!c->src_size[k] || c->src_size[k] != (uint64_t)sb[k].st_size || c->src_mtime[k] != (uint64_t)sb[k].st_mtime) return 0;
+    for (int k = 0; k < 4; k++) if (!c->src_size[k] || c->src_size[k] != (uint64_t)sb[k].st_size + 1 || c->src_mtime[k] != (uint64_t)sb[k].st_mtim.tv_sec * 1000000000ull + (uint64_t)sb[k].st_mtim.tv_nsec) return 0;
     return 1;
 }
 
@@ -662,6 +663,7 @@ typedef struct {
     cgx_gappat *p1d; int32_t *c2d; uint32_t *one2;            /* per distinct pattern: symbols of aXb, token c and one-gap id of aXbXc */
     range *rng0, *rng1, *rng2;
     cgx_lextask *tasks; uint32_t ntask;
+    int gz_level;                                             /* of the context this batch runs on (the host formatter may run later, on the writer thread) */
 } batch;
 
 static void batch_free(batch *b) {
@@ -1081,12 +1083,11 @@ static void *write_worker(void *arg) {
     return NULL;
 }
 /* one file per query (PrintResults.c:434-446); queries are independent, so a pool of host threads formats them */
-static int g_gz_level_host;                               /* set by run_batch before the host formatter path runs */
 static int write_grammars(const batch *b, const char *outdir, int32_t first, uint64_t *lines) {
     int nt = nthreads_host(); if (nt > b->nq) nt = b->nq > 0 ? b->nq : 1;
     { const char *e = getenv("CGX_DIAG_FORMAT_ONLY"); g_diag_format_only = e && *e == '1'; }
     writejob jobs[64]; pthread_t th[64]; int32_t next = 0;
-    for (int t = 0; t < nt; t++) { jobs[t].b = b; jobs[t].outdir = outdir; jobs[t].first = first; jobs[t].next = &next; jobs[t].lines = 0; jobs[t].rc = CGX_OK; jobs[t].gz = g_gz_level_host; }
+    for (int t = 0; t < nt; t++) { jobs[t].b = b; jobs[t].outdir = outdir; jobs[t].first = first; jobs[t].next = &next; jobs[t].lines = 0; jobs[t].rc = CGX_OK; jobs[t].gz = b->gz_level; }
     for (int t = 1; t < nt; t++) if (pthread_create(&th[t], NULL, write_worker, &jobs[t])) return CGX_ERR_NOMEM;
     write_worker(&jobs[0]);
     for (int t = 1; t < nt; t++) pthread_join(th[t], NULL);
@@ -1360,7 +1361,7 @@ static int run_batch(cgx_ctx *ctx, const cgx_corpus *c, batch *b, const char *ou
     }
     LAP("blocks");
     const int devfmt = outdir && cgx__option(ctx, "device_format");
-    g_gz_level_host = (int)cgx__option(ctx, "gz_level");
+    b->gz_level = (int)cgx__option(ctx, "gz_level");
     if (devfmt && (rc = ensure_vocab(ctx, c)) != CGX_OK) return rc;
     LAP("qblocks");
     if ((rc = cgx_gappy_search(ctx)) != CGX_OK) return rc;
@@ -1519,7 +1520,7 @@ static int extract_ids_once(cgx_ctx *ctx, const cgx_corpus *c, const int32_t *qo
     if (!b) return CGX_ERR_NOMEM;
     b->nq = nq; b->ntok = ntok;
     b->qoff = malloc(((size_t)nq + 1) * 4); b->qtok = malloc(((size_t)ntok + 1) * 4);
-    if (!b->qoff || !b->qtok) return CGX_ERR_NOMEM;
+    if (!b->qoff || !b->qtok) { batch_free(b); free(b); return CGX_ERR_NOMEM; }
     const int32_t base = nq ? qoff[0] : 0;                   /* sub-batches start in the middle of the caller's arrays */
     for (int32_t q = 0; q < nq; q++) b->qoff[q] = qoff[q] - base;
     b->qoff[nq] = ntok; if (ntok) memcpy(b->qtok, qtok + base, (size_t)ntok * 4);
@@ -1537,13 +1538,16 @@ int cgx_extract_grammars_ids(cgx_ctx *ctx, const cgx_corpus *c, const int32_t *q
     const int64_t sub = cgx__option(ctx, "sub_batch"), AUTO_BATCH_TOKENS = cgx__option(ctx, "auto_batch_tokens");
     if ((sub <= 0 || sub >= nq) && ntok <= AUTO_BATCH_TOKENS) return extract_ids_once(ctx, c, qoff, nq, qtok, ntok, outdir, first, nrules);
     uint64_t total = 0;
+    /* the offsets may start anywhere in the caller's token array (a shard, cgx_extract_grammars_shard): `ntok` counts
+     * the tokens of these nq queries, so the last query ends at qoff[0] + ntok */
+    const int32_t end = qoff[0] + ntok;
     (void)cgx_set_option(ctx, "prealloc_text", 1);           /* several internal batches: both text slots are going to be needed */
     for (int32_t q0 = 0; q0 < nq;) {
         int32_t q1 = q0;
         if (sub > 0) q1 = q0 + (int32_t)sub < nq ? q0 + (int32_t)sub : nq;
-        else { while (q1 < nq && ((q1 + 1 < nq ? qoff[q1 + 1] : ntok) - qoff[q0] <= AUTO_BATCH_TOKENS || q1 == q0)) q1++; }
+        else { while (q1 < nq && ((q1 + 1 < nq ? qoff[q1 + 1] : end) - qoff[q0] <= AUTO_BATCH_TOKENS || q1 == q0)) q1++; }
         uint64_t n = 0;
-        int32_t t1 = q1 < nq ? qoff[q1] : ntok;
+        int32_t t1 = q1 < nq ? qoff[q1] : end;
         int rc = extract_ids_once(ctx, c, qoff + q0, q1 - q0, qtok, t1 - qoff[q0], outdir, first + q0, &n);
         if (rc != CGX_OK) return rc;
         total += n; q0 = q1;

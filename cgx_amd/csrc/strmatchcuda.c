@@ -6,7 +6,8 @@
  * contiguous query shards balanced by token count; one process per GPU), --index-cache FILE (load the parsed
  * corpus from FILE and the built index -- suffix array, frequent-pair lists, tables -- from FILE.idx if they exist and
  * still match the text files; otherwise parse / build and write them for the next run), --gz LEVEL (1..9: write
- * grammar.<q>.s.gz through zlib instead of plain files).
+ * grammar.<q>.s.gz through zlib instead of plain files), --sub-batch N (queries per internal batch; default: as many as
+ * hold 300 000 query tokens.  Any split writes the same files).
  */
 #include "../../include/cgx.h"
 #include <stdio.h>
@@ -21,13 +22,14 @@ static void print_help(void) {
 }
 
 int main(int argc, char **argv) {
-    int minmatchlen = 1, fingerlen = 10, device = 0, shard = 0, nshard = 1, gz = 0; const char *timefile = NULL, *cache = NULL;
+    int minmatchlen = 1, fingerlen = 10, device = 0, shard = 0, nshard = 1, gz = 0, sub_batch = 0; const char *timefile = NULL, *cache = NULL;
     /* pull the long options out first so getopt sees the reference's grammar only */
     char **av = malloc(sizeof(char *) * (size_t)(argc + 1)); int ac = 0;
     for (int i = 0; i < argc; i++) {
         if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--index-cache") && i + 1 < argc) cache = argv[++i];
         else if (!strcmp(argv[i], "--gz") && i + 1 < argc) { gz = atoi(argv[++i]); if (gz < 1 || gz > 9) print_help(); }
+        else if (!strcmp(argv[i], "--sub-batch") && i + 1 < argc) { sub_batch = atoi(argv[++i]); if (sub_batch < 1) print_help(); }
         else if (!strcmp(argv[i], "--shard") && i + 1 < argc) { if (sscanf(argv[++i], "%d/%d", &shard, &nshard) != 2 || nshard < 1 || shard < 0 || shard >= nshard) print_help(); }
         else av[ac++] = argv[i];
     }
@@ -90,6 +92,7 @@ int main(int argc, char **argv) {
     free(idx);
     uint64_t nrules = 0;
     if (gz) (void)cgx_set_option(ctx, "gz_level", gz);       /* grammar.<q>.s.gz instead of grammar.<q>.s */
+    if (sub_batch) (void)cgx_set_option(ctx, "sub_batch", sub_batch);
     (void)cgx_set_option(ctx, "async_write", 1);             /* large query files run as several internal batches: write batch k while batch k+1 is on the GPU */
     rc = nshard == 1 ? cgx_extract_grammars(ctx, corpus, qry, out, 0, -1, &nrules)
                      : cgx_extract_grammars_shard(ctx, corpus, qry, out, shard, nshard, &nrules);   /* contiguous shards balanced by token count */

@@ -162,6 +162,18 @@ def test_cli_query_shards_union_is_the_whole(cgx, fixtures_dir, tmp_path):
     assert op.sha_dir(str(out), nq) == META["mid"]["grammar"]
 
 
+def test_cli_query_shards_run_in_several_internal_batches(cgx, fixtures_dir, tmp_path):
+    """A shard other than the first whose queries take several internal batches (what a shard of more than 300 000 query
+    tokens does by itself; --sub-batch forces it here): the offsets of a shard start in the middle of the query token array."""
+    fx = make_fixture("mid", fixtures_dir); out = tmp_path / "sh"; out.mkdir(); exe = os.path.join(ROOT, "bin", "strmatchcuda")
+    for i in range(3):
+        r = subprocess.run([exe, "--shard", "%d/3" % i, "--sub-batch", "4"] + op.fixture_args(fx) + [str(out)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+    nq = META["mid"]["spec"][2]
+    assert sorted(os.listdir(out)) == sorted("grammar.%d.s" % q for q in range(nq))
+    assert op.sha_dir(str(out), nq) == META["mid"]["grammar"]
+
+
 @pytest.mark.parametrize("name", ["tiny", "mid"])
 def test_every_stage_matches_the_oracle(name, cgx, oracle_bin, fixtures_dir, tmp_path):
     fx = make_fixture(name, fixtures_dir); dump = str(tmp_path / "d.bin")
