@@ -41,7 +41,7 @@ FETCH_DTYPES = {
     "s1": GAPSEARCH, "hits1": HIT1, "g2": TWOGAPPY, "c2": np.int32, "pid2": np.uint32, "s2": TWOGAPSEARCH, "hits2": HIT2,
     "r0": RULE0, "r1": RULE1, "r2": RULE2, "counts": np.uint32, "p1d": GAPPAT, "c2d": np.int32, "one2": np.uint32,
     "lex0": LEXENT, "lex1": LEXENT, "lex2": LEXENT, "rng0": np.int32, "rng1": np.int32, "rng2": np.int32,
-    "blocks": BLOCK, "qb_off": np.uint32, "qb_ids": np.uint32,
+    "blocks": BLOCK, "qb_off": np.uint32, "qb_ids": np.uint32, "qo_off": np.uint32, "qo_ids": np.uint32, "qt_off": np.uint32, "qt_ids": np.uint32,
 }
 COUNT_NAMES = ["e1", "d1", "h1", "e2", "d2", "h2", "g", "n0", "n1", "n2", "sep1", "sep2a", "sep2b", "nphits", "guard_exits", "last"]
 
@@ -299,6 +299,13 @@ class Extractor:
         self.lib.cgx_format.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
         self._chk(self.lib.cgx_format(self.h, C.byref(nb), C.byref(nl), C.byref(slot)), "cgx_format")
         return int(nb.value), int(nl.value), int(slot.value)
+
+    def count_rules(self):
+        """cgx_format without a text slot: builds the per-query pattern lists ("qo_*", "qt_*") and counts the rule lines."""
+        nl = C.c_uint64()
+        self.lib.cgx_format.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
+        self._chk(self.lib.cgx_format(self.h, None, C.byref(nl), None), "cgx_format")
+        return int(nl.value)
 
     def text(self, slot, nq):
         """The unique text of the slot and the piece lists: (text bytes, qseg u64[nq+1], seg_off u64[nseg], seg_len u32[nseg], qtext u64[nq+1])."""

@@ -74,7 +74,7 @@ struct cgx_ctx {
     // ---- device text formatter ----
     char *d_spool = nullptr, *d_tpool = nullptr; uint32_t *d_soff = nullptr, *d_toff = nullptr; uint32_t vocab_ns = 0, vocab_nt = 0;
     float *d_aa = nullptr, *d_bb = nullptr, *d_fs = nullptr;
-    uint32_t nqb = 0;                                         // entries of d_qb_ids
+    uint32_t nqb = 0, nqo = 0, nqt = 0;                       // entries of d_qb_ids / d_qo_ids / d_qt_ids
     uint32_t *d_qb_off = nullptr, *d_qb_ids = nullptr, *d_qo_off = nullptr, *d_qo_ids = nullptr, *d_qt_off = nullptr, *d_qt_ids = nullptr;
     char *d_text[2] = {nullptr, nullptr}; size_t text_cap[2] = {0, 0}; uint64_t text_bytes[2] = {0, 0}; uint64_t *d_qtext[2] = {nullptr, nullptr}; int32_t text_nq[2] = {0, 0}; int text_sel = 0;
     uint64_t *d_seg_off[2] = {nullptr, nullptr}, *d_qseg[2] = {nullptr, nullptr}; uint32_t *d_seg_len[2] = {nullptr, nullptr}; uint64_t text_nseg[2] = {0, 0}, text_total[2] = {0, 0};   // pieces of the unique text per query

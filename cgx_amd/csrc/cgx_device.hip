@@ -349,7 +349,7 @@ static void free_batch(cgx_ctx *c) {
     dfree(c->d_qoff); dfree(c->d_qtok); dfree(c->d_tok2q); dfree(c->d_lm); dfree(c->d_up); dfree(c->d_down);
     dfree(c->d_g1); dfree(c->d_p1); dfree(c->d_pid1); dfree(c->d_s1); dfree(c->d_hits1);
     dfree(c->d_g2); dfree(c->d_c2); dfree(c->d_pid2); dfree(c->d_s2); dfree(c->d_hits2); dfree(c->d_p1d); dfree(c->d_c2d); dfree(c->d_one2);
-    dfree(c->d_qb_off); dfree(c->d_qb_ids); dfree(c->d_qo_off); dfree(c->d_qo_ids); dfree(c->d_qt_off); dfree(c->d_qt_ids);
+    dfree(c->d_qb_off); dfree(c->d_qb_ids); dfree(c->d_qo_off); dfree(c->d_qo_ids); dfree(c->d_qt_off); dfree(c->d_qt_ids); c->nqo = c->nqt = 0;
     dfree(c->d_blocks); dfree(c->d_r0); dfree(c->d_r1); dfree(c->d_r2); dfree(c->d_lex0); dfree(c->d_lex1); dfree(c->d_lex2); dfree(c->d_rng0); dfree(c->d_rng1); dfree(c->d_rng2); c->nl0 = c->nl1 = c->nl2 = 0;
     c->e1 = c->d1 = c->h1 = c->e2 = c->d2 = c->h2 = c->g = c->n0 = c->n1 = c->n2 = c->sep1 = c->sep2a = c->sep2b = 0;
     c->guard_exits = 0;
@@ -479,6 +479,8 @@ extern "C" int64_t cgx_fetch(cgx_ctx *ctx, const char *name, void *dst, int64_t 
     ENT("lex0", ctx->d_lex0, ctx->nl0, cgx_lexent) ENT("lex1", ctx->d_lex1, ctx->nl1, cgx_lexent) ENT("lex2", ctx->d_lex2, ctx->nl2, cgx_lexent)
     ENT("r0", ctx->d_r0, ctx->n0, cgx_rule0) ENT("r1", ctx->d_r1, ctx->n1, cgx_rule1) ENT("r2", ctx->d_r2, ctx->n2, cgx_rule2)
     ENT("blocks", ctx->d_blocks, ctx->g, cgx_block) ENT("qb_off", ctx->d_qb_off, ctx->d_qb_off ? (size_t)ctx->nq + 1 : 0, uint32_t) ENT("qb_ids", ctx->d_qb_ids, ctx->nqb, uint32_t)
+    ENT("qo_off", ctx->d_qo_off, ctx->d_qo_off ? (size_t)ctx->nq + 1 : 0, uint32_t) ENT("qo_ids", ctx->d_qo_ids, ctx->nqo, uint32_t)      /* per-query pattern lists: after cgx_format */
+    ENT("qt_off", ctx->d_qt_off, ctx->d_qt_off ? (size_t)ctx->nq + 1 : 0, uint32_t) ENT("qt_ids", ctx->d_qt_ids, ctx->nqt, uint32_t)
 #undef ENT
     if (s == "counts") { bytes = sizeof counts; if (!dst) return bytes; if (cap < bytes) return CGX_ERR_ARG; memcpy(dst, counts, sizeof counts); return bytes; }
     if (bytes < 0) { snprintf(ctx->err, sizeof ctx->err, "unknown result %s", name); return CGX_ERR_ARG; }

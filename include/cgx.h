@@ -131,7 +131,9 @@ void cgx_pinned_free(void *p);
 /* ---- results: copy a named device/host result into caller memory.
  * dst == NULL returns the size in bytes; otherwise returns bytes written, or < 0. Names:
  *   "sa" "tokstart" "freq" "pidx" "miss" "phit_start" "phit_len"
- *   "lm" "up" "down" "g1" "p1" "pid1" "s1" "hits1" "g2" "c2" "pid2" "s2" "hits2" "r0" "r1" "r2" "p1d" "c2d" "one2" "lex0" "lex1" "lex2" "rng0" "rng1" "rng2" (id -> first,last line; -1,-1 when empty) "counts" */
+ *   "lm" "up" "down" "g1" "p1" "pid1" "s1" "hits1" "g2" "c2" "pid2" "s2" "hits2" "r0" "r1" "r2" "p1d" "c2d" "one2" "lex0" "lex1" "lex2" "rng0" "rng1" "rng2" (id -> first,last line; -1,-1 when empty) "counts"
+ *   "blocks" "qb_off" "qb_ids" (after cgx_make_blocks), "qo_off" "qo_ids" "qt_off" "qt_ids" (after cgx_format: per query, the ascending ids of its
+ *   one-gap / two-gap patterns, CSR; oneGapQueryWithID / twoGapQueryWithID, SuffixArray.cu:1658-1719, 2058-2097) */
 int64_t cgx_fetch(cgx_ctx *ctx, const char *name, void *dst, int64_t cap);
 /* same, but into page-locked memory owned by the context (DMA speed); the pointer stays valid until
  * cgx_pinned_next_batch has been called twice.  Returns CGX_ERR_NOMEM (and *out = NULL) when pinned memory is unavailable. */

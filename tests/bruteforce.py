@@ -213,3 +213,465 @@ def check_batch(c, sa, freq, phits, s1, p1d, hits1, s2, c2d, hits2, blocks, r0, 
     got_r0 = sorted((int(r["block"]), int(r["tar_start"]), int(r["tar_end"])) for r in r0)
     assert got_r0 == contiguous_rules(c, sa, blocks), "ab rules"
     return checked + len(blocks)
+
+
+# =====================================================================================================================
+# Round 3: the remaining stages without a reference-held pin -- query-side enumeration, the extension rules
+# (Xab / abX / XabX of a contiguous phrase, XaXb / aXbX of a one-gap pattern) and the MaxLex features.
+# Written from the reference text itself (file:line below) and SURVEY Appendix B, NOT from cgx_rules.h and NOT from
+# oracle/: a separate restatement in another language and another shape (per-occurrence generators over python ints).
+# =====================================================================================================================
+import ctypes as _C
+import ctypes.util as _Cu
+
+_libm = _C.CDLL(_Cu.find_library("m") or "libm.so.6")
+_libm.log10f.restype = _C.c_float; _libm.log10f.argtypes = [_C.c_float]
+F32 = np.float32
+MAX_SYMBOLS = 5
+
+
+def corpus_ngrams(c, maxn=5):
+    """every phrase of <= maxn tokens that occurs inside a sentence, as a set of tuples"""
+    s = [int(x) for x in c.s]; out = set()
+    for i, t in enumerate(s):
+        if t < 2:
+            continue
+        g = ()
+        for l in range(maxn):
+            if i + l >= len(s) or s[i + l] < 2:
+                break
+            g = g + (s[i + l],); out.add(g)
+    return out
+
+
+def longest_matches(grams, qoff, qtok, k1_limit=128, cap=5):
+    """lm[t] = min(cap, longest prefix of q[t..end of sentence) that occurs in the corpus), OOV (-1) ends a match;
+    0 for tokens at in-sentence position >= k1_limit (K1 launches 128 threads per sentence, SuffixArray.cu:1374-1378)"""
+    T = len(qtok); lm = [0] * T; qoff = list(qoff) + [T]
+    for q in range(len(qoff) - 1):
+        for t in range(qoff[q], qoff[q + 1]):
+            if t - qoff[q] >= k1_limit:
+                continue
+            g = (); l = 0
+            while l < cap and t + l < qoff[q + 1] and qtok[t + l] >= 2 and (g + (int(qtok[t + l]),)) in grams:
+                g = g + (int(qtok[t + l]),); l += 1
+            lm[t] = l
+    return lm
+
+
+def enumerate_onegap(qoff, qtok, lm):
+    """oneGapEnumeration (SuffixArray.cu:928-1039): instances (t, a_len, s, b_len) and their symbol tuples (gap = -1)."""
+    T = len(qtok); ends = list(qoff[1:]) + [T]; inst = []
+    for q in range(len(qoff)):
+        end = ends[q]
+        for t in range(qoff[q], end):
+            if t >= T - 1 or t == end - 1 or t == end - 2:
+                continue
+            for al in range(1, lm[t] + 1):
+                s = t + al + 1
+                while s < end and s - t <= MAX_SPAN:
+                    if qtok[s] != -1:
+                        bl = 1
+                        while al + 1 + bl <= MAX_SYMBOLS and bl <= lm[s] and s - t + bl - 1 <= MAX_SPAN:
+                            pat = tuple(int(x) for x in qtok[t:t + al]) + (-1,) + tuple(int(x) for x in qtok[s:s + bl])
+                            inst.append((q, t, al, s, bl, pat)); bl += 1
+                    s += 1
+    return inst
+
+
+def onegap_ids(inst):
+    """distinct patterns in the order of oneGapEnumerationCompare (SuffixArray.cu:51-67): number of symbols, then the
+    symbols left to right as ints (the gap, -1, sorts before every token)"""
+    pats = sorted(set(p for *_, p in inst), key=lambda p: (len(p), p))
+    return pats, {p: i for i, p in enumerate(pats)}
+
+
+def enumerate_twogap(qoff, qtok, lm, inst, idof, has_hits):
+    """twoGapEnumeration (SuffixArray.cu:816-926): for every instance of a one-gap pattern that has corpus hits, the
+    tokens c right of it (second gap >= 1): instances (query, one-gap id, position of c, (c,))."""
+    T = len(qtok); ends = list(qoff[1:]) + [T]; out = []
+    for q, t, al, s, bl, pat in inst:
+        one = idof[pat]
+        limit = MAX_SYMBOLS - 2 - al - bl
+        if not has_hits[one] or limit < 1:
+            continue
+        last = s + bl - 1                                     # last token of b
+        if last > T - 1:
+            continue
+        end = ends[q]
+        for sc in range(last + 2, end):
+            it = 1
+            while it <= limit and it <= lm[sc] and sc - t + it - 1 <= MAX_SPAN:
+                out.append((q, one, sc, tuple(int(x) for x in qtok[sc:sc + it]))); it += 1
+    return out
+
+
+def twogap_ids(inst2):
+    """twoGapEnumerationCompare (SuffixArray.cu:31-49): one-gap id, number of symbols of c, symbols"""
+    pats = sorted(set((one, c) for _, one, _, c in inst2), key=lambda x: (x[0], len(x[1]), x[1]))
+    return pats, {p: i for i, p in enumerate(pats)}
+
+
+def per_query_ids(nq, pairs):
+    """oneGapQueryWithID / twoGapQueryWithID (SuffixArray.cu:1679-1718, 2058-2093): walking the instances in pattern
+    order, a query gets each id once -> ascending distinct ids per query"""
+    out = [set() for _ in range(nq)]
+    for q, i in pairs:
+        out[q].add(i)
+    return [sorted(x) for x in out]
+
+
+# ---- alignment helpers of the extension rules ------------------------------------------------------------------------
+def _back(c, ts, te, s_chk, e_chk, src0):
+    """consistent() (ExtractPair.cu:103-133): the aligned target words of [ts,te] project onto exactly [s_chk,e_chk]"""
+    lo, hi = 255, 0
+    for j in range(ts, te + 1):
+        l, r = int(c.ltar[j]), int(c.rtar[j])
+        if l != 255 and r != 255:
+            lo = min(lo, l); hi = max(hi, r)
+    return src0 + lo == s_chk and src0 + hi == e_chk
+
+
+class _Side:
+    """a gap growing one token at a time away from a phrase: running [min L, max R] of its aligned tokens"""
+    def __init__(self):
+        self.lo, self.hi = 255, 0
+
+    def add(self, c, k):
+        if not c.aligned(k):
+            return False
+        self.lo = min(self.lo, int(c.L[k])); self.hi = max(self.hi, int(c.R[k]))
+        return True
+
+
+def block_extension_rules(c, cs, m):
+    """Xab / abX / XabX of ONE occurrence (start cs, m tokens) of a contiguous phrase, extractConsistentPairs_Gappy
+    (ExtractPair.cu:1162-1791).  Returns (xab, abx, xabx): each None or the rule tuple (tstart, end, gap1, gap1_1[, gap2, gap2_1])."""
+    ender = cs + m - 1
+    src0, tb = c.sentence(cs)
+    ab = True; open_abx = True; open_xab = True                # "NoSuccess" flags: the side has not emitted yet
+    mn, mx = 255, 0
+    for k in range(cs, ender + 1):                              # :1176-1212
+        if not c.aligned(k):
+            if k == cs or k == ender:
+                ab = False
+                if k == cs:
+                    open_abx = False
+                else:
+                    open_xab = False
+        else:
+            mn = min(mn, int(c.L[k])); mx = max(mx, int(c.R[k]))
+    xab = abx = xabx = True
+    if mn > mx or mx - mn >= MAX_SPAN:                          # :1218-1224
+        xab = abx = xabx = False
+    if m + 1 > MAX_SYMBOLS:                                     # :1263-1269
+        xab = abx = False
+    if m + 2 > MAX_SYMBOLS:
+        xabx = False
+    left, right = _Side(), _Side(); nl = nr = 0                 # nl / nr = XabCount / abXCount: largest gap size validated so far
+    r_xab = r_abx = r_xabx = None
+    i = 1
+    while m + i <= MAX_SPAN and (open_abx or open_xab or xabx):
+        # ---- grow the left gap to i tokens (:1284-1399)
+        if xab and cs - i >= 0 and c.s[cs - i] >= 2:
+            ok = left.add(c, cs - i)
+            if not ok and i == 1:
+                xab = False; xabx = False
+            if left.hi - left.lo >= MAX_SPAN:
+                ok = False; xab = False
+            if ok:
+                g = (tb + left.lo, tb + left.hi)
+                ok = _back(c, g[0], g[1], cs - i, cs - 1, src0)
+                if ok:
+                    nl = i
+            if open_xab and ok:
+                ts = tb + min(left.lo, mn); te = tb + max(left.hi, mx)
+                if te - ts >= MAX_SPAN:
+                    ok = False; xab = False
+                if ok:
+                    ok = _back(c, ts, te, cs - i, ender, src0)
+                if ok:
+                    r_xab = (ts, te - ts, g[0] - ts, g[1] - ts); open_xab = False
+        else:
+            xab = False
+        # ---- grow the right gap to i tokens (:1404-1509)
+        if abx and c.s[ender + i] >= 2:
+            ok = right.add(c, ender + i)
+            if not ok and i == 1:
+                abx = False; xabx = False
+            if right.hi - right.lo >= MAX_SPAN:
+                ok = False; abx = False
+            if ok:
+                g = (tb + right.lo, tb + right.hi)
+                ok = _back(c, g[0], g[1], ender + 1, ender + i, src0)
+                if ok:
+                    nr = i
+            if open_abx and ok:
+                ts = tb + min(right.lo, mn); te = tb + max(right.hi, mx)
+                if te - ts >= MAX_SPAN:
+                    ok = False; abx = False
+                if ok:
+                    ok = _back(c, ts, te, cs, ender + i, src0)
+                if ok:
+                    r_abx = (ts, te - ts, g[0] - ts, g[1] - ts); open_abx = False
+        else:
+            abx = False
+        # ---- both gaps (:1514-1777): the side validated at THIS size is paired with every size of the other side up to
+        # its best so far, smallest first
+        if xabx and (abx or xab):
+            if nl == i:
+                oth = _Side(); ic = 1
+                while xabx and ic <= nr:
+                    if ic + nl + m > MAX_SPAN:
+                        break
+                    ok = oth.add(c, ender + ic)
+                    if ok and oth.hi - oth.lo >= MAX_SPAN:
+                        break
+                    if ok:
+                        g2 = (tb + oth.lo, tb + oth.hi)
+                        ok = _back(c, g2[0], g2[1], ender + 1, ender + ic, src0)
+                    if ok:
+                        ts = tb + min(oth.lo, left.lo, mn); te = tb + max(oth.hi, left.hi, mx)
+                        if te - ts >= MAX_SPAN:
+                            break
+                        if _back(c, ts, te, cs - nl, ender + ic, src0):
+                            r_xabx = (ts, te - ts, tb + left.lo - ts, tb + left.hi - ts, g2[0] - ts, g2[1] - ts); xabx = False
+                    ic += 1
+            if xabx and nr == i:
+                oth = _Side(); ic = 1
+                while xabx and ic <= nl:
+                    if ic + nr + m > MAX_SPAN:
+                        break
+                    ok = oth.add(c, cs - ic)
+                    if ok and oth.hi - oth.lo >= MAX_SPAN:
+                        break
+                    if ok:
+                        g1 = (tb + oth.lo, tb + oth.hi)
+                        ok = _back(c, g1[0], g1[1], cs - ic, cs - 1, src0)
+                    if ok:
+                        ts = tb + min(oth.lo, right.lo, mn); te = tb + max(oth.hi, right.hi, mx)
+                        if te - ts >= MAX_SPAN:
+                            break
+                        if _back(c, ts, te, cs - ic, ender + nr, src0):
+                            r_xabx = (ts, te - ts, g1[0] - ts, g1[1] - ts, tb + right.lo - ts, tb + right.hi - ts); xabx = False
+                    ic += 1
+        else:
+            xabx = False
+        if not xabx:                                            # :1781-1788
+            if not xab:
+                open_xab = False
+            if not abx:
+                open_abx = False
+        i += 1
+    return r_xab, r_abx, r_xabx
+
+
+def block_rules(c, sa, blocks):
+    """all Xab / abX (one-gap ids b / G+b) and XabX (two-gap id b) rules of the sampled occurrences of every block"""
+    G = len(blocks); r1 = []; r2 = []
+    for bn, b in enumerate(blocks):
+        n = int(b["end"]) - int(b["start"]) + 1; m = int(b["matchlen"])
+        for x in sample_indices(n, 300):
+            xab, abx, xabx = block_extension_rules(c, int(sa[int(b["start"]) + x]), m)
+            if xab:
+                r1.append((bn,) + xab)
+            if abx:
+                r1.append((G + bn,) + abx)
+            if xabx:
+                r2.append((bn,) + xabx)
+    return sorted(r1), sorted(r2)
+
+
+def onegap_outer_rules(c, st, l, al, bl):
+    """XaXb / aXbX of ONE hit (start st, span l+1) of a X b, extractConsistentPairs_OneGap (ExtractPair.cu:540-884).
+    Returns (xaxb, axbx): None or (tstart, end, gap1, gap1_1, gap2, gap2_1)."""
+    ender = st + l; gs, ge = st + al, ender - bl
+    if not (c.aligned(gs) and c.aligned(ge)):                  # checkBoundaryFast (:135-194): cannot happen for a hit
+        return None, None
+    src0, tb = c.sentence(gs)
+    glo, ghi = c.target_span(gs, ge)
+    if ghi - glo >= MAX_SPAN:
+        return None, None
+    gap = (tb + glo, tb + ghi)
+    # checkBoundary (:252-342): whole span; codes 2 / 3 / 4 = first / last / both edge tokens unaligned
+    left = c.aligned(ender); right = c.aligned(st)              # code 3 or 4 stops XaXb, code 2 or 4 stops aXbX
+    mn, mx = c.target_span(st, ender)
+    if al + bl + 2 > MAX_SYMBOLS:
+        return None, None
+    lft, rgt = _Side(), _Side(); xaxb = axbx = None
+    i = 1
+    while l + 1 + i <= MAX_SPAN and (left or right):
+        if left and st - i >= 0 and c.s[st - i] >= 2:
+            ok = lft.add(c, st - i)
+            if not ok and i == 1:
+                left = False
+            if lft.hi - lft.lo >= MAX_SPAN:
+                ok = False; left = False
+            if ok:
+                g = (tb + lft.lo, tb + lft.hi)
+                ok = _back(c, g[0], g[1], st - i, st - 1, src0)
+            if ok:
+                ts = tb + min(lft.lo, mn); te = tb + max(lft.hi, mx)
+                if te - ts >= MAX_SPAN:
+                    ok = False; left = False
+                if ok and _back(c, ts, te, st - i, ender, src0):
+                    xaxb = (ts, te - ts, g[0] - ts, g[1] - ts, gap[0] - ts, gap[1] - ts); left = False
+        else:
+            left = False
+        if right and c.s[ender + i] >= 2:
+            ok = rgt.add(c, ender + i)
+            if not ok and i == 1:
+                right = False
+            if rgt.hi - rgt.lo >= MAX_SPAN:
+                ok = False; right = False
+            if ok:
+                g = (tb + rgt.lo, tb + rgt.hi)
+                ok = _back(c, g[0], g[1], ender + 1, ender + i, src0)
+            if ok:
+                ts = tb + min(rgt.lo, mn); te = tb + max(rgt.hi, mx)
+                if te - ts >= MAX_SPAN:
+                    ok = False; right = False
+                if ok and _back(c, ts, te, st, ender + i, src0):
+                    axbx = (ts, te - ts, gap[0] - ts, gap[1] - ts, g[0] - ts, g[1] - ts); right = False
+        else:
+            right = False
+        i += 1
+    return xaxb, axbx
+
+
+def outer_rules(c, hits_of, s1, D1):
+    """XaXb (two-gap id = one-gap id) and aXbX (D1 + id) of the sampled hits of the given patterns"""
+    out = []
+    for pid, hits in hits_of.items():
+        al, bl = int(s1[pid]["a_len"]), int(s1[pid]["b_len"])
+        for x in sample_indices(len(hits), 65):
+            st, l = hits[x]
+            a, b = onegap_outer_rules(c, st, l, al, bl)
+            if a:
+                out.append((pid,) + a)
+            if b:
+                out.append((D1 + pid,) + b)
+    return sorted(out)
+
+
+# ---- MaxLex (lexicalTaskMaxEF, ExtractPair.cu:2144-2432) -------------------------------------------------------------
+class LexTable:
+    def __init__(self, lexk, lexv):
+        self.t = {}
+        for k, v in zip(lexk, lexv):
+            self.t.setdefault((int(k["src"]), int(k["tgt"])), (F32(v["v1"]), F32(v["v2"])))
+
+    def get(self, s, t, which):
+        """value 1 or 2 of row (s, t); an absent row scores 0 (searchLexFile, :2108-2142)"""
+        v = self.t.get((int(s), int(t)))
+        return F32(0) if v is None else v[which - 1]
+
+
+def maxlex(table, tstr, src, tstart, end, gaps):
+    """(MaxLexFgivenE, MaxLexEgivenF) in float32: per source word the best value-2 score over the target words outside the
+    gaps and NULL (-1), per target word outside the gaps the best value-1 score over NULL and the source words; each word
+    adds -log10f(best) or 99 when nothing scores.  `gaps` = [(first, last)] relative to tstart."""
+    tw = [j for j in range(tstart, tstart + end + 1) if not any(tstart + a <= j <= tstart + b for a, b in gaps)]
+    fe = F32(0); ef = F32(0)
+    for s in src:
+        best = F32(0)
+        if tw:
+            best = max(best, table.get(s, -1, 2))
+        for j in tw:
+            best = max(best, table.get(s, int(tstr[j]), 2))
+        fe = F32(fe + (F32(-_libm.log10f(_C.c_float(best))) if best > 0 else F32(99.0)))
+    for j in tw:
+        best = F32(0)
+        if len(src):
+            best = max(best, table.get(-1, int(tstr[j]), 1))
+        for s in src:
+            best = max(best, table.get(s, int(tstr[j]), 1))
+        ef = F32(ef + (F32(-_libm.log10f(_C.c_float(best))) if best > 0 else F32(99.0)))
+    return fe, ef
+
+
+def lexline_source(kind, lid, G, D1, D2, blocks, c, p1d, c2d, one2):
+    """source-side terminals of lexicon line id `lid` (converted ids: ExtractPair.c:724-728, 1000-1006, 609-611)"""
+    def blk(b):
+        return [int(x) for x in c.s[int(blocks[b]["string_start"]):int(blocks[b]["string_start"]) + int(blocks[b]["matchlen"])]]
+    def pat(p):
+        return [int(x) for x in p1d[p]["pat"][:int(p1d[p]["number"])] if int(x) >= 0]
+    if kind == 0:
+        return blk(lid)
+    if kind == 1:
+        return blk(lid) if lid < G else blk(lid - G) if lid < 2 * G else pat(lid - 2 * G)
+    if lid < G:
+        return blk(lid)
+    if lid < G + D2:
+        return pat(int(one2[lid - G])) + [int(c2d[lid - G])]
+    return pat(lid - G - D2) if lid < G + D2 + D1 else pat(lid - G - D2 - D1)
+
+
+def _t1(r):
+    return (int(r["id"]), int(r["tstart"]), int(r["end"]), int(r["gap1"]), int(r["gap1_1"]))
+
+
+def _t2(r):
+    return _t1(r) + (int(r["gap2"]), int(r["gap2_1"]))
+
+
+def check_query_side(c, qoff, qtok, lm, g1_count, s1, p1d, qone, g2_count, s2, c2d, qtwo, k1_limit=128):
+    """Longest matches, one-/two-gap enumeration, distinct-pattern ids and per-query id lists of a batch against the
+    definitions.  `qone` / `qtwo`: list (per query) of id lists.  Returns (#one-gap patterns, #two-gap patterns)."""
+    qoff = [int(x) for x in qoff]; qtok = [int(x) for x in qtok]; nq = len(qoff)
+    want_lm = longest_matches(corpus_ngrams(c), qoff, qtok, k1_limit)
+    assert want_lm == [min(int(x), 5) for x in lm], "longest matches"
+    inst = enumerate_onegap(qoff, qtok, want_lm)
+    pats, idof = onegap_ids(inst)
+    assert len(inst) == g1_count and len(pats) == len(s1), ("one-gap enumeration", len(inst), g1_count, len(pats), len(s1))
+    for i, p in enumerate(pats):
+        assert tuple(int(x) for x in p1d[i]["pat"][:int(p1d[i]["number"])]) == p, ("one-gap pattern id", i)
+        s = s1[i]; t, al, bl, gp = int(s["qrystart"]), int(s["a_len"]), int(s["b_len"]), int(s["gap"])
+        assert tuple(qtok[t:t + al]) + (-1,) + tuple(qtok[t + al + gp:t + al + gp + bl]) == p, ("representative instance", i)
+    assert per_query_ids(nq, [(q, idof[p]) for q, *_, p in inst]) == [list(x) for x in qone], "per-query one-gap ids"
+    has = [int(s["sa_start"]) != -1 for s in s1]
+    inst2 = enumerate_twogap(qoff, qtok, want_lm, inst, idof, has)
+    pats2, idof2 = twogap_ids(inst2)
+    assert len(inst2) == g2_count and len(pats2) == len(s2), ("two-gap enumeration", len(inst2), g2_count, len(pats2), len(s2))
+    for i, (one, cc) in enumerate(pats2):
+        assert int(s2[i]["blockid"]) == one and (int(c2d[i]),) == cc and int(qtok[int(s2[i]["gap2"])]) == cc[0], ("two-gap pattern id", i)
+    assert per_query_ids(nq, [(q, idof2[(one, cc)]) for q, one, sc, cc in inst2]) == [list(x) for x in qtwo], "per-query two-gap ids"
+    return len(pats), len(pats2)
+
+
+def hit_lists(s1, hits1, pidx, phit_start, phit_len):
+    """pattern id -> [(start, span - 1)] as the extraction stage sees them: a marker record stands for its frequent-pair list"""
+    pidx = np.asarray(pidx, np.int64).reshape(-1, 2); out = {}
+    for pid in range(len(s1)):
+        a = int(s1[pid]["sa_start"])
+        if a == -1:
+            continue
+        sl = hits1[a:int(s1[pid]["sa_end"]) + 1]
+        if len(sl) == 1 and int(sl[0]["length"]) == 0:
+            lo, hi = pidx[int(sl[0]["str_position"])]
+            out[pid] = [(int(phit_start[k]), int(phit_len[k])) for k in range(lo, hi + 1)]
+        else:
+            out[pid] = [(int(x["str_position"]), int(x["length"])) for x in sl]
+    return out
+
+
+def check_extension_rules(c, sa, blocks, s1, hits_of, r1, sep1, r2, sep2a, sep2b):
+    """Xab / abX (r1[:sep1]), XabX (r2[:sep2a]) and XaXb / aXbX (r2[sep2b:]) against the definitions."""
+    w1, w2 = block_rules(c, sa, blocks)
+    assert sorted(_t1(r) for r in r1[:sep1]) == w1, "Xab / abX rules"
+    assert sorted(_t2(r) for r in r2[:sep2a]) == w2, "XabX rules"
+    assert sorted(_t2(r) for r in r2[sep2b:]) == outer_rules(c, hits_of, s1, len(s1)), "XaXb / aXbX rules"
+    return len(w1) + len(w2) + len(r2) - sep2b
+
+
+def check_maxlex_lines(c, tstr, lexk, lexv, lines, G, D1, D2, blocks, p1d, c2d, one2):
+    """(fe, ef) of every device lexicon line (cgx_lexent arrays for kind 0, 1, 2) against the float32 definition, bit for bit."""
+    tab = LexTable(lexk, lexv); n = 0
+    for kind, arr in lines.items():
+        for e in arr:
+            gaps = [] if kind == 0 else [(int(e["gap1"]), int(e["gap1_1"]))] if kind == 1 else [(int(e["gap1"]), int(e["gap1_1"])), (int(e["gap2"]), int(e["gap2_1"]))]
+            src = lexline_source(kind, int(e["id"]), G, D1, D2, blocks, c, p1d, c2d, one2)
+            fe, ef = maxlex(tab, tstr, src, int(e["tstart"]), int(e["end"]), gaps)
+            assert fe.tobytes() == np.float32(e["fe"]).tobytes() and ef.tobytes() == np.float32(e["ef"]).tobytes(), ("MaxLex", kind, int(e["id"]), fe, e["fe"], ef, e["ef"])
+            n += 1
+    return n

@@ -1,7 +1,8 @@
-"""Third opinion for the stages whose oracle cannot be pinned against reference object code (one-/two-gap hit sets,
-frequent-pair lists, ab / aXb / aXbXc rules): tests/bruteforce.py restates the DEFINITIONS of those results (SURVEY.md
-Appendix B) in numpy, independently of both the kernels and oracle/.  CPU: the oracle against the definitions; GPU: the
-HIP path against the definitions."""
+"""Third opinion for the stages whose oracle cannot be pinned against reference object code (longest matches, query-side
+enumeration and pattern ids, one-/two-gap hit sets, frequent-pair lists, every rule family -- ab, Xab, abX, XabX, aXb, XaXb,
+aXbX, aXbXc -- and the MaxLex features): tests/bruteforce.py restates the DEFINITIONS of those results (SURVEY.md
+Appendix B, the reference text) in numpy / python, independently of both the kernels and oracle/.  CPU: the oracle against the
+definitions; GPU: the HIP path against the definitions."""
 import os
 
 import numpy as np
@@ -35,6 +36,64 @@ def test_oracle_agrees_with_the_definitions(oracle_bin, fixtures_dir, tmp_path):
     rng = np.random.default_rng(3)
     for pre in rng.integers(0, 10000, 300):
         assert ph.get(int(pre), []) == bf.frequent_pair_list(c, freq[pre // 100], freq[pre % 100]), pre
+
+
+def _lists(flat, nq):
+    out = []; p = 0
+    for _ in range(nq):
+        k = int(flat[p]); out.append([int(x) for x in flat[p + 1:p + 1 + k]]); p += 1 + k
+    return out
+
+
+def _csr(off, ids):
+    return [[int(x) for x in ids[int(off[q]):int(off[q + 1])]] for q in range(len(off) - 1)]
+
+
+@pytest.mark.parametrize("name", ["tiny", "toy", "mid"])
+def test_oracle_agrees_with_the_definitions_of_the_remaining_stages(name, oracle_bin, fixtures_dir, tmp_path):
+    """Query-side enumeration + ids + per-query lists, the extension rules (Xab, abX, XabX, XaXb, aXbX) and MaxLex: every
+    block, every pattern, every lexical task of the fixture."""
+    fx = make_fixture(name, fixtures_dir); dump = str(tmp_path / "d.bin")
+    op.run_oracle(oracle_bin, fx, str(tmp_path / "o"), dump)
+    d = op.read_dump(dump); h = d["hdr"]; n, nt = h["n"], h["nt"]; nq = h["nq"]
+    c = bf.Corpus(d["str"][:n], d["rlp"], d["ltar"], d["rtar"])
+    p1d = d["p1"][d["s1"]["position"]]; c2d = d["p2"]["pat"][:, 0][d["s2"]["position"]]
+    a, b = bf.check_query_side(c, d["qoff"][:-1], d["qtok"], d["lm"], len(d["g1"]), d["s1"], p1d, _lists(d["qone"], nq), len(d["g2"]), d["s2"], c2d, _lists(d["qtwo"], nq))
+    assert (a, b) == (h["d1"], h["d2"])
+    hits_of = bf.hit_lists(d["s1"], d["hits1"], d["pidx"], d["phits"]["start"], d["phits"]["length"])
+    assert bf.check_extension_rules(c, d["sa"], d["blocks"], d["s1"], hits_of, d["r1"], h["sep1"], d["r2"], h["sep2a"], h["sep2b"]) > 1000
+    tab = bf.LexTable(d["lexk"], d["lexv"]); nl1, nl2 = len(d["lex1_int"]) // 4, len(d["lex2_int"]) // 4
+    for i, t in enumerate(d["tasks"]):
+        g1, g2 = (int(t["gap1"]), int(t["gap1_1"])), (int(t["gap2"]), int(t["gap2_1"]))
+        fe, ef = bf.maxlex(tab, d["tstr"], [int(x) for x in t["src"][:int(t["nsrc"])]], int(t["tstart"]), int(t["end"]), [g1] if i < nl1 else [g1, g2] if i < nl1 + nl2 else [])
+        assert fe.tobytes() == d["task_fe"][i].tobytes() and ef.tobytes() == d["task_ef"][i].tobytes(), ("MaxLex task", i)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["tiny", "toy", "mid"])
+def test_hip_path_agrees_with_the_definitions_of_the_remaining_stages(name, oracle_bin, fixtures_dir, tmp_path):
+    """The HIP path's r1 / r2 ids b, G+b (Xab, abX), b (XabX), oneId, D1+oneId (XaXb, aXbX), its pattern ids and per-query
+    lists, and lex*.fe / lex*.ef, all against tests/bruteforce.py -- no oracle result is compared here."""
+    import torch
+    torch.zeros(1, device="cuda:0")
+    import cgx_amd as cgx
+    fx = make_fixture(name, fixtures_dir); dump = str(tmp_path / "d.bin")
+    op.run_oracle(oracle_bin, fx, str(tmp_path / "o"), dump)               # only for the id-level input arrays of the fixture
+    d = op.read_dump(dump); h = d["hdr"]; n, nt = h["n"], h["nt"]
+    ex = cgx.Extractor(0)
+    ex.upload_index(d["str"][:n], d["rlp"], d["tstr"][:nt], d["ltar"], d["rtar"], d["lexk"], d["lexv"])
+    ex.build_sa(); ex.precompute(); ex.upload_queries(d["qoff"][:-1], d["qtok"]); ex.sa_lookup(); ex.make_blocks(); ex.gappy_search(); ex.extract(); ex.lexicon()
+    ex.count_rules()                                                        # builds the per-query pattern lists
+    c = bf.Corpus(d["str"][:n], d["rlp"], d["ltar"], d["rtar"]); k = ex.counts()
+    s1, s2, p1d, c2d, one2, blocks = ex.fetch("s1"), ex.fetch("s2"), ex.fetch("p1d"), ex.fetch("c2d"), ex.fetch("one2"), ex.fetch("blocks")
+    a, b = bf.check_query_side(c, d["qoff"][:-1], d["qtok"], ex.fetch("lm"), k["e1"], s1, p1d, _csr(ex.fetch("qo_off"), ex.fetch("qo_ids")),
+                               k["e2"], s2, c2d, _csr(ex.fetch("qt_off"), ex.fetch("qt_ids")))
+    assert (a, b) == (k["d1"], k["d2"])
+    hits_of = bf.hit_lists(s1, ex.fetch("hits1"), ex.fetch("pidx"), ex.fetch("phit_start"), ex.fetch("phit_len"))
+    assert bf.check_extension_rules(c, ex.fetch("sa"), blocks, s1, hits_of, ex.fetch("r1"), k["sep1"], ex.fetch("r2"), k["sep2a"], k["sep2b"]) > 1000
+    done = bf.check_maxlex_lines(c, d["tstr"], d["lexk"], d["lexv"], {0: ex.fetch("lex0"), 1: ex.fetch("lex1"), 2: ex.fetch("lex2")}, k["g"], k["d1"], k["d2"], blocks, p1d, c2d, one2)
+    assert done > 1000 and k["guard_exits"] == 0
+    ex.close()
 
 
 @pytest.mark.gpu
