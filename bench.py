@@ -11,7 +11,8 @@ separately.
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Workloads (BASELINE.json configs): --config cfg3 (default; 10 M sentence pairs, 10 k queries per
+Workloads (BASELINE.json configs): --config toy (20 k sentence pairs, 7 queries per step: the toy line north_star asks for;
+the reference's hansards files are not in its checkout, so the corpus is synthetic), cfg3 (default; 10 M sentence pairs, 10 k queries per
 GPU per step, weak scaling), cfg4 (Europarl scale, N = 5.5e7 source tokens, one 50 k-query batch
 split over the ranks: strong scaling), cfg5 (1e8 source tokens, 1 M queries split over the ranks).
 
@@ -37,6 +38,8 @@ sys.path.insert(0, ROOT)
 
 CONFIGS = {
     # name: (sentence pairs, vocabulary, queries, queries are per GPU?, default scaling, default steps, default warmup)
+    "toy": dict(pairs=20_000, vocab=160, queries=7, scaling="weak", steps=40, warmup=5, lo=4, hi=18,
+                what="BASELINE configs[1] stand-in (toy/hansards is absent from the reference checkout): synthetic 20k-pair toy corpus of the test suite's shape (vocabulary 160, sentences of 4..18 tokens), 7 queries per GPU per step"),
     "cfg3": dict(pairs=10_000_000, vocab=200_000, queries=10_000, scaling="weak", steps=5, warmup=2,
                  what="BASELINE configs[2]: synthetic 10M-sentence parallel corpus (Zipf token ids), 10k queries per GPU per step"),
     "cfg4": dict(pairs=2_115_000, vocab=150_000, queries=50_000, scaling="strong", steps=2, warmup=1,
@@ -148,6 +151,7 @@ def main():
     ap.add_argument("--sub-batch", type=int, default=0, help="queries per internal batch inside one call (0 = automatic)")
     ap.add_argument("--no-numa-pin", action="store_true", help="do not bind the writer threads to the GPU's NUMA node")
     ap.add_argument("--sync-write", action="store_true", help="write each chunk's files before starting the next chunk")
+    ap.add_argument("--fresh-steps", type=int, default=None, help="extra timed steps AFTER the contract's K steps that write every chunk into a NEW directory (value_fresh_files); default 3 (1 when a step is several chunks), 0 = skip")
     ap.add_argument("--no-write", action="store_true", help="count the rules on the GPU, lay out no text, write no files (kernel-side study; not the headline)")
     ap.add_argument("--option", action="append", default=[], help="name=value passed to cgx_set_option (repeatable)")
     args = ap.parse_args()
@@ -166,7 +170,7 @@ def main():
         # the ranks of one host share its CPUs (and its cgroup quota): each writer gets its share, two CPUs of it left to
         # the thread that feeds the GPU (what the library does by itself for a single process)
         share = usable_cpus() // local_world
-        os.environ["CGX_THREADS"] = str(max(1, min(16, share - 2 if share >= 8 else share)))
+        os.environ["CGX_THREADS"] = str(max(2, min(16, share - 2 if share >= 8 else share)))   # never fewer than two: one writer thread cannot keep up with any GPU
     # the CPU baseline runs first, in its own process, while this one generates the corpus: its cores are free
     # again long before the timed region starts (it is joined before the warm-up steps)
     cpu_proc = start_cpu_baseline(args, cfg) if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
@@ -200,7 +204,7 @@ def main():
         base_shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
         share = os.path.join(base_shm, "cgx_bench_corpus_%s_%d_%d_%d" % (os.environ.get("MASTER_PORT", "0"), cfg["pairs"], cfg["vocab"], args.seed))
     if leader:
-        corpus = synth.make_corpus(cfg["pairs"], cfg["vocab"], args.seed)
+        corpus = synth.make_corpus(cfg["pairs"], cfg["vocab"], args.seed, cfg.get("lo", 5), cfg.get("hi", 45))
         if share:
             os.makedirs(share, exist_ok=True)
             for k in keys:
@@ -314,9 +318,9 @@ def main():
     acc = {"on": False, "kernel_ms": [], "stage": {k: 0.0 for k in stage_names}, "host": {k: 0.0 for k in host_names},
            "look1_items": 0.0, "look2_items": 0.0, "h1": 0, "h2": 0, "batches": 0}      # summed over every batch (chunk) of the timed steps
 
-    def run_chunk(a, b):
+    def run_chunk(a, b, outdir=None):
         t0_, t1_ = int(qoff[a]), (int(qoff[b]) if b < nq else len(qtok))
-        n = ex.extract_grammars_ids(host, (qoff[a:b] - t0_).astype(np.int32), qtok[t0_:t1_], spool, first + a if whole else 0)
+        n = ex.extract_grammars_ids(host, (qoff[a:b] - t0_).astype(np.int32), qtok[t0_:t1_], outdir or spool, first + a if whole else 0)
         if acc["on"]:                                         # the per-batch timers and tallies of the library hold the batch that just ran
             acc["kernel_ms"].append(ex.stage_ms("sa_lookup_kernel"))
             for k in stage_names: acc["stage"][k] += max(ex.stage_ms(k), 0.0)
@@ -361,10 +365,66 @@ def main():
     total_q = shard.sum_over_ranks(nq * steps, dist if world > 1 else None)
     total_rules = shard.sum_over_ranks(rules, dist if world > 1 else None)
 
+    # ---- what every rank did in the timed steps: the GPU chain alone, and the two host stages beside it ----
+    chain_s = sum(stage[k] for k in ("sa_lookup", "blocks", "gappy", "extract", "lexicon", "format")) / 1e3
+    mine = {"rank": rank, "queries": int(nq * steps), "gpu_chain_s": chain_s, "dma_wait_s": hoststage["write_wait_d2h"] / 1e3, "file_phase_s": hoststage["write_file"] / 1e3,
+            "writer_threads": int(max(ex.host_ms("writer_threads"), 0)), "cpus_usable": usable_cpus(), "cgx_threads_env": os.environ.get("CGX_THREADS")}
+    ranks = [mine]
+    if world > 1:
+        ranks = [None] * world; dist.all_gather_object(ranks, mine)
+
+    # ---- the same steps into FRESH directories (what a user who writes every batch into a new directory sees): every chunk
+    # goes into a directory of its own; the directory from three chunks back is deleted by a helper thread (the library keeps
+    # at most two batches in flight, so its files are complete), which bounds the memory at four generations ----
+    fresh_steps = args.fresh_steps if args.fresh_steps is not None else (3 if len(chunks) == 1 else 1)
+    fresh = {"steps": 0, "value": None, "ms_per_step": None, "note": None}
+    if write and fresh_steps > 0:
+        import threading
+        gen_bytes = max(spool_bytes[0], 1)
+        shutil.rmtree(spool, ignore_errors=True); os.makedirs(spool, exist_ok=True)     # the in-place spool has done its work: its memory goes to the generations
+        fits = gen_bytes * 5.6 <= per_rank * 2.6                                         # three live generations + one being deleted + the writer's page-locked buffers (1.6)
+        fits = bool(shard.min_over_ranks(1.0 if fits else 0.0, dist if world > 1 else None))      # all ranks or none (the region has barriers)
+        if not fits:
+            fresh["note"] = "skipped: four generations of %.1f GB of files do not fit this rank's memory budget" % (gen_bytes / 1e9)
+        else:
+            gens, deleters = [], []
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            tf = time.perf_counter()
+            for _ in range(fresh_steps):
+                for a, b in chunks:
+                    while len(deleters) > 1:
+                        deleters.pop(0).join()
+                    d = tempfile.mkdtemp(prefix="gen_", dir=spool)
+                    run_chunk(a, b, d); gens.append(d)
+                    if len(gens) > 2:
+                        th = threading.Thread(target=shutil.rmtree, args=(gens.pop(0), True)); th.start(); deleters.append(th)
+            ex.flush()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            dtf = shard.max_over_ranks(time.perf_counter() - tf, dist if world > 1 else None)
+            for th in deleters:
+                th.join()
+            tq = shard.sum_over_ranks(nq * fresh_steps, dist if world > 1 else None)
+            fresh.update(steps=fresh_steps, value=round(tq / dtf, 3), ms_per_step=round(dtf / fresh_steps * 1e3, 3),
+                         note="every chunk written into a new directory; directories older than two chunks deleted by a helper thread inside the timed region")
+
     if rank == 0:
         line = {"metric": "query sentences/sec", "value": round(total_q / dt, 3), "unit": "query sentences/s", "rules_per_s": round(total_rules / dt, 1),
                 "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(dt / max(steps, 1) * 1e3, 3), "higher_is_better": True,
-                "scaling": cfg["scaling"], "vs_baseline": None, "dtype": "i32", "data": "synthetic"}
+                "scaling": cfg["scaling"], "vs_baseline": None, "dtype": "i32", "data": "synthetic",
+                # value = files rewritten in place in one spool directory per rank (page-cache friendly); the same path into new directories:
+                "value_fresh_files": fresh["value"], "fresh_files": fresh,
+                # the GPU stages alone (lookup .. text layout, hipEvent-timed per stage), without DMA and file phases: what scales with the GPU count by construction
+                "value_gpu_chain": round(sum(r["queries"] for r in ranks) / max(max(r["gpu_chain_s"] for r in ranks), 1e-9), 3),
+                "per_rank": {"gpu_chain_ms_per_step": [round(min(r["gpu_chain_s"] for r in ranks) / max(steps, 1) * 1e3, 2), round(max(r["gpu_chain_s"] for r in ranks) / max(steps, 1) * 1e3, 2)],
+                             "dma_wait_ms_per_step": [round(min(r["dma_wait_s"] for r in ranks) / max(steps, 1) * 1e3, 2), round(max(r["dma_wait_s"] for r in ranks) / max(steps, 1) * 1e3, 2)],
+                             "file_phase_ms_per_step": [round(min(r["file_phase_s"] for r in ranks) / max(steps, 1) * 1e3, 2), round(max(r["file_phase_s"] for r in ranks) / max(steps, 1) * 1e3, 2)],
+                             "writer_threads": [min(r["writer_threads"] for r in ranks), max(r["writer_threads"] for r in ranks)],
+                             "cpus_usable_per_process": [min(r["cpus_usable"] for r in ranks), max(r["cpus_usable"] for r in ranks)],
+                             "cgx_threads_env": mine["cgx_threads_env"], "note": "[min, max] over the ranks; per step of the timed region"}}
         try:
             line.update(report(ex, args, cfg, locals()))
         except Exception as e:                                   # the measurement above stands whatever the extras do
@@ -397,8 +457,9 @@ def report(ex, args, cfg, L):
     pb, ps, pq, plk = (ex.stage_ms("sa_probe_" + k) for k in ("bucket", "slots", "search", "lookups"))
     kms_last = ex.stage_ms("sa_lookup_kernel")                # the same launch (the last chunk of a step), timed by its own events
     # bytes the kernel must move for these lookups: its query tokens (4 B each + 12 B of offsets), 4 B per bucket-table entry,
-    # 16 B per l-gram slot, 8 B per search probe (SA entry + corpus token), 44 B of results per token
-    exec_bytes = T * (4 + 12 + 44) + 4 * pb + 16 * ps + 8 * pq
+    # 64 B per l-gram slot, 8 B per search probe (SA entry + corpus token), 44 B of results per token
+    slot_b = max(ex.stage_ms("ngram_slot_bytes"), 16.0)      # 64: a slot is one memory sector and the lookup uses all of it (phrase + the intervals of its prefixes)
+    exec_bytes = T * (4 + 12 + 44) + 4 * pb + slot_b * ps + 8 * pq
     sv_bytes, lookups = survey_bytes(n_src, lm)
     traffic = None; requests = None; rr16 = None
     try:
@@ -406,22 +467,24 @@ def report(ex, args, cfg, L):
         pc = pmc["config"]
         if (pc["pairs"], pc["queries"], pc["seed"], pc["vocab"]) == (cfg["pairs"], nq, args.seed, cfg["vocab"]) and len(L["chunks"]) == 1:
             traffic = int(pmc["traffic_bytes"]); requests = float(pmc["TCC_EA0_RDREQ_per_launch"])
-            rr16 = json.load(open(os.path.join(ROOT, "profiles", "pmc_lookup_kernels.json")))["random_read_peak"]["reads_per_s_16B"]
+            rr16 = json.load(open(os.path.join(ROOT, "profiles", "pmc_lookup_kernels.json")))["random_read_peak"]["reads_per_s_64B"]
     except Exception:
         traffic = None
-    ach = exec_bytes / (kms_last * 1e-3) / 1e9 if kms_last > 0 else 0.0
+    kuse = kms if kms > 0 else kms_last                          # the mean over the launches of the timed steps (a single relaunch after the run is 2-3x slower: cold tables)
+    ach = exec_bytes / (kuse * 1e-3) / 1e9 if kuse > 0 else 0.0
     roofline = {"bound": "hbm", "kernel": "k_sa_lookup (batched SA interval search, K1+K2)", "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(ach / 8000.0, 4), "traffic": traffic,
-                "algorithmic_bytes_per_launch": int(exec_bytes), "kernel_ms": round(kms_last, 5), "kernel_ms_mean_timed_steps": round(kms, 5),
+                "algorithmic_bytes_per_launch": int(exec_bytes), "kernel_ms": round(kuse, 5), "kernel_ms_mean_timed_steps": round(kms, 5), "kernel_ms_single_relaunch_after_run": round(kms_last, 5),
+                "traffic_source": (None if traffic is None else "profiles/pmc_k_sa_lookup.json (rocprofv3 --pmc passes of the same kernel on the same workload, committed) -- NOT measured in this run"),
                 "units_per_launch": {"query_tokens": int(T), "lookups": int(plk), "bucket_entries_read": int(pb), "ngram_slots_read": int(ps), "search_probes": int(pq)},
-                "lookups_per_s": round(plk / (kms_last * 1e-3), 1) if kms_last > 0 else None,
-                "traffic_GBps": (round(traffic / (kms_last * 1e-3) / 1e9, 1) if traffic and kms_last > 0 else None),
-                "survey_8d_formula": {"bytes": int(sv_bytes), "GBps": round(sv_bytes / (kms_last * 1e-3) / 1e9, 1) if kms_last > 0 else None,
+                "lookups_per_s": round(plk / (kuse * 1e-3), 1) if kuse > 0 else None,
+                "traffic_GBps": (round(traffic / (kuse * 1e-3) / 1e9, 1) if traffic and kuse > 0 else None),
+                "survey_8d_formula": {"bytes": int(sv_bytes), "GBps": round(sv_bytes / (kuse * 1e-3) / 1e9, 1) if kuse > 0 else None,
                                       "note": "what the reference's full-depth binary search would touch for the same lookups (SURVEY 8d); not a fraction of anything this kernel moves"},
-                "random_read_requests_per_launch": requests, "random_read_peak_per_s_16B": rr16,
-                "frac_of_random_read_peak": (round(requests / (kms_last * 1e-3) / rr16, 3) if requests and rr16 and kms_last > 0 else None),
+                "random_read_requests_per_launch": requests, "random_read_peak_per_s_64B": rr16,
+                "frac_of_random_read_peak": (round(requests / (kuse * 1e-3) / rr16, 3) if requests and rr16 and kuse > 0 else None),
                 "target_60pct_met": bool(ach / 8000.0 >= 0.6),
-                "note": "achieved = bytes of the probes the kernel executed (counted by the kernel) / its event-timed duration, against the 8 TB/s streaming peak (target 0.6: see target_60pct_met); the probes are scattered 16-byte reads, so the bound that applies is the card's random-read request rate (tools/micro/gather_bw): frac_of_random_read_peak"}
+                "note": "achieved = bytes of the probes the kernel executed (counted by the kernel) / its event-timed duration, against the 8 TB/s streaming peak (target 0.6: see target_60pct_met); the probes are scattered 64-byte slot reads (one sector each, every byte used), so the bound that applies is the card's random-read request rate (tools/micro/gather_bw, 64-byte reads): frac_of_random_read_peak"}
     # ---- the kernels that take the most time per step, priced per corpus occurrence they visit ----
     k1, k2 = stage["look1_kernel"] / nb, stage["look2_kernel"] / nb
     by_time = []

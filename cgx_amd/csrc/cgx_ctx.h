@@ -4,7 +4,10 @@
 #include <hip/hip_runtime.h>
 #include "cgx_rules.h"
 #define CGX_COPY_STREAMS 3
-struct __attribute__((aligned(16))) cgx_ngslot { unsigned long long key; uint32_t lo, hi; };   // one 16-byte slot: a probe touches one sector
+// One 64-byte slot of an l-gram table = one memory sector: the phrase itself (exact, no fingerprint), and the SA interval of
+// EVERY prefix of it (lo[k-1]..hi[k-1] = interval of its first k tokens), so that ONE probe of the longest candidate answers
+// all lengths of a query token at once.  used = 0: empty slot, else the phrase length.
+struct __attribute__((aligned(64))) cgx_ngfat { int32_t tok[5]; uint32_t lo[5], hi[5]; uint32_t used; };
 #include <stdint.h>
 #include <map>
 #include <string>
@@ -38,7 +41,7 @@ struct cgx_ctx {
     uint64_t *d_lexhkey = nullptr; uint32_t *d_lexhidx = nullptr; uint32_t lex_hmask = 0; unsigned lex_hshift = 0;   // pair hash (derived, rebuilt on replicas)
     int32_t *d_tokstart = nullptr; int8_t *d_tokrank = nullptr; int32_t *d_freq = nullptr;
     uint32_t *d_pidx = nullptr; int32_t *d_miss = nullptr; uint32_t *d_phit_start = nullptr; uint8_t *d_phit_len = nullptr;
-    cgx_ngslot *d_ng[4] = {nullptr, nullptr, nullptr, nullptr}; uint32_t ng_cap[4] = {0, 0, 0, 0}; unsigned ng_shift[4] = {0, 0, 0, 0};   // l-gram (l = 2..5) -> SA interval
+    cgx_ngfat *d_ng[4] = {nullptr, nullptr, nullptr, nullptr}; uint32_t ng_cap[4] = {0, 0, 0, 0};   // l-gram tables (l = 2..5): phrase -> SA intervals of all its prefixes
     int gz_level = 0;                   // 1..9: grammar.<q>.s.gz through zlib instead of plain files
     bool use_layouts = true;            // test hook: 0 = window kernels read the plain str / rlp / ltar / rtar arrays (round-1 access pattern)
     int ngram_max = 5;                  // longest phrase answered from the l-gram tables (1: none, every l >= 2 by binary search)
@@ -48,6 +51,7 @@ struct cgx_ctx {
     bool use_lex_hash = true;           // MaxLex pair lookups through the pair hash (0: binary search in the source word's row)
     int64_t auto_batch_tokens = 300000; // with sub_batch == 0: query tokens per internal batch (bounds device memory per call)
     int64_t sub_batch = 0;              // queries per internal batch of cgx_extract_grammars* (0 = all at once)
+    int64_t write_period = 0, write_count = 0;   // write_period > 0: only the grammar files of queries g with g % write_period < write_count are written (rules are still counted for all); batches without such a query skip text layout and DMA
     int64_t fault_inject = 0;           // test hook: the n-th device allocation from now fails
     uint32_t pool_cap = 1u << 30;       // test hook: entries of the per-block append pool in use (clamped to POOL_N)
     uint32_t look_rec_cap = 65535;      // test hook: groups with more records than this read them from global memory

@@ -393,6 +393,8 @@ extern "C" int cgx_set_option(cgx_ctx *c, const char *name, int64_t value) {
     if (!strcmp(name, "prealloc_text")) { c->prealloc_text = value != 0; return CGX_OK; }
     if (!strcmp(name, "use_lex_hash")) { c->use_lex_hash = value != 0; return CGX_OK; }
     if (!strcmp(name, "wide_hits2")) { c->wide_hits2 = value != 0; return CGX_OK; }
+    if (!strcmp(name, "write_period")) { if (value < 0) return CGX_ERR_ARG; c->write_period = value; return CGX_OK; }
+    if (!strcmp(name, "write_count")) { if (value < 0) return CGX_ERR_ARG; c->write_count = value; return CGX_OK; }
     if (!strcmp(name, "fault_inject")) { c->fault_inject = value; return CGX_OK; }
     if (!strcmp(name, "pool_cap")) { if (value < 1) return CGX_ERR_ARG; c->pool_cap = (uint32_t)(value > POOL_N ? POOL_N : value); return CGX_OK; }
     if (!strcmp(name, "look_rec_cap")) { if (value < 0) return CGX_ERR_ARG; c->look_rec_cap = (uint32_t)(value > 65535 ? 65535 : value); return CGX_OK; }
@@ -415,6 +417,8 @@ extern "C" int64_t cgx__option(cgx_ctx *c, const char *name) {
     if (!strcmp(name, "auto_batch_tokens")) return c->auto_batch_tokens;
     if (!strcmp(name, "numa_pin")) return (int64_t)c->numa_pin;
     if (!strcmp(name, "gz_level")) return (int64_t)c->gz_level;
+    if (!strcmp(name, "write_period")) return c->write_period;
+    if (!strcmp(name, "write_count")) return c->write_count;
     return 0;
 }
 // "local_cpulist" of the GPU's PCI function (the CPUs of its NUMA node), or an empty string

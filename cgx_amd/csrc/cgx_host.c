@@ -664,6 +664,7 @@ typedef struct {
     range *rng0, *rng1, *rng2;
     cgx_lextask *tasks; uint32_t ntask;
     int gz_level;                                             /* of the context this batch runs on (the host formatter may run later, on the writer thread) */
+    int64_t write_period, write_count;
 } batch;
 
 static void batch_free(batch *b) {
@@ -1038,7 +1039,9 @@ static int emit_range(sbuf *s, const batch *b, int kind, const cgx_lexent *lex, 
     return 0;
 }
 static int g_diag_format_only;
-typedef struct { const batch *b; const char *outdir; int32_t first; int32_t *next; uint64_t lines; int rc, gz; } writejob;
+typedef struct { const batch *b; const char *outdir; int32_t first; int32_t *next; uint64_t lines; int rc, gz; int64_t period, count; } writejob;
+/* options "write_period" / "write_count": with a period, only queries g (index in the whole query list) with g % period < count get a file */
+static int file_selected(int64_t period, int64_t count, int64_t g) { return period <= 0 || g % period < count; }
 static void *write_worker(void *arg) {
     writejob *w = arg; const batch *b = w->b;
     const uint32_t G = b->g, D1 = b->d1, D2 = b->d2;
@@ -1062,7 +1065,7 @@ static void *write_worker(void *arg) {
         if (bad) { w->rc = CGX_ERR_NOMEM; break; }
         snprintf(fn, sizeof fn, "%s/grammar.%d.s", w->outdir, w->first + q);
         /* overwrite in place and cut to length: same bytes as fopen(fn,"w"), but an existing file keeps its pages */
-        if (g_diag_format_only) continue;                   /* diagnostic (CGX_DIAG_FORMAT_ONLY=1): measure formatting without the file system */
+        if (g_diag_format_only || !file_selected(w->period, w->count, (int64_t)w->first + q)) continue;                   /* diagnostic (CGX_DIAG_FORMAT_ONLY=1): measure formatting without the file system */
         if (w->gz) {
             char mode[8]; snprintf(mode, sizeof mode, "wb%d", w->gz); strcat(fn, ".gz");
             gzFile f = gzopen(fn, mode);
@@ -1087,7 +1090,7 @@ static int write_grammars(const batch *b, const char *outdir, int32_t first, uin
     int nt = nthreads_host(); if (nt > b->nq) nt = b->nq > 0 ? b->nq : 1;
     { const char *e = getenv("CGX_DIAG_FORMAT_ONLY"); g_diag_format_only = e && *e == '1'; }
     writejob jobs[64]; pthread_t th[64]; int32_t next = 0;
-    for (int t = 0; t < nt; t++) { jobs[t].b = b; jobs[t].outdir = outdir; jobs[t].first = first; jobs[t].next = &next; jobs[t].lines = 0; jobs[t].rc = CGX_OK; jobs[t].gz = b->gz_level; }
+    for (int t = 0; t < nt; t++) { jobs[t].b = b; jobs[t].outdir = outdir; jobs[t].first = first; jobs[t].next = &next; jobs[t].lines = 0; jobs[t].rc = CGX_OK; jobs[t].gz = b->gz_level; jobs[t].period = b->write_period; jobs[t].count = b->write_count; }
     for (int t = 1; t < nt; t++) if (pthread_create(&th[t], NULL, write_worker, &jobs[t])) return CGX_ERR_NOMEM;
     write_worker(&jobs[0]);
     for (int t = 1; t < nt; t++) pthread_join(th[t], NULL);
@@ -1189,7 +1192,7 @@ static void pin_to_device_node(cgx_ctx *ctx) {
 typedef struct {
     cgx_ctx *ctx; int tid, rc; int32_t nq, first; const char *outdir; int32_t *next_q;
     const char *utext; const uint64_t *qseg, *seg_off; const uint32_t *seg_len;
-    double file_ms; uint64_t calls; int gz;
+    double file_ms; uint64_t calls; int gz; int64_t period, count;
 } devjob;
 /* optional gzip output (option "gz_level" 1..9): grammar.<q>.s.gz, the same bytes through zlib's deflate */
 static int write_one_file_gz(devjob *w, int32_t q) {
@@ -1239,6 +1242,7 @@ static void *dev_write_worker(void *arg) {
     for (;;) {
         int32_t q = __atomic_fetch_add(w->next_q, 1, __ATOMIC_RELAXED);
         if (q >= w->nq) break;
+        if (!file_selected(w->period, w->count, (int64_t)w->first + q)) continue;
         int rc = write_one_file(w, q, iov);
         if (rc != CGX_OK) { w->rc = rc; break; }
     }
@@ -1267,7 +1271,7 @@ static int dev_write_files(pending *pw) {
     cgx__set_host_ms(ctx, "writer_threads", nt);             /* reported beside the timings (bench.py) */
     devjob jobs[MAX_WRITERS]; pthread_t th[MAX_WRITERS]; int started[MAX_WRITERS]; int32_t next = 0; int rc = CGX_OK;
     for (int t = 0; t < nt; t++) { memset(&jobs[t], 0, sizeof jobs[t]); jobs[t].ctx = ctx; jobs[t].tid = t; jobs[t].nq = nq; jobs[t].first = pw->first; jobs[t].outdir = pw->outdir; jobs[t].next_q = &next;
-                                   jobs[t].utext = hb->utext; jobs[t].qseg = hb->qseg; jobs[t].seg_off = hb->segoff; jobs[t].seg_len = hb->seglen; jobs[t].rc = CGX_OK; jobs[t].gz = (int)cgx__option(ctx, "gz_level"); }
+                                   jobs[t].utext = hb->utext; jobs[t].qseg = hb->qseg; jobs[t].seg_off = hb->segoff; jobs[t].seg_len = hb->seglen; jobs[t].rc = CGX_OK; jobs[t].gz = (int)cgx__option(ctx, "gz_level"); jobs[t].period = cgx__option(ctx, "write_period"); jobs[t].count = cgx__option(ctx, "write_count"); }
     started[0] = 1;
     for (int t = 1; t < nt; t++) started[t] = !pthread_create(&th[t], NULL, dev_write_worker, &jobs[t]);   /* a thread that cannot start: the others take its share */
     dev_write_worker(&jobs[0]);
@@ -1349,6 +1353,12 @@ static int run_batch(cgx_ctx *ctx, const cgx_corpus *c, batch *b, const char *ou
     int rc; double t0 = now_ms(), t, tl = t0;
 #define LAP(name) do { double n_ = now_ms(); cgx__set_host_ms(ctx, "t_" name, n_ - tl); tl = n_; } while (0)
     b->c = c;
+    b->write_period = cgx__option(ctx, "write_period"); b->write_count = cgx__option(ctx, "write_count");
+    if (outdir && b->write_period > 0) {                      /* a batch none of whose queries gets a file only counts its rules: no text layout, no DMA */
+        int any = 0;
+        for (int64_t g = first; g < (int64_t)first + b->nq && !any; ) { if (file_selected(b->write_period, b->write_count, g)) any = 1; else g += b->write_period - g % b->write_period; }
+        if (!any) outdir = NULL;
+    }
     if ((rc = cgx_upload_queries(ctx, b->qoff, b->nq, b->qtok, b->ntok)) != CGX_OK) return rc;
     if ((rc = cgx_sa_lookup(ctx)) != CGX_OK) return rc;
     LAP("upload_sa");

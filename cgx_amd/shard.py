@@ -38,6 +38,17 @@ def max_over_ranks(seconds, dist=None):
     return float(t.item())
 
 
+def min_over_ranks(value, dist=None):
+    """Smallest value over the ranks (a decision every rank must take the same way: yes only if all say yes)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(value)
+    import torch
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return float(t.item())
+
+
 def sum_over_ranks(value, dist=None):
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return int(value)

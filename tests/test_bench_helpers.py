@@ -28,6 +28,7 @@ def test_memory_budget_is_bounded_by_what_the_process_may_use():
 def test_presets_are_the_baseline_configs():
     c = bench.CONFIGS
     assert c["cfg3"]["pairs"] == 10_000_000 and c["cfg3"]["queries"] == 10_000 and c["cfg3"]["scaling"] == "weak"
+    assert c["toy"]["pairs"] == 20_000 and c["toy"]["queries"] == 7                                 # the toy line (hansards stand-in)
     assert c["cfg4"]["queries"] == 50_000 and c["cfg4"]["scaling"] == "strong"
     assert c["cfg5"]["queries"] == 1_000_000 and abs(c["cfg5"]["pairs"] * 26 - 1e8) < 2e6          # 26 tokens per sentence pair incl. the delimiter
 

@@ -141,6 +141,50 @@ def test_grammar_files_do_not_depend_on_batching(world):
         shutil.rmtree(out, ignore_errors=True)
 
 
+def _sample_files(d, period, count, nq):
+    h = hashlib.sha256(); n = 0
+    for q in range(nq):
+        if q % period < count:
+            with open(os.path.join(d, "grammar.%d.s" % q), "rb") as f:
+                h.update(f.read()); h.update(b"\0"); n += 1
+    return h.hexdigest(), n
+
+
+def test_cfg5_one_million_queries(world, request):
+    """BASELINE configs[4] at its stated query count: 10^6 query sentences (2.5e7 query tokens) against the 1e8-token corpus,
+    once as ONE call (84 internal batches chosen by the library) and once cut into sub-batches of 6 000 sentences with small
+    lookup launches and the asynchronous writer.  The rule counts must agree, and so must the grammar files of 200 sampled
+    queries (four windows of 50; option write_period / write_count: the other 999 800 files are counted, not written) -- which
+    in turn equal the files the same 50 sentences produce as a small batch of their own."""
+    cgx, synth, corpus, host, ex = world
+    if request.node.callspec.params["world"] != "cfg5":
+        pytest.skip("the stress configuration only")
+    nq = int(os.environ.get("CGX_CFG5_QUERIES", "1000000")); period, count = nq // 4, 50
+    qoff, qtok = synth.make_queries(corpus, nq, 21)
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    out = tempfile.mkdtemp(prefix="cgx_cfg5_", dir=base)
+    try:
+        a, b, c = (os.path.join(out, x) for x in "abc")
+        for d in (a, b, c):
+            os.mkdir(d)
+        ex.set_option("write_period", period); ex.set_option("write_count", count); ex.set_option("async_write", 1)
+        n_a = ex.extract_grammars_ids(host, qoff, qtok, a, 0); ex.flush()
+        ex.set_option("sub_batch", 6000); ex.set_option("chunk_items", 1 << 24)
+        n_b = ex.extract_grammars_ids(host, qoff, qtok, b, 0); ex.flush()
+        ex.set_option("sub_batch", 0); ex.set_option("chunk_items", 1 << 26); ex.set_option("write_period", 0); ex.set_option("async_write", 0)
+        assert n_a == n_b and n_a > 50 * nq                    # thousands of rules per sentence
+        sa_, na = _sample_files(a, period, count, nq); sb_, nb = _sample_files(b, period, count, nq)
+        assert na == nb == 4 * count and sa_ == sb_
+        assert len(os.listdir(a)) == 4 * count                  # nothing else was written
+        # the first window as a batch of its own
+        t1 = int(qoff[count])
+        ex.extract_grammars_ids(host, qoff[:count], qtok[:t1], c, 0)
+        for q in range(count):
+            assert open(os.path.join(a, "grammar.%d.s" % q), "rb").read() == open(os.path.join(c, "grammar.%d.s" % q), "rb").read(), q
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
 def test_cfg4_two_contexts_split_equals_one(tmp_path):
     """BASELINE configs[3] on one card: Europarl-scale corpus (about 2.1 M sentence pairs, N = 5.5e7), one batch of queries
     (a) on the context that built the index, (b) split by token count (cgx_amd.shard, the policy of bench.py and of
@@ -179,6 +223,22 @@ def test_cfg4_two_contexts_split_equals_one(tmp_path):
             total += ex.extract_grammars_ids(host, so, st, b, first)
         root.flush(); rep.flush()
         assert total == n_all and n_all > 0 and _sha_dir(a, nq) == _sha_dir(b, nq)
+        # ---- the configuration's own batch: 50 000 query sentences (1.3e6 tokens, five internal batches), whole on one
+        # context and split by token count over the two; rule counts must agree, and the files of 200 sampled queries
+        # (four windows of 50) written by the whole run and by the two shards must be the same bytes
+        NQ = int(os.environ.get("CGX_CFG4_QUERIES", "50000")); period, count = NQ // 4, 50
+        qoff, qtok = synth.make_queries(corpus, NQ, 9)
+        c, d = os.path.join(out, "c"), os.path.join(out, "d"); os.mkdir(c); os.mkdir(d)
+        for ex in (root, rep):
+            ex.set_option("write_period", period); ex.set_option("write_count", count); ex.set_option("async_write", 1)
+        n_whole = root.extract_grammars_ids(host, qoff, qtok, c, 0); root.flush()
+        n_split = 0
+        for r, ex in enumerate((root, rep)):
+            first, so, st = shard.take_shard(qoff, qtok, r, 2)
+            n_split += ex.extract_grammars_ids(host, so, st, d, first)
+        root.flush(); rep.flush()
+        assert n_whole == n_split and n_whole > 50 * NQ
+        assert _sample_files(c, period, count, NQ) == _sample_files(d, period, count, NQ) and len(os.listdir(c)) == 4 * count == len(os.listdir(d))
     finally:
         shutil.rmtree(out, ignore_errors=True)
         rep.close(); root.close(); host.close()
@@ -205,6 +265,23 @@ def test_bench_contract_small(tmp_path):
     assert d["config"]["grammar_files_written"] and "3 chunk(s)" in d["config"]["outdir_mode"]
     cb = d["cpu_baseline"]
     assert cb.get("kind") == "port" and cb["one_core"]["value"] > 0 and cb["all_cores"]["cores"] >= 1 and cb["value"] > 0
+    # beside the in-place figure: the same steps into fresh directories, the GPU chain alone, and the per-rank host stages
+    assert d["fresh_files"]["steps"] == 1 and d["value_fresh_files"] > 0 and d["value_gpu_chain"] >= d["value"] * 0.9
+    pr = d["per_rank"]
+    assert pr["gpu_chain_ms_per_step"][0] > 0 and pr["writer_threads"][0] >= 1 and pr["cpus_usable_per_process"][0] >= 1
+    assert rf["kernel_ms"] == rf["kernel_ms_mean_timed_steps"]            # the fraction is priced on the launches of the timed steps
+
+
+def test_bench_toy_line():
+    """bench.py --config toy: the toy line north_star asks for (20 k sentence pairs, 7 queries per step)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "toy", "--steps", "5", "--warmup", "2", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["config"]["name"] == "toy" and d["config"]["sentence_pairs"] == 20000 and d["config"]["queries_per_step_this_rank"] == 7 and d["value"] > 0 and d["rules_per_s"] > 0
 
 
 @pytest.mark.parametrize("bcast", ["torch", "c"])
