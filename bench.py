@@ -110,7 +110,7 @@ def usable_cpus():
 def start_cpu_baseline(args, cfg):
     """tools/cpu_baseline.py in its own process (never touches the GPU); the result is collected later."""
     cmd = [sys.executable, os.path.join(ROOT, "tools", "cpu_baseline.py"), "--pairs", str(min(args.cpu_pairs, cfg["pairs"])), "--vocab", str(cfg["vocab"]),
-           "--seed", str(args.seed), "--budget-s", str(args.cpu_seconds), "--corpus-pairs", str(cfg["pairs"])]
+           "--seed", str(args.seed), "--budget-s", str(args.cpu_seconds), "--corpus-pairs", str(cfg["pairs"]), "--full-sa-seconds", str(args.cpu_full_sa_seconds if (cfg.get("lo", 5), cfg.get("hi", 45)) == (5, 45) else 0)]
     return subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
 
 
@@ -144,6 +144,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--cpu-pairs", type=int, default=200000, help="sentence pairs of the CPU baseline's sample corpus")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="seconds of timed CPU work per baseline leg (one core, all cores)")
+    ap.add_argument("--cpu-full-sa-seconds", type=float, default=150.0, help="the CPU baseline process also runs the reference's own suffixArrayConstruct on the WHOLE corpus (one core, beside its other legs), for at most this long (0: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; nccl (= RCCL over xGMI) for real runs, gloo only to rehearse N>1 on a one-GPU box")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -336,7 +337,7 @@ def main():
         return n
 
     # the CPU baseline has had the corpus generation and the index build to finish; wait for the rest of it now
-    cpu_res = collect_cpu_baseline(cpu_proc, 240) if cpu_proc else None
+    cpu_res = collect_cpu_baseline(cpu_proc, 240 + int(args.cpu_full_sa_seconds)) if cpu_proc else None
 
     # timed steps must not be the first rewrite of the file slots (the first rewrite of a file set costs 4x the page-cache
     # time of any later one): the slots are filled at least twice before the clock starts
@@ -457,8 +458,8 @@ def report(ex, args, cfg, L):
     pb, ps, pq, plk = (ex.stage_ms("sa_probe_" + k) for k in ("bucket", "slots", "search", "lookups"))
     kms_last = ex.stage_ms("sa_lookup_kernel")                # the same launch (the last chunk of a step), timed by its own events
     # bytes the kernel must move for these lookups: its query tokens (4 B each + 12 B of offsets), 4 B per bucket-table entry,
-    # 64 B per l-gram slot, 8 B per search probe (SA entry + corpus token), 44 B of results per token
-    slot_b = max(ex.stage_ms("ngram_slot_bytes"), 16.0)      # 64: a slot is one memory sector and the lookup uses all of it (phrase + the intervals of its prefixes)
+    # 16 B per l-gram slot, 8 B per search probe (SA entry + corpus token), 44 B of results per token
+    slot_b = 16.0                                            # one l-gram slot {key, lo, hi}; it arrives in a 64-byte sector, which is what the counters see
     exec_bytes = T * (4 + 12 + 44) + 4 * pb + slot_b * ps + 8 * pq
     sv_bytes, lookups = survey_bytes(n_src, lm)
     traffic = None; requests = None; rr16 = None
@@ -467,7 +468,7 @@ def report(ex, args, cfg, L):
         pc = pmc["config"]
         if (pc["pairs"], pc["queries"], pc["seed"], pc["vocab"]) == (cfg["pairs"], nq, args.seed, cfg["vocab"]) and len(L["chunks"]) == 1:
             traffic = int(pmc["traffic_bytes"]); requests = float(pmc["TCC_EA0_RDREQ_per_launch"])
-            rr16 = json.load(open(os.path.join(ROOT, "profiles", "pmc_lookup_kernels.json")))["random_read_peak"]["reads_per_s_64B"]
+            rr16 = json.load(open(os.path.join(ROOT, "profiles", "pmc_lookup_kernels.json")))["random_read_peak"]["reads_per_s_16B"]
     except Exception:
         traffic = None
     kuse = kms if kms > 0 else kms_last                          # the mean over the launches of the timed steps (a single relaunch after the run is 2-3x slower: cold tables)
@@ -481,10 +482,10 @@ def report(ex, args, cfg, L):
                 "traffic_GBps": (round(traffic / (kuse * 1e-3) / 1e9, 1) if traffic and kuse > 0 else None),
                 "survey_8d_formula": {"bytes": int(sv_bytes), "GBps": round(sv_bytes / (kuse * 1e-3) / 1e9, 1) if kuse > 0 else None,
                                       "note": "what the reference's full-depth binary search would touch for the same lookups (SURVEY 8d); not a fraction of anything this kernel moves"},
-                "random_read_requests_per_launch": requests, "random_read_peak_per_s_64B": rr16,
+                "random_read_requests_per_launch": requests, "random_read_peak_per_s_16B": rr16,
                 "frac_of_random_read_peak": (round(requests / (kuse * 1e-3) / rr16, 3) if requests and rr16 and kuse > 0 else None),
                 "target_60pct_met": bool(ach / 8000.0 >= 0.6),
-                "note": "achieved = bytes of the probes the kernel executed (counted by the kernel) / its event-timed duration, against the 8 TB/s streaming peak (target 0.6: see target_60pct_met); the probes are scattered 64-byte slot reads (one sector each, every byte used), so the bound that applies is the card's random-read request rate (tools/micro/gather_bw, 64-byte reads): frac_of_random_read_peak"}
+                "note": "achieved = bytes of the probes the kernel executed (counted by the kernel) / its event-timed duration, against the 8 TB/s streaming peak (target 0.6: see target_60pct_met); the probes are scattered 16-byte reads, so the bound that applies is the card's random-read request rate (tools/micro/gather_bw, 64-byte reads): frac_of_random_read_peak"}
     # ---- the kernels that take the most time per step, priced per corpus occurrence they visit ----
     k1, k2 = stage["look1_kernel"] / nb, stage["look2_kernel"] / nb
     by_time = []

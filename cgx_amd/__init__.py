@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcgx_hip.so")
+LIB_PATH = os.environ.get("CGX_LIB") or os.path.join(_HERE, "libcgx_hip.so")   # CGX_LIB: another build of the same ABI (A/B measurements of kernel variants)
 
 # numpy views of the wire structs in include/cgx.h
 GAPPY = np.dtype([("qrystart", "<i4"), ("a_len", "u1"), ("b_len", "u1"), ("gap", "u1")])
@@ -52,7 +52,7 @@ ABI = [
     "cgx_upload_queries", "cgx_sa_lookup", "cgx_gappy_search", "cgx_make_blocks", "cgx_set_blocks", "cgx_extract", "cgx_lexicon", "cgx_lex_features", "cgx_fetch",
     "cgx_stage_ms", "cgx_corpus_load", "cgx_corpus_free", "cgx_corpus_checksum", "cgx_corpus_save", "cgx_corpus_load_cache", "cgx_corpus_matches_sources", "cgx_corpus_upload", "cgx_extract_grammars", "cgx_extract_grammars_shard", "cgx_shard_bounds", "cgx_extract_grammars_ids",
     "cgx_corpus_from_ids", "cgx_host_ms", "cgx_flush", "cgx_fetch_pinned", "cgx_pinned_next_batch", "cgx_upload_vocab", "cgx_upload_score_tables", "cgx_set_query_blocks",
-    "cgx_format", "cgx_text_info", "cgx_text_segments", "cgx_text_segments_begin", "cgx_text_offsets", "cgx_text_read", "cgx_text_read_begin", "cgx_text_read_wait", "cgx_pinned_alloc", "cgx_pinned_free",
+    "cgx_format", "cgx_text_info", "cgx_text_segments", "cgx_text_segments_begin", "cgx_text_offsets", "cgx_text_read", "cgx_text_read_begin", "cgx_text_read_wait", "cgx_pinned_alloc", "cgx_pinned_free", "cgx_assemble_files",
 ]
 
 
@@ -324,7 +324,7 @@ class Extractor:
         self.lib.cgx_text_read.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int]
         try:
             self._chk(self.lib.cgx_text_read(self.h, slot, 0, n, buf, 0), "cgx_text_read")
-            text = C.string_at(buf, n)
+            text = bytes((C.c_char * n).from_address(buf)) if n else b""       # not C.string_at: its size argument is a C int (a unique text of 5 GB came back 1.6 GB long)
         finally:
             self.lib.cgx_pinned_free(buf)
         return text, qseg, so[:int(ns.value)], sl[:int(ns.value)], qtext

@@ -4,10 +4,7 @@
 #include <hip/hip_runtime.h>
 #include "cgx_rules.h"
 #define CGX_COPY_STREAMS 3
-// One 64-byte slot of an l-gram table = one memory sector: the phrase itself (exact, no fingerprint), and the SA interval of
-// EVERY prefix of it (lo[k-1]..hi[k-1] = interval of its first k tokens), so that ONE probe of the longest candidate answers
-// all lengths of a query token at once.  used = 0: empty slot, else the phrase length.
-struct __attribute__((aligned(64))) cgx_ngfat { int32_t tok[5]; uint32_t lo[5], hi[5]; uint32_t used; };
+struct __attribute__((aligned(16))) cgx_ngslot { unsigned long long key; uint32_t lo, hi; };   // one 16-byte slot: a probe touches one sector
 #include <stdint.h>
 #include <map>
 #include <string>
@@ -35,14 +32,16 @@ struct cgx_ctx {
     uint32_t *d_rlp = nullptr;
     uint8_t *d_ltar = nullptr, *d_rtar = nullptr;
     cgx_tok8 *d_tok8 = nullptr; uint8_t *d_lr16 = nullptr;   // derived layouts (cgx_rules.h), built by build_layouts
+    int32_t *d_pos1 = nullptr;          // derived: the corpus positions of every token in ascending order, token by token (same buckets as the suffix array's one-token intervals: tokstart)
     uint64_t *d_lexkey = nullptr; float *d_lexv1 = nullptr, *d_lexv2 = nullptr, *d_lexn1 = nullptr, *d_lexn2 = nullptr;
     uint32_t *d_lexrow = nullptr; int32_t *d_lexnullt = nullptr; uint32_t lex_nrow = 0, lex_ntgt = 0;
     cgx_lexslot *d_lexslot = nullptr; cgx_lexnull *d_lexnullv = nullptr;
     uint64_t *d_lexhkey = nullptr; uint32_t *d_lexhidx = nullptr; uint32_t lex_hmask = 0; unsigned lex_hshift = 0;   // pair hash (derived, rebuilt on replicas)
     int32_t *d_tokstart = nullptr; int8_t *d_tokrank = nullptr; int32_t *d_freq = nullptr;
     uint32_t *d_pidx = nullptr; int32_t *d_miss = nullptr; uint32_t *d_phit_start = nullptr; uint8_t *d_phit_len = nullptr;
-    cgx_ngfat *d_ng[4] = {nullptr, nullptr, nullptr, nullptr}; uint32_t ng_cap[4] = {0, 0, 0, 0};   // l-gram tables (l = 2..5): phrase -> SA intervals of all its prefixes
+    cgx_ngslot *d_ng[4] = {nullptr, nullptr, nullptr, nullptr}; uint32_t ng_cap[4] = {0, 0, 0, 0}; unsigned ng_shift[4] = {0, 0, 0, 0};   // l-gram (l = 2..5) -> SA interval
     int gz_level = 0;                   // 1..9: grammar.<q>.s.gz through zlib instead of plain files
+    bool occ_order = true;              // one-token driving phrases take their occurrences in corpus order (d_pos1) instead of suffix order (test / A-B hook)
     bool use_layouts = true;            // test hook: 0 = window kernels read the plain str / rlp / ltar / rtar arrays (round-1 access pattern)
     int ngram_max = 5;                  // longest phrase answered from the l-gram tables (1: none, every l >= 2 by binary search)
     bool count_probes = false;          // cgx_sa_lookup also runs the probe-counting variant of its kernel (untimed; "sa_probe_*")

@@ -326,6 +326,49 @@ static int sort128(cgx_ctx *ctx, uint64_t *&hi, uint64_t *&lo, size_t n, unsigne
     return CGX_OK;
 }
 
+// ---- windowed sort in LDS -------------------------------------------------------------------------------------------
+// The rule and lexicon keys of a batch are "id-major with short runs": the array is already ordered by its major field (the
+// rule / lexicon id: work items are laid out unit by unit), and the records of one id are at most `halo` apart (a unit has at
+// most 300 / 65 / 70 sampled occurrences).  Only the order INSIDE each id run is missing.  A global radix sort spends 7-10
+// passes over the whole array on that; here a block loads a tile of WS_TILE records -- its own `core` plus `halo` records of
+// context on either side -- sorts the tile with a bitonic network in LDS and writes back its core.  Because the major field
+// is non-decreasing, sorting a tile only moves records inside their run's own position range, and every run that touches the
+// core lies wholly inside the tile, so the core positions receive exactly what a global sort would put there.  One read and
+// one write of the array instead of 14-20.
+#define WS_TILE 2048
+struct wrec64  { uint64_t k;            static __device__ __forceinline__ wrec64 inf() { return wrec64{~0ull}; }            static __device__ __forceinline__ bool less(const wrec64 &a, const wrec64 &b) { return a.k < b.k; } };
+struct wrec128 { uint64_t h, l;         static __device__ __forceinline__ wrec128 inf() { return wrec128{~0ull, ~0ull}; }   static __device__ __forceinline__ bool less(const wrec128 &a, const wrec128 &b) { return a.h < b.h || (a.h == b.h && a.l < b.l); } };
+struct wrec96  { uint64_t k; uint32_t i, pad; static __device__ __forceinline__ wrec96 inf() { return wrec96{~0ull, ~0u, 0u}; } static __device__ __forceinline__ bool less(const wrec96 &a, const wrec96 &b) { return a.k < b.k || (a.k == b.k && a.i < b.i); } };
+template <class R>
+__global__ __launch_bounds__(256) void k_window_sort(const R *__restrict__ in, R *__restrict__ out, uint32_t n, uint32_t halo) {
+    __shared__ R w[WS_TILE];
+    const uint32_t S = WS_TILE - 2 * halo;
+    const uint64_t c0 = (uint64_t)blockIdx.x * S, c1 = c0 + S < n ? c0 + S : n, ws = c0 > halo ? c0 - halo : 0;
+    for (uint32_t i = threadIdx.x; i < WS_TILE; i += 256) { const uint64_t g = ws + i; w[i] = g < n ? in[g] : R::inf(); }
+    __syncthreads();
+    for (uint32_t k = 2; k <= WS_TILE; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = threadIdx.x; t < WS_TILE / 2; t += 256) {
+                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), p = i | j;           // the pair (i, i + j), i with bit j clear
+                const bool asc = (i & k) == 0;
+                const R a = w[i], b = w[p];
+                if (R::less(b, a) == asc && (R::less(a, b) || R::less(b, a))) { w[i] = b; w[p] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = threadIdx.x; i < WS_TILE; i += 256) { const uint64_t g = ws + i; if (g >= c0 && g < c1) out[g] = w[i]; }
+}
+template <class R>
+static int window_sort(cgx_ctx *ctx, const R *in, R *out, size_t n, uint32_t halo) {
+    if (n == 0) return CGX_OK;
+    if (n > 0xFFFFFFF0ull || 2 * halo + 256 > WS_TILE) return fail(ctx, CGX_ERR_ARG, "window_sort: size", hipSuccess);
+    const uint32_t S = WS_TILE - 2 * halo;
+    k_window_sort<R><<<(unsigned)((n + S - 1) / S), 256, 0, ctx->stream>>>(in, out, (uint32_t)n, halo);
+    HIPCHK(hipGetLastError());
+    return CGX_OK;
+}
+
 // ------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------
@@ -355,7 +398,7 @@ static void free_batch(cgx_ctx *c) {
     c->guard_exits = 0;
 }
 static void free_index(cgx_ctx *c) {
-    dfree(c->d_str); dfree(c->d_sa); dfree(c->d_rlp); dfree(c->d_tstr); dfree(c->d_ltar); dfree(c->d_rtar); dfree(c->d_tok8); dfree(c->d_lr16);
+    dfree(c->d_str); dfree(c->d_sa); dfree(c->d_rlp); dfree(c->d_tstr); dfree(c->d_ltar); dfree(c->d_rtar); dfree(c->d_tok8); dfree(c->d_lr16); dfree(c->d_pos1);
     dfree(c->d_lexkey); dfree(c->d_lexv1); dfree(c->d_lexv2); dfree(c->d_lexn1); dfree(c->d_lexn2); dfree(c->d_lexrow); dfree(c->d_lexnullt); dfree(c->d_lexhkey); dfree(c->d_lexhidx); dfree(c->d_lexslot); dfree(c->d_lexnullv); c->lex_hmask = 0;
     dfree(c->d_tokstart); dfree(c->d_tokrank); dfree(c->d_freq); dfree(c->d_pidx); dfree(c->d_miss);
     dfree(c->d_phit_start); dfree(c->d_phit_len); for (int k = 0; k < 4; k++) { dfree(c->d_ng[k]); c->ng_cap[k] = 0; }
@@ -388,6 +431,7 @@ extern "C" int cgx_set_option(cgx_ctx *c, const char *name, int64_t value) {
     if (!strcmp(name, "ngram_tables")) { if (value < 1 || value > 5) return CGX_ERR_ARG; c->ngram_max = (int)value; return CGX_OK; }
     if (!strcmp(name, "gz_level")) { if (value < 0 || value > 9) return CGX_ERR_ARG; c->gz_level = (int)value; return CGX_OK; }
     if (!strcmp(name, "use_layouts")) { c->use_layouts = value != 0; return CGX_OK; }
+    if (!strcmp(name, "occ_order")) { c->occ_order = value != 0; return CGX_OK; }
     if (!strcmp(name, "count_probes")) { c->count_probes = value != 0; return CGX_OK; }
     if (!strcmp(name, "numa_pin")) { c->numa_pin = value != 0; return CGX_OK; }
     if (!strcmp(name, "prealloc_text")) { c->prealloc_text = value != 0; return CGX_OK; }

@@ -1285,6 +1285,27 @@ static int dev_write_files(pending *pw) {
     return rc;
 }
 
+/* The file phase by itself, for a caller that holds the unique text and the piece lists (cgx_text_info / cgx_text_read /
+ * cgx_text_segments hand them out): assembles grammar.<first+q>.s for q < nq in `outdir` with `nthreads` threads, exactly as the
+ * writer of cgx_extract_grammars* does (the same write_one_file).  Needs no GPU and no context: tools/rehearse_writers.py
+ * replays one recorded batch from several processes at once to measure what one host can write. */
+int cgx_assemble_files(const char *utext, const uint64_t *qseg, const uint64_t *seg_off, const uint32_t *seg_len, int32_t nq, int32_t first,
+                       const char *outdir, int nthreads, double *file_ms) {
+    if (!utext || !qseg || !seg_off || !seg_len || nq < 0 || !outdir) return CGX_ERR_ARG;
+    int nt = nthreads < 1 ? 1 : nthreads > MAX_WRITERS ? MAX_WRITERS : nthreads; if (nt > nq) nt = nq > 0 ? nq : 1;
+    devjob jobs[MAX_WRITERS]; pthread_t th[MAX_WRITERS]; int started[MAX_WRITERS]; int32_t next = 0; int rc = CGX_OK;
+    for (int t = 0; t < nt; t++) { memset(&jobs[t], 0, sizeof jobs[t]); jobs[t].tid = t; jobs[t].nq = nq; jobs[t].first = first; jobs[t].outdir = outdir; jobs[t].next_q = &next;
+                                   jobs[t].utext = utext; jobs[t].qseg = qseg; jobs[t].seg_off = seg_off; jobs[t].seg_len = seg_len; jobs[t].rc = CGX_OK; }
+    started[0] = 1;
+    for (int t = 1; t < nt; t++) started[t] = !pthread_create(&th[t], NULL, dev_write_worker, &jobs[t]);
+    dev_write_worker(&jobs[0]);
+    for (int t = 1; t < nt; t++) if (started[t]) pthread_join(th[t], NULL);
+    double wr = 0; int ran = 0;
+    for (int t = 0; t < nt; t++) if (started[t]) { if (jobs[t].rc != CGX_OK && rc == CGX_OK) rc = jobs[t].rc; wr += jobs[t].file_ms; ran++; }
+    if (file_ms) *file_ms = wr / (ran ? ran : 1);
+    return rc;
+}
+
 /* number of grammar lines the writer will produce (PrintResults.c:451-570 walked without formatting) */
 static uint64_t range_len(const range *r, uint32_t id) { return (r[id].down == -1 || r[id].up == -1) ? 0 : (uint64_t)(r[id].up - r[id].down + 1); }
 static uint64_t count_lines(const batch *b) {

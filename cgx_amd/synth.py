@@ -20,6 +20,21 @@ def _zipf_ids(rng, n, vocab):
     return np.clip(r, 0, vocab - 1)
 
 
+def make_source_tokens(pairs, vocab, seed, lo=5, hi=45):
+    """Only the source token array of make_corpus(pairs, vocab, seed, lo, hi) (the same first draws of the same generator):
+    what a suffix-array builder needs, in a tenth of the time and memory."""
+    rng = np.random.default_rng(seed)
+    slen = rng.integers(lo, hi + 1, pairs).astype(np.int64)
+    ns = int(slen.sum())
+    words = _zipf_ids(rng, ns, vocab) + 2
+    sent_of = np.repeat(np.arange(pairs, dtype=np.int32), slen)
+    n = ns + pairs + 2
+    str_ = np.ones(n, np.int32)
+    str_[np.arange(ns, dtype=np.int64) + sent_of] = words
+    str_[n - 1] = int(words.max()) + 1
+    return str_
+
+
 def make_corpus(pairs, vocab, seed, lo=5, hi=45):
     rng = np.random.default_rng(seed)
     slen = rng.integers(lo, hi + 1, pairs).astype(np.int64)

@@ -125,6 +125,10 @@ int cgx_text_offsets(cgx_ctx *ctx, int slot, uint64_t *qtext);                  
 int cgx_text_read(cgx_ctx *ctx, int slot, uint64_t off, uint64_t bytes, void *dst, int reader); /* D2H of unique-text bytes on side stream `reader` (0..CGX_MAX_READERS-1), thread safe per reader */
 int cgx_text_read_begin(cgx_ctx *ctx, int slot, uint64_t off, uint64_t bytes, void *dst, int reader); /* the same copy, only enqueued */
 int cgx_text_read_wait(cgx_ctx *ctx, int reader);                                                      /* wait for everything enqueued on `reader` */
+/* the file phase alone: grammar.<first+q>.s, q < nq, assembled in `outdir` by `nthreads` host threads from a unique text and piece lists held by the caller
+ * (no GPU, no context needed; what the writer of cgx_extract_grammars* runs after the DMA).  *file_ms = mean busy time per thread */
+int cgx_assemble_files(const char *utext, const uint64_t *qseg, const uint64_t *seg_off, const uint32_t *seg_len, int32_t nq, int32_t first,
+                       const char *outdir, int nthreads, double *file_ms);
 void *cgx_pinned_alloc(size_t bytes);
 void cgx_pinned_free(void *p);
 

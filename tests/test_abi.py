@@ -113,3 +113,27 @@ def test_loader_tokenisation_quirks(lib, tmp_path):
     (d / "s.e").write_text("x y\n")
     with pytest.raises(cgx_amd.CgxError, match="lines"):
         cgx_amd.Corpus.load(str(d / "s.f"), str(d / "s.e"), str(d / "s.a"), str(d / "lex"))
+
+
+def test_file_phase_assembles_files_from_text_and_pieces(tmp_path):
+    """cgx_assemble_files (no GPU, no context): the writer's file phase on a made-up unique text -- every file is the
+    concatenation of its pieces, an older longer file is cut to length, an empty query gives an empty file."""
+    import ctypes as C
+    import numpy as np
+    import cgx_amd
+    lib = cgx_amd.load_library()
+    lib.cgx_assemble_files.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_char_p, C.c_int, C.POINTER(C.c_double)]
+    rng = np.random.default_rng(1)
+    text = rng.integers(32, 127, 200000, dtype=np.uint8)
+    nq = 37; counts = rng.integers(0, 3000, nq); counts[5] = 0; counts[6] = 2500          # more pieces than one pwritev takes (IOV_MAX = 1024)
+    qseg = np.concatenate(([0], np.cumsum(counts))).astype(np.uint64); ns = int(qseg[-1])
+    seg_len = rng.integers(1, 90, ns).astype(np.uint32); seg_off = rng.integers(0, len(text) - 100, ns).astype(np.uint64)
+    out = tmp_path / "g"; out.mkdir()
+    (out / "grammar.103.s").write_bytes(b"x" * 10_000_000)                                # stale, longer than what replaces it
+    for threads in (1, 5):
+        ms = C.c_double()
+        assert lib.cgx_assemble_files(text.ctypes.data, qseg.ctypes.data, seg_off.ctypes.data, seg_len.ctypes.data, nq, 100, str(out).encode(), threads, C.byref(ms)) == 0
+        for q in range(nq):
+            want = b"".join(text[int(seg_off[s]):int(seg_off[s]) + int(seg_len[s])].tobytes() for s in range(int(qseg[q]), int(qseg[q + 1])))
+            assert (out / ("grammar.%d.s" % (100 + q))).read_bytes() == want, q
+    assert lib.cgx_assemble_files(text.ctypes.data, qseg.ctypes.data, seg_off.ctypes.data, seg_len.ctypes.data, nq, 0, str(tmp_path / "missing").encode(), 2, None) != 0
