@@ -326,45 +326,103 @@ static int sort128(cgx_ctx *ctx, uint64_t *&hi, uint64_t *&lo, size_t n, unsigne
     return CGX_OK;
 }
 
-// ---- windowed sort in LDS -------------------------------------------------------------------------------------------
-// The rule and lexicon keys of a batch are "id-major with short runs": the array is already ordered by its major field (the
-// rule / lexicon id: work items are laid out unit by unit), and the records of one id are at most `halo` apart (a unit has at
-// most 300 / 65 / 70 sampled occurrences).  Only the order INSIDE each id run is missing.  A global radix sort spends 7-10
-// passes over the whole array on that; here a block loads a tile of WS_TILE records -- its own `core` plus `halo` records of
-// context on either side -- sorts the tile with a bitonic network in LDS and writes back its core.  Because the major field
-// is non-decreasing, sorting a tile only moves records inside their run's own position range, and every run that touches the
-// core lies wholly inside the tile, so the core positions receive exactly what a global sort would put there.  One read and
-// one write of the array instead of 14-20.
-#define WS_TILE 2048
-struct wrec64  { uint64_t k;            static __device__ __forceinline__ wrec64 inf() { return wrec64{~0ull}; }            static __device__ __forceinline__ bool less(const wrec64 &a, const wrec64 &b) { return a.k < b.k; } };
-struct wrec128 { uint64_t h, l;         static __device__ __forceinline__ wrec128 inf() { return wrec128{~0ull, ~0ull}; }   static __device__ __forceinline__ bool less(const wrec128 &a, const wrec128 &b) { return a.h < b.h || (a.h == b.h && a.l < b.l); } };
-struct wrec96  { uint64_t k; uint32_t i, pad; static __device__ __forceinline__ wrec96 inf() { return wrec96{~0ull, ~0u, 0u}; } static __device__ __forceinline__ bool less(const wrec96 &a, const wrec96 &b) { return a.k < b.k || (a.k == b.k && a.i < b.i); } };
-template <class R>
-__global__ __launch_bounds__(256) void k_window_sort(const R *__restrict__ in, R *__restrict__ out, uint32_t n, uint32_t halo) {
-    __shared__ R w[WS_TILE];
-    const uint32_t S = WS_TILE - 2 * halo;
-    const uint64_t c0 = (uint64_t)blockIdx.x * S, c1 = c0 + S < n ? c0 + S : n, ws = c0 > halo ? c0 - halo : 0;
-    for (uint32_t i = threadIdx.x; i < WS_TILE; i += 256) { const uint64_t g = ws + i; w[i] = g < n ? in[g] : R::inf(); }
+// ---- sorting inside short id runs --------------------------------------------------------------------------------------
+// The rule and lexicon keys of a batch are "id-major with short runs": work items are laid out unit by unit (block by block,
+// pattern by pattern), so the array is already ordered by its id (`major`, non-decreasing) and one id has at most RS_MAXRUN
+// records (a unit has at most 300 / 65 / 70 sampled occurrences).  Only the order INSIDE each id run is missing, and the id
+// need not even be part of the key.  A device-wide radix sort spends 7-10 passes over the whole array on that (round 2: 24 ms
+// per batch for the rule keys, 16 ms for the lexicon keys).  Here, two kernels, one read and one write of the array:
+//   k_runsort_block   a block takes 256 consecutive records into LDS; every record counts the records of ITS run inside the block
+//                     that sort before it (ties by position: stable) and goes to that rank.  Runs that lie inside one block --
+//                     nearly all of them -- are done; the work per record is its run's length, at most 256.
+//   k_runsort_fix     one wave per block boundary that cuts a run: the run's pieces (each sorted by the first kernel) are loaded
+//                     into LDS and ranked against each other.
+// (Measured and dropped on the way, profiles/r3l, r3m: a bitonic network over 2048-record tiles with halos -- 66 barrier stages,
+// 68 us per tile; a counting rank sort over such tiles -- per-thread tails on 300-record runs; rocPRIM's segmented radix sort --
+// 5 ms per 6.7e7 keys in 1e7 segments.  All three were slower than the radix sort they were to replace.)
+#define RS_BLOCK 256
+#define RS_MAXRUN 320
+template <bool VAL>
+__global__ __launch_bounds__(RS_BLOCK) void k_runsort_block(const uint32_t *__restrict__ major, const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin,
+                                                             uint64_t *__restrict__ kout, uint32_t *__restrict__ vout, uint32_t n) {
+    __shared__ uint64_t sk[RS_BLOCK + 8]; __shared__ unsigned long long heads[RS_BLOCK / 64];
+    const uint32_t base = blockIdx.x * RS_BLOCK, i = base + threadIdx.x;
+    const bool valid = i < n;
+    const uint64_t k = valid ? kin[i] : ~0ull; const uint32_t m = valid ? major[i] : 0xFFFFFFFFu;
+    uint32_t v = 0; if (VAL && valid) v = vin[i];
+    // run heads: a record whose id differs from its left neighbour's (the first record of the block always).  One ballot per
+    // wave gives every lane the bounds of its run without walking: the nearest head at or before it, the next head after it.
+    const uint32_t mprev = (threadIdx.x == 0 || i == 0 || !valid) ? ~m : major[i - 1];       // i - 1 is in this block for threadIdx.x > 0: an L1 hit
+    const unsigned long long hmask = __ballot(threadIdx.x == 0 || !valid || mprev != m);
+    const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+    if (lane == 0) heads[wave] = hmask;
+    sk[threadIdx.x] = k;
     __syncthreads();
-    for (uint32_t k = 2; k <= WS_TILE; k <<= 1) {
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t t = threadIdx.x; t < WS_TILE / 2; t += 256) {
-                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), p = i | j;           // the pair (i, i + j), i with bit j clear
-                const bool asc = (i & k) == 0;
-                const R a = w[i], b = w[p];
-                if (R::less(b, a) == asc && (R::less(a, b) || R::less(b, a))) { w[i] = b; w[p] = a; }
-            }
-            __syncthreads();
-        }
+    if (!valid) return;
+    // lo: highest head bit at or below this position, searching this wave's mask, then the waves to the left
+    int lo = -1; { int w = wave; unsigned long long hm = heads[w] & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+                   while (hm == 0) { w--; hm = heads[w]; }              // wave 0 has bit 0 set: terminates
+                   lo = w * 64 + 63 - __clzll((long long)hm); }
+    // hi: one before the next head above this position (or the end of the block / of the valid records)
+    int hi; { int w = wave; unsigned long long hm = lane == 63 ? 0ull : (heads[w] >> (lane + 1)) << (lane + 1);
+              while (hm == 0 && w + 1 < RS_BLOCK / 64) { w++; hm = heads[w]; }
+              hi = hm ? w * 64 + __ffsll((long long)hm) - 2 : RS_BLOCK - 1; }
+    uint32_t rank = 0; const int me = (int)threadIdx.x;
+    int x = lo;
+    for (; x + 3 <= hi; x += 4) {                                        // four independent LDS reads in flight
+        const uint64_t o0 = sk[x], o1 = sk[x + 1], o2 = sk[x + 2], o3 = sk[x + 3];
+        rank += (o0 < k || (o0 == k && x < me)) + (o1 < k || (o1 == k && x + 1 < me)) + (o2 < k || (o2 == k && x + 2 < me)) + (o3 < k || (o3 == k && x + 3 < me));
     }
-    for (uint32_t i = threadIdx.x; i < WS_TILE; i += 256) { const uint64_t g = ws + i; if (g >= c0 && g < c1) out[g] = w[i]; }
+    for (; x <= hi; x++) { const uint64_t o = sk[x]; rank += (o < k || (o == k && x < me)) ? 1u : 0u; }
+    kout[base + (uint32_t)lo + rank] = k; if (VAL) vout[base + (uint32_t)lo + rank] = v;
 }
-template <class R>
-static int window_sort(cgx_ctx *ctx, const R *in, R *out, size_t n, uint32_t halo) {
+template <bool VAL>
+__global__ __launch_bounds__(64) void k_runsort_fix(const uint32_t *__restrict__ major, uint64_t *__restrict__ key, uint32_t *__restrict__ val, uint32_t n) {
+    __shared__ uint64_t sk[RS_MAXRUN]; __shared__ uint32_t sv[RS_MAXRUN];
+    const uint32_t p = (blockIdx.x + 1) * RS_BLOCK;            // the boundary between record p-1 and record p
+    if (p >= n) return;
+    const uint32_t m = major[p];
+    if (major[p - 1] != m) return;                               // no run is cut here
+    const int lane = (int)threadIdx.x;
+    // run start: the first record of the id, at most RS_MAXRUN back (wave-parallel: every lane looks at one record per round)
+    uint32_t rs = p;
+    for (uint32_t back = 0; back < RS_MAXRUN; back += 64) {
+        const uint32_t q = p - 1 - back - (uint32_t)lane; const bool same = p >= 1 + back + (uint32_t)lane && major[q] == m;
+        const unsigned long long b = __ballot(same);
+        const int run = b == ~0ull ? 64 : __ffsll((long long)~b) - 1;   // lanes 0..run-1 still belong to the id
+        rs = p - back - (uint32_t)run;
+        if (run < 64) break;
+    }
+    if ((rs / RS_BLOCK + 1) * RS_BLOCK != p) return;             // a run cut by several boundaries is handled at the first of them
+    uint32_t re = p;                                             // one past the last record of the id
+    for (uint32_t fwd = 0; fwd < RS_MAXRUN; fwd += 64) {
+        const uint32_t q = p + fwd + (uint32_t)lane; const bool same = q < n && major[q] == m;
+        const unsigned long long b = __ballot(same);
+        const int run = b == ~0ull ? 64 : __ffsll((long long)~b) - 1;
+        re = p + fwd + (uint32_t)run;
+        if (run < 64) break;
+    }
+    const uint32_t len = re - rs;
+    if (len > RS_MAXRUN) return;                                 // not a short run: the callers' contract excludes it (checked on the host)
+    for (uint32_t j = (uint32_t)lane; j < len; j += 64) { sk[j] = key[rs + j]; if (VAL) sv[j] = val[rs + j]; }
+    __syncthreads();
+    for (uint32_t j = (uint32_t)lane; j < len; j += 64) {
+        const uint64_t k = sk[j]; uint32_t rank = 0;
+        for (uint32_t x = 0; x < len; x++) { const uint64_t o = sk[x]; rank += (o < k || (o == k && x < j)) ? 1u : 0u; }
+        key[rs + rank] = k; if (VAL) val[rs + rank] = sv[j];
+    }
+}
+// keys (and an optional payload) sorted inside every run of equal `major`; kout/vout must not alias the inputs
+static int run_sort(cgx_ctx *ctx, const uint32_t *major, const uint64_t *kin, const uint32_t *vin, uint64_t *kout, uint32_t *vout, size_t n) {
     if (n == 0) return CGX_OK;
-    if (n > 0xFFFFFFF0ull || 2 * halo + 256 > WS_TILE) return fail(ctx, CGX_ERR_ARG, "window_sort: size", hipSuccess);
-    const uint32_t S = WS_TILE - 2 * halo;
-    k_window_sort<R><<<(unsigned)((n + S - 1) / S), 256, 0, ctx->stream>>>(in, out, (uint32_t)n, halo);
+    if (n > 0xFFFFFF00ull) return fail(ctx, CGX_ERR_NOMEM, "run_sort: too many records", hipSuccess);
+    const unsigned nb = nblocks(n, RS_BLOCK);
+    if (vin) k_runsort_block<true><<<nb, RS_BLOCK, 0, ctx->stream>>>(major, kin, vin, kout, vout, (uint32_t)n);
+    else k_runsort_block<false><<<nb, RS_BLOCK, 0, ctx->stream>>>(major, kin, nullptr, kout, nullptr, (uint32_t)n);
+    if (nb > 1) {
+        if (vin) k_runsort_fix<true><<<nb - 1, 64, 0, ctx->stream>>>(major, kout, vout, (uint32_t)n);
+        else k_runsort_fix<false><<<nb - 1, 64, 0, ctx->stream>>>(major, kout, nullptr, (uint32_t)n);
+    }
     HIPCHK(hipGetLastError());
     return CGX_OK;
 }
