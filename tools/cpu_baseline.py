@@ -105,21 +105,6 @@ def main():
     lib = load_oracle()
     scratch = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
 
-    # the reference's own suffix-array builder on the FULL benchmark corpus (one core, beside everything below)
-    full = None; ref_bin = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
-    if args.full_sa_seconds > 0 and args.corpus_pairs > 0 and os.path.exists(ref_bin):
-        try:
-            tf = time.perf_counter()
-            fs = synth.make_source_tokens(args.corpus_pairs, args.vocab, args.seed)
-            fd = tempfile.mkdtemp(prefix="cgx_fullsa_", dir=scratch); fdump = os.path.join(fd, "str.dump")
-            with open(fdump, "wb") as f:                            # the two sections ref_harness time-sa reads: header[0] = n, str = n tokens + 3 zero pads
-                hdr = np.zeros(15, np.uint32); hdr[0] = len(fs)
-                f.write(b"header".ljust(8, b"\0") + np.uint64(hdr.nbytes).tobytes() + hdr.tobytes())
-                f.write(b"str".ljust(8, b"\0") + np.uint64((len(fs) + 3) * 4).tobytes()); fs.tofile(f); f.write(np.zeros(3, np.int32).tobytes())
-            full = {"proc": subprocess.Popen([ref_bin, "time-sa", fdump], stdout=subprocess.PIPE, text=True), "dir": fd, "t0": time.perf_counter(), "tokens": int(len(fs)), "prep_s": time.perf_counter() - tf}
-            del fs
-        except Exception as e:
-            full = {"error": repr(e)}
     t0 = time.perf_counter()
     corpus = synth.make_corpus(args.pairs, args.vocab, args.seed)        # same model, vocabulary and seed as the benchmark corpus, fewer sentence pairs
     t_gen = time.perf_counter() - t0
@@ -169,7 +154,6 @@ def main():
             refd["error"] = repr(e)
         shutil.rmtree(d, ignore_errors=True)
     res["reference_objects"] = refd or None
-    _G["full"] = full
 
     # ---- all cores: forked workers share the index copy-on-write ----
     _G.update(lib=lib, ix=ix, qoff=qoff, qtok=qtok, scratch=scratch)
@@ -181,14 +165,28 @@ def main():
     slow = max(o[0] for o in outs)
     res["all_cores"] = {"value": round(cores * n1 / slow, 3), "rules_per_s": round(sum(o[1] for o in outs) / slow, 1), "cores": cores, "queries": cores * n1,
                         "seconds": round(slow, 3), "wall_seconds_with_fork": round(wall, 3)}
-    full = _G.get("full")
+    # the reference's own suffix-array builder on the FULL benchmark corpus (one core; started only now, after the timed legs: run beside them it took one of the 16 CPUs and a good part of the memory bandwidth and cut the all-core figure by a third)
+    full = None; ref_bin = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+    if args.full_sa_seconds > 0 and args.corpus_pairs > 0 and os.path.exists(ref_bin):
+        try:
+            tf = time.perf_counter()
+            fs = synth.make_source_tokens(args.corpus_pairs, args.vocab, args.seed)
+            fd = tempfile.mkdtemp(prefix="cgx_fullsa_", dir=scratch); fdump = os.path.join(fd, "str.dump")
+            with open(fdump, "wb") as f:                            # the two sections ref_harness time-sa reads: header[0] = n, str = n tokens + 3 zero pads
+                hdr = np.zeros(15, np.uint32); hdr[0] = len(fs)
+                f.write(b"header".ljust(8, b"\0") + np.uint64(hdr.nbytes).tobytes() + hdr.tobytes())
+                f.write(b"str".ljust(8, b"\0") + np.uint64((len(fs) + 3) * 4).tobytes()); fs.tofile(f); f.write(np.zeros(3, np.int32).tobytes())
+            full = {"proc": subprocess.Popen([ref_bin, "time-sa", fdump], stdout=subprocess.PIPE, text=True), "dir": fd, "t0": time.perf_counter(), "tokens": int(len(fs)), "prep_s": time.perf_counter() - tf}
+            del fs
+        except Exception as e:
+            full = {"error": repr(e)}
     if full and "proc" in full:                                  # join the full-size reference run (it has had the time of every leg above)
         try:
             left = max(1.0, args.full_sa_seconds - (time.perf_counter() - full["t0"]))
             out, _ = full["proc"].communicate(timeout=left)
             if full["proc"].returncode == 0 and out.strip():
                 refd["suffixArrayConstruct_full_s"] = float(out.strip().split()[-1]); refd["suffixArrayConstruct_full_tokens"] = full["tokens"]
-                refd["suffixArrayConstruct_full_note"] = "SuffixArray.c:196-242 (DC3 + LCP tables) compiled in place, one core, on the source tokens of the whole benchmark corpus; ran beside the other CPU legs"
+                refd["suffixArrayConstruct_full_note"] = "SuffixArray.c:196-242 (DC3 + LCP tables) compiled in place, one core, on the source tokens of the whole benchmark corpus; run after the other CPU legs"
             else:
                 refd["suffixArrayConstruct_full_s"] = None; refd["suffixArrayConstruct_full_note"] = "ref_harness exited with %s" % full["proc"].returncode
         except subprocess.TimeoutExpired:

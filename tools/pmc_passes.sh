@@ -6,7 +6,7 @@ OUT=$1; shift
 REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 mkdir -p "$OUT"; OUT=$(cd "$OUT" && pwd)
 cd /tmp && export TMPDIR=/tmp
-KER='k_look1|k_look2|k_lex_finish|k_fmt_lines|k_extract|k_sa_lookup'
+KER='k_look1|k_look2|k_lex_finish|k_fmt_lines|k_extract|k_sa_lookup|k_runsort'
 i=0
 for grp in \
   "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VALU" \
