@@ -52,7 +52,7 @@ ABI = [
     "cgx_upload_queries", "cgx_sa_lookup", "cgx_gappy_search", "cgx_make_blocks", "cgx_set_blocks", "cgx_extract", "cgx_lexicon", "cgx_lex_features", "cgx_fetch",
     "cgx_stage_ms", "cgx_corpus_load", "cgx_corpus_free", "cgx_corpus_checksum", "cgx_corpus_save", "cgx_corpus_load_cache", "cgx_corpus_matches_sources", "cgx_corpus_upload", "cgx_extract_grammars", "cgx_extract_grammars_shard", "cgx_shard_bounds", "cgx_extract_grammars_ids",
     "cgx_corpus_from_ids", "cgx_host_ms", "cgx_flush", "cgx_fetch_pinned", "cgx_pinned_next_batch", "cgx_upload_vocab", "cgx_upload_score_tables", "cgx_set_query_blocks",
-    "cgx_format", "cgx_text_info", "cgx_text_segments", "cgx_text_segments_begin", "cgx_text_offsets", "cgx_text_read", "cgx_text_read_begin", "cgx_text_read_wait", "cgx_pinned_alloc", "cgx_pinned_free", "cgx_assemble_files",
+    "cgx_format", "cgx_text_info", "cgx_text_segments", "cgx_text_segments_begin", "cgx_text_offsets", "cgx_text_read", "cgx_text_read_begin", "cgx_text_read_wait", "cgx_pinned_alloc", "cgx_pinned_free", "cgx_assemble_files", "cgx_corpus_load_opt",
 ]
 
 
@@ -63,7 +63,7 @@ class CgxError(RuntimeError):
 class IndexHost(C.Structure):
     _fields_ = [("str", C.c_void_p), ("n", C.c_uint32), ("rlp", C.c_void_p), ("tstr", C.c_void_p), ("nt", C.c_uint32),
                 ("ltar", C.c_void_p), ("rtar", C.c_void_p), ("lexk", C.c_void_p), ("lexv", C.c_void_p), ("nlex", C.c_uint32),
-                ("sa", C.c_void_p)]
+                ("sa", C.c_void_p), ("ltar16", C.c_void_p), ("rtar16", C.c_void_p)]      # the last two: long-sentence mode only (None otherwise)
 
 
 _lib = None
@@ -125,10 +125,11 @@ class Corpus:
         self._keep = keep
 
     @classmethod
-    def load(cls, src, tgt, align, lex):
+    def load(cls, src, tgt, align, lex, long_sentences=False):
         lib = load_library()
         err = C.create_string_buffer(512)
-        h = lib.cgx_corpus_load(src.encode(), tgt.encode(), align.encode(), lex.encode(), err, 512)
+        lib.cgx_corpus_load_opt.restype = C.c_void_p; lib.cgx_corpus_load_opt.argtypes = [C.c_char_p] * 4 + [C.c_int, C.c_char_p, C.c_size_t]
+        h = lib.cgx_corpus_load_opt(src.encode(), tgt.encode(), align.encode(), lex.encode(), 1 if long_sentences else 0, err, 512)
         if not h:
             raise CgxError(err.value.decode(errors="replace"))
         return cls(h)

@@ -31,6 +31,8 @@ struct cgx_ctx {
     int32_t *d_str = nullptr, *d_sa = nullptr, *d_tstr = nullptr;
     uint32_t *d_rlp = nullptr;
     uint8_t *d_ltar = nullptr, *d_rtar = nullptr;
+    bool long_pos = false;              // long-sentence mode (cgx_rules.h): alignment words carry extra position bits, target-side tables are 16-bit
+    uint16_t *d_ltar16 = nullptr, *d_rtar16 = nullptr;
     cgx_tok8 *d_tok8 = nullptr; uint8_t *d_lr16 = nullptr;   // derived layouts (cgx_rules.h), built by build_layouts
     int32_t *d_pos1 = nullptr;          // derived: the corpus positions of every token in ascending order, token by token (same buckets as the suffix array's one-token intervals: tokstart)
     uint64_t *d_lexkey = nullptr; float *d_lexv1 = nullptr, *d_lexv2 = nullptr, *d_lexn1 = nullptr, *d_lexn2 = nullptr;

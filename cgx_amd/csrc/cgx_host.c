@@ -73,6 +73,7 @@ struct cgx_corpus {
     int32_t *str, *tstr, *sentind, *tsentind;
     uint8_t *P;
     uint32_t *rlp; uint8_t *ltar, *rtar;
+    int long_pos; uint16_t *ltar16, *rtar16;              /* long-sentence mode (cgx_corpus_load_opt, CGX_CORPUS_LONG_SENTENCES): wider positions, see cgx_rules.h */
     char **svocab, **tvocab; int32_t nsvocab, ntvocab;   /* id -> spelling, NULL entries when built from ids */
     uint32_t *svlen, *tvlen; uint32_t maxword;            /* spelling lengths (writer) */
     struct wslot { uint8_t len; char s[15]; } *svslot, *tvslot;   /* words of <= 15 bytes packed in 16-byte slots: one cache line serves four words */
@@ -242,21 +243,41 @@ static int load_side(const char *path, int32_t **str_out, uint32_t *n_out, uint8
     return rc;
 }
 
-static int pack_alignment(cgx_corpus *c, const uint8_t *Ls, const uint8_t *Rs) {
+/* cgx_rlp_pack of csrc/cgx_rules.h, restated for this C file: L / R < 0 = not aligned; position codes skip every value whose low byte is 255 */
+static uint32_t rlp_pack_long(int L, int R, uint32_t P) {
+    const uint32_t cl = L < 0 ? 255u : (uint32_t)L + (uint32_t)L / 255u, cr = R < 0 ? 255u : (uint32_t)R + (uint32_t)R / 255u;
+    return ((cl & 255u) << 24) | ((cr & 255u) << 16) | ((P & 255u) << 8) | ((cl >> 8) << 5) | ((cr >> 8) << 2) | (P >> 8);
+}
+#define LONG_MAX_SRC 1024
+#define LONG_MAX_TGT 2040
+/* Ls / Rs: min / max aligned target position per source token, -1 = none */
+static int pack_alignment_i(cgx_corpus *c, const int32_t *Ls, const int32_t *Rs) {
     c->rlp = calloc((size_t)c->n + 1, sizeof(uint32_t));
     if (!c->rlp) return -1;
     int q = 1;
     for (uint32_t i = 0; i + 1 < c->n; i++) {
         if (q <= c->nsent && (int32_t)i == c->sentind[q] - 1) { c->rlp[i] = (uint32_t)c->tsentind[q]; q++; }
-        else c->rlp[i] = ((uint32_t)Ls[i] << 24) | ((uint32_t)Rs[i] << 16) | ((uint32_t)c->P[i] << 8);
+        else if (!c->long_pos) c->rlp[i] = ((uint32_t)(Ls[i] < 0 ? 255 : Ls[i]) << 24) | ((uint32_t)(Rs[i] < 0 ? 255 : Rs[i]) << 16) | ((uint32_t)c->P[i] << 8);
+        else {
+            const uint32_t pp = q - 1 < c->nsent ? (uint32_t)((int32_t)i - c->sentind[q - 1]) : 0u;      /* the token's true position in its sentence */
+            if (pp >= LONG_MAX_SRC) return -2;
+            c->rlp[i] = rlp_pack_long(Ls[i], Rs[i], pp);
+        }
     }
     return 0;
 }
+static int pack_alignment(cgx_corpus *c, const uint8_t *Ls, const uint8_t *Rs) {      /* byte tables (cgx_corpus_from_ids) */
+    int32_t *l = malloc(((size_t)c->n + 1) * 4), *r = malloc(((size_t)c->n + 1) * 4); int rc = -1;
+    if (l && r) { for (uint32_t i = 0; i < c->n; i++) { l[i] = Ls[i] == 255 ? -1 : Ls[i]; r[i] = Rs[i] == 255 ? -1 : Rs[i]; } rc = pack_alignment_i(c, l, r); }
+    free(l); free(r);
+    return rc;
+}
 /* Alignment lines are independent once their line number is known, and line q only touches the tokens of
  * sentence pair q: pieces of whole lines are parsed by several threads; the error of the earliest piece wins. */
-typedef struct { cgx_corpus *c; const char *buf; size_t begin, end; int q0, rc; uint8_t *Ls, *Rs; char err[160]; } alignpiece;
+typedef struct { cgx_corpus *c; const char *buf; size_t begin, end; int q0, rc; int32_t *Ls, *Rs, *lt, *rt; char err[160]; } alignpiece;
 static void *align_piece_job(void *arg) {
-    alignpiece *a = arg; cgx_corpus *c = a->c; const char *buf = a->buf; uint8_t *Ls = a->Ls, *Rs = a->Rs;
+    alignpiece *a = arg; cgx_corpus *c = a->c; const char *buf = a->buf; int32_t *Ls = a->Ls, *Rs = a->Rs, *lt = a->lt, *rt = a->rt;
+    const int max_s = c->long_pos ? LONG_MAX_SRC : 255, max_t = c->long_pos ? LONG_MAX_TGT : 255;       /* the reference: 255 (ExtractPair.cu:2683) */
     size_t i = a->begin; const size_t len = a->end; int q = a->q0 - 1; int rc = CGX_OK;
     while (i < len && rc == CGX_OK) {
         size_t e = i; while (e < len && buf[e] != '\n') e++;
@@ -273,11 +294,11 @@ static void *align_piece_job(void *arg) {
             p = t;
             if (!have_s) { s = val; have_s = 1; continue; }
             have_s = 0;
-            if (s >= 255 || val >= 255 || s < 0 || val < 0) { snprintf(a->err, sizeof a->err, "Not possible, too long sentence"); rc = CGX_ERR_ALIGN_RANGE; break; }
+            if (s >= max_s || val >= max_t || s < 0 || val < 0) { snprintf(a->err, sizeof a->err, "Not possible, too long sentence"); rc = CGX_ERR_ALIGN_RANGE; break; }
             uint32_t si = (uint32_t)(c->sentind[q] + s), ti = (uint32_t)(c->tsentind[q] + val);
             if (si >= (uint32_t)c->sentind[q + 1] || ti >= (uint32_t)c->tsentind[q + 1]) { snprintf(a->err, sizeof a->err, "alignment link outside its sentence pair on line %d", q + 1); rc = CGX_ERR_ARG; break; }
-            if (Ls[si] == 255 || Rs[si] == 255) Ls[si] = Rs[si] = (uint8_t)val; else if (val > Rs[si]) Rs[si] = (uint8_t)val; else if (val < Ls[si]) Ls[si] = (uint8_t)val;
-            if (c->ltar[ti] == 255 || c->rtar[ti] == 255) c->ltar[ti] = c->rtar[ti] = (uint8_t)s; else if (s > c->rtar[ti]) c->rtar[ti] = (uint8_t)s; else if (s < c->ltar[ti]) c->ltar[ti] = (uint8_t)s;
+            if (Ls[si] < 0 || Rs[si] < 0) Ls[si] = Rs[si] = val; else if (val > Rs[si]) Rs[si] = val; else if (val < Ls[si]) Ls[si] = val;
+            if (lt[ti] < 0 || rt[ti] < 0) lt[ti] = rt[ti] = s; else if (s > rt[ti]) rt[ti] = s; else if (s < lt[ti]) lt[ti] = s;
         }
         if (rc == CGX_OK && have_s) { snprintf(a->err, sizeof a->err, "Not possible!"); rc = CGX_ERR_ALIGN_PAIR; }
         i = e + 1;
@@ -288,14 +309,14 @@ static void *align_piece_job(void *arg) {
 static int load_alignment(cgx_corpus *c, const char *path, char *err, size_t errcap) {
     size_t len; char *buf = slurp(path, &len);
     if (!buf) { snprintf(err, errcap, "Can not open reference file \"%s\"", path); return CGX_ERR_IO; }
-    uint8_t *Ls = malloc(c->n), *Rs = malloc(c->n);
+    int32_t *Ls = malloc(((size_t)c->n + 1) * 4), *Rs = malloc(((size_t)c->n + 1) * 4), *lt = malloc(((size_t)c->nt + 1) * 4), *rt = malloc(((size_t)c->nt + 1) * 4);
     c->ltar = malloc((size_t)c->nt + 1); c->rtar = malloc((size_t)c->nt + 1);
-    if (!Ls || !Rs || !c->ltar || !c->rtar) return CGX_ERR_NOMEM;
-    memset(Ls, 255, c->n); memset(Rs, 255, c->n); memset(c->ltar, 255, c->nt); memset(c->rtar, 255, c->nt);
+    if (!Ls || !Rs || !lt || !rt || !c->ltar || !c->rtar) { free(Ls); free(Rs); free(lt); free(rt); free(buf); return CGX_ERR_NOMEM; }
+    memset(Ls, 0xFF, ((size_t)c->n + 1) * 4); memset(Rs, 0xFF, ((size_t)c->n + 1) * 4); memset(lt, 0xFF, ((size_t)c->nt + 1) * 4); memset(rt, 0xFF, ((size_t)c->nt + 1) * 4);   /* -1 = none */
     int np = nthreads_host() / 2; if (np > SIDE_MAX_PIECES) np = SIDE_MAX_PIECES; if (len < piece_min_bytes() || np < 1) np = 1;   /* the lexical table loads at the same time */
     alignpiece pc[SIDE_MAX_PIECES]; size_t cut = 0; int line = 0;
     for (int k = 0; k < np; k++) {
-        pc[k].c = c; pc[k].buf = buf; pc[k].Ls = Ls; pc[k].Rs = Rs; pc[k].rc = CGX_OK; pc[k].err[0] = 0; pc[k].begin = cut; pc[k].q0 = line;
+        pc[k].c = c; pc[k].buf = buf; pc[k].Ls = Ls; pc[k].Rs = Rs; pc[k].lt = lt; pc[k].rt = rt; pc[k].rc = CGX_OK; pc[k].err[0] = 0; pc[k].begin = cut; pc[k].q0 = line;
         size_t e = k + 1 == np ? len : len / (size_t)np * (size_t)(k + 1);
         if (e < cut) e = cut;
         while (e < len && buf[e] != '\n') e++;
@@ -311,8 +332,15 @@ static int load_alignment(cgx_corpus *c, const char *path, char *err, size_t err
     int rc = CGX_OK;
     for (int k = 0; k < np && rc == CGX_OK; k++) if (pc[k].rc != CGX_OK) { rc = pc[k].rc; snprintf(err, errcap, "%s", pc[k].err); }
     free(buf);
-    if (rc == CGX_OK && pack_alignment(c, Ls, Rs)) rc = CGX_ERR_NOMEM;
-    free(Ls); free(Rs);
+    /* target-side tables: bytes as in the reference; 16-bit words beside them in long-sentence mode */
+    for (uint32_t i = 0; i < c->nt; i++) { c->ltar[i] = (uint8_t)(lt[i] < 0 || lt[i] > 254 ? 255 : lt[i]); c->rtar[i] = (uint8_t)(rt[i] < 0 || rt[i] > 254 ? 255 : rt[i]); }
+    if (rc == CGX_OK && c->long_pos) {
+        c->ltar16 = malloc(((size_t)c->nt + 1) * 2); c->rtar16 = malloc(((size_t)c->nt + 1) * 2);
+        if (!c->ltar16 || !c->rtar16) rc = CGX_ERR_NOMEM;
+        else for (uint32_t i = 0; i < c->nt; i++) { c->ltar16[i] = (uint16_t)(lt[i] < 0 ? 0xFFFF : lt[i]); c->rtar16[i] = (uint16_t)(rt[i] < 0 ? 0xFFFF : rt[i]); }
+    }
+    if (rc == CGX_OK) { int pr = pack_alignment_i(c, Ls, Rs); if (pr == -2) { snprintf(err, errcap, "Not possible, too long sentence"); rc = CGX_ERR_ALIGN_RANGE; } else if (pr) rc = CGX_ERR_NOMEM; }
+    free(Ls); free(Rs); free(lt); free(rt);
     return rc;
 }
 /* Lexical table: four white-space separated fields per entry, like `file >> a >> b >> v1 >> v2` (entries, not lines:
@@ -415,6 +443,8 @@ uint64_t cgx_corpus_checksum(const cgx_corpus *c) {
     if (c->rlp) h = fnv_more(h, c->rlp, (size_t)c->n * 4);
     if (c->ltar) h = fnv_more(h, c->ltar, c->nt);
     if (c->rtar) h = fnv_more(h, c->rtar, c->nt);
+    if (c->ltar16) h = fnv_more(h, c->ltar16, (size_t)c->nt * 2);
+    if (c->rtar16) h = fnv_more(h, c->rtar16, (size_t)c->nt * 2);
     if (c->lexk) h = fnv_more(h, c->lexk, (size_t)c->nlex * sizeof *c->lexk);
     if (c->lexv) h = fnv_more(h, c->lexv, (size_t)c->nlex * sizeof *c->lexv);
     for (int32_t i = 2; c->svocab && i < c->nsvocab; i++) if (c->svocab[i]) h = fnv_more(h, c->svocab[i], strlen(c->svocab[i]) + 1);
@@ -426,7 +456,7 @@ void cgx_corpus_free(cgx_corpus *c) {
     for (int32_t i = 0; c->svocab && i < c->nsvocab; i++) free(c->svocab[i]);
     for (int32_t i = 0; c->tvocab && i < c->ntvocab; i++) free(c->tvocab[i]);
     free(c->svocab); free(c->tvocab); free(c->svlen); free(c->tvlen); free(c->svslot); free(c->tvslot); wordmap_free(&c->smap); wordmap_free(&c->tmap);
-    free(c->str); free(c->tstr); free(c->sentind); free(c->tsentind); free(c->P); free(c->rlp); free(c->ltar); free(c->rtar);
+    free(c->str); free(c->tstr); free(c->sentind); free(c->tsentind); free(c->P); free(c->rlp); free(c->ltar); free(c->rtar); free(c->ltar16); free(c->rtar16);
     free(c->lexk); free(c->lexv); free(c);
 }
 
@@ -440,10 +470,14 @@ static void *load_side_job(void *arg) {
     return NULL;
 }
 cgx_corpus *cgx_corpus_load(const char *src, const char *tgt, const char *align, const char *lex, char *err, size_t errcap) {
+    return cgx_corpus_load_opt(src, tgt, align, lex, 0, err, errcap);
+}
+cgx_corpus *cgx_corpus_load_opt(const char *src, const char *tgt, const char *align, const char *lex, int flags, char *err, size_t errcap) {
     char dummy[8]; if (!err) { err = dummy; errcap = sizeof dummy; }
     err[0] = 0;
     cgx_corpus *c = calloc(1, sizeof *c);
     if (!c) return NULL;
+    c->long_pos = (flags & CGX_CORPUS_LONG_SENTENCES) != 0;
     /* the two sides of the bitext are parsed concurrently, then the lexical table and the alignment (both only
      * read what the first pair produced) */
     int32_t tn = 0; const int trace = getenv("CGX_TRACE") != NULL; double t0 = now_ms();
@@ -522,6 +556,7 @@ cgx_corpus *cgx_corpus_from_ids(const int32_t *str, uint32_t n, const int32_t *s
 typedef struct { char magic[8]; uint64_t checksum; uint32_t n, nt, nsent, nlex, nsvocab, ntvocab, maxword, reserved; uint64_t sbytes, tbytes; uint64_t src_size[4], src_mtime[4]; } cachehdr;
 static const char CACHE_MAGIC[8] = {'C', 'G', 'X', 'C', 'O', 'R', 'P', '3'};   /* 3: source fingerprint = size + 1 and nanosecond mtime */
 int cgx_corpus_save(const cgx_corpus *c, const char *path) {
+    if (c && c->long_pos) return CGX_ERR_STATE;              /* the cache format holds the reference's byte tables only: a long-sentence corpus is parsed each time */
     if (!c || !path || !c->rlp || !c->svocab || !c->tvocab) return CGX_ERR_ARG;
     /* written under a private name and renamed into place: a reader (another --shard process started at the same time)
      * sees either no cache or a complete one, never a file with holes */
@@ -628,6 +663,7 @@ int cgx_corpus_upload(cgx_ctx *ctx, const cgx_corpus *c) {
     cgx_index_host ix; memset(&ix, 0, sizeof ix);
     ix.str = c->str; ix.n = c->n; ix.rlp = c->rlp; ix.tstr = c->tstr; ix.nt = c->nt; ix.ltar = c->ltar; ix.rtar = c->rtar;
     ix.lexk = c->lexk; ix.lexv = c->lexv; ix.nlex = c->nlex; ix.sa = NULL;
+    if (c->long_pos) { ix.ltar16 = c->ltar16; ix.rtar16 = c->rtar16; }
     int rc = cgx_upload_index(ctx, &ix);
     if (rc == CGX_OK) rc = cgx_build_sa(ctx);
     if (rc == CGX_OK) rc = cgx_precompute(ctx);

@@ -45,6 +45,8 @@ struct cgx_view {            // read-only index arrays (device pointers on the G
     const cgx_tok8 *tok8;    // str and rlp interleaved: a 16-token window is ONE 128-byte run instead of two 64-byte runs in two arrays
     const uint8_t *lr16;     // ltar/rtar in blocks of 16 target words: 16 L bytes, then their 16 R bytes -- the back-projection test
                              // of a <= 16-word span reads one 64..96-byte run instead of two runs in two arrays
+    const uint16_t *ltar16;  // long-sentence mode only (else null): ltar / rtar with 16-bit positions, 0xFFFF = none (then the byte tables and lr16 are unused)
+    const uint16_t *rtar16;
 };
 // token / alignment word of corpus position k: from the interleaved array where it exists (one sector serves both), else from the two plain arrays
 CGX_HD int32_t cgx_tok(const cgx_view &v, int64_t k) { return v.tok8 ? v.tok8[k].tok : v.str[k]; }
@@ -53,17 +55,35 @@ CGX_HD uint32_t cgx_rlpw(const cgx_view &v, int64_t k) { return v.tok8 ? v.tok8[
 CGX_HD uint32_t cgx_lr16_off(uint32_t w) { return ((w >> 4) << 5) | (w & 15u); }
 
 // running min/max of aligned target positions over a set of source tokens
+#define CGX_NOPOS 0xFFFF     // "no position yet": above every position (the reference starts its unsigned chars at 255, above every position IT allows)
 struct cgx_span {
-    int lo, hi;              // 255 / 0 when empty, like the reference's unsigned chars
-    CGX_HD void reset() { lo = 255; hi = 0; }
+    int lo, hi;              // CGX_NOPOS / 0 when empty
+    CGX_HD void reset() { lo = CGX_NOPOS; hi = 0; }
     CGX_HD void add(int L, int R) { if (lo > L) lo = L; if (hi < R) hi = R; }
     CGX_HD bool empty() const { return lo > hi; }
 };
 
-CGX_HD int cgx_L(uint32_t w) { return (int)((w >> 24) & 0xFF); }
-CGX_HD int cgx_R(uint32_t w) { return (int)((w >> 16) & 0xFF); }
-CGX_HD int cgx_P(uint32_t w) { return (int)((w >> 8) & 0xFF); }
-CGX_HD bool cgx_unaligned(uint32_t w) { return cgx_L(w) == 255 || cgx_R(w) == 255; }
+// Alignment word of a source token: the reference layout (L<<24)|(R<<16)|(P<<8) -- min / max aligned target position and the
+// token's own position, all inside the sentence, 255 = not aligned -- plus, in the opt-in long-sentence mode only (sentences
+// of 255 tokens and more; the reference rejects them, ExtractPair.cu:2683), three more bits for L and for R and
+// two for P in the low byte the reference leaves zero: bits 7..5, 4..2, 1..0.  L and R are stored as CODES that skip every
+// value whose low byte is 255 (code = p + p / 255, p = low + 255 * high), so "low byte == 255" stays the not-aligned test and a
+// reference-format word (high bits zero) decodes to exactly the values it always had.  cgx_L8 / cgx_R8 / cgx_P8 read the bytes
+// alone: the inner loops of the lookup kernels use them when the index is in the reference format.
+CGX_HD int cgx_L8(uint32_t w) { return (int)((w >> 24) & 0xFF); }
+CGX_HD int cgx_R8(uint32_t w) { return (int)((w >> 16) & 0xFF); }
+CGX_HD int cgx_P8(uint32_t w) { return (int)((w >> 8) & 0xFF); }
+CGX_HD int cgx_L(uint32_t w) { return (int)(((w >> 24) & 0xFF) + 255u * ((w >> 5) & 7u)); }
+CGX_HD int cgx_R(uint32_t w) { return (int)(((w >> 16) & 0xFF) + 255u * ((w >> 2) & 7u)); }
+CGX_HD int cgx_P(uint32_t w) { return (int)(((w >> 8) & 0xFF) | ((w & 3u) << 8)); }
+CGX_HD bool cgx_unaligned(uint32_t w) { return ((w >> 24) & 0xFF) == 255 || ((w >> 16) & 0xFF) == 255; }
+CGX_HD uint32_t cgx_pos_code(uint32_t p) { return p + p / 255u; }                       // position -> code (low byte never 255)
+CGX_HD uint32_t cgx_rlp_pack(int L, int R, uint32_t P) {                                  // L / R < 0: not aligned
+    const uint32_t cl = L < 0 ? 255u : cgx_pos_code((uint32_t)L), cr = R < 0 ? 255u : cgx_pos_code((uint32_t)R);
+    return ((cl & 255u) << 24) | ((cr & 255u) << 16) | ((P & 255u) << 8) | ((cl >> 8) << 5) | ((cr >> 8) << 2) | (P >> 8);
+}
+#define CGX_LONG_MAX_SRC 1024   // P has 10 bits
+#define CGX_LONG_MAX_TGT 2040   // codes up to 2046
 
 // sentence bookkeeping for the token at k: *src0 = index of the first token of its source
 // sentence, returns the offset of its target sentence (GappyLook.cu:70-77)
@@ -76,7 +96,11 @@ CGX_HD int cgx_sentence(const cgx_view &v, int k, uint32_t w, int *src0) {
 // Does the target span [ts,te] project back exactly onto source [s_chk,e_chk]?  Unaligned
 // target words inside the span are ignored (ExtractPair.cu:103-133).
 CGX_HD bool cgx_tight(const cgx_view &v, int ts, int te, int s_chk, int e_chk, int src0) {
-    int lo = 255, hi = 0;
+    int lo = CGX_NOPOS, hi = 0;
+    if (v.ltar16) {                                           // long-sentence mode: 16-bit tables, plain loop
+        for (int k = ts; k <= te; k++) { const int L = v.ltar16[k], R = v.rtar16[k]; if (L == 0xFFFF || R == 0xFFFF) continue; if (lo > L) lo = L; if (hi < R) hi = R; }
+        return src0 + lo == s_chk && src0 + hi == e_chk;
+    }
 #if defined(__HIP_DEVICE_COMPILE__)
     // Every caller has already rejected target spans of 15 words or more, so [ts,te] fits 16 bytes: on the device
     // both byte tables are read with five aligned dword loads each (they are padded) instead of a byte load per
@@ -139,7 +163,7 @@ CGX_HD bool cgx_gap_ok(const cgx_view &v, uint32_t start, uint32_t ender) {
 //   0 not consistent, 1 consistent, 2 first token unaligned, 3 last token unaligned, 4 both.
 // *ts/*te receive the target span computed from the aligned tokens even when the code != 1.
 CGX_HD int cgx_span_code(const cgx_view &v, uint32_t start, uint32_t ender, uint32_t *ts, uint32_t *te) {
-    int lo = 255, hi = 0, src0 = 0, tb = -1, wrong = 0;
+    int lo = CGX_NOPOS, hi = 0, src0 = 0, tb = -1, wrong = 0;
     for (uint32_t k = start; k <= ender; k++) {
         uint32_t w = cgx_rlpw(v, k);
         bool un = cgx_unaligned(w);
@@ -348,8 +372,8 @@ CGX_HD bool cgx_extract_onegap(const cgx_view &v, int32_t id, int32_t D1, int a_
 }
 CGX_HD bool cgx_onegap_tail(const cgx_view &v, int32_t id, int32_t D1, int a_len, int b_len, uint32_t cur, int firstEnd, uint32_t ender,
                             int src0, int tb, uint32_t g0s, uint32_t g0e, uint32_t ts, uint32_t te, int code, cgx_r1 *o_aXb, cgx_r2 *o_XaXb, cgx_r2 *o_aXbX) {
-    // whole-phrase span in sentence coordinates, truncated to a byte like the reference
-    int bodyLo = (int)(uint8_t)(ts - (uint32_t)tb), bodyHi = (int)(uint8_t)(te - (uint32_t)tb);
+    // whole-phrase span in sentence coordinates (the reference keeps it in unsigned chars; an empty span is caught by the guard below either way)
+    int bodyLo = (int)(ts - (uint32_t)tb), bodyHi = (int)(te - (uint32_t)tb);
     bool left = !(code == 3 || code == 4), right = !(code == 2 || code == 4);
     if ((ts == 0 && te == 0) || bodyLo > bodyHi || g0s < ts || g0e > te) return true;
     if (code == 1) cgx_put1(o_aXb, id, ts, te, g0s, g0e);

@@ -7,7 +7,9 @@
  * corpus from FILE and the built index -- suffix array, frequent-pair lists, tables -- from FILE.idx if they exist and
  * still match the text files; otherwise parse / build and write them for the next run), --gz LEVEL (1..9: write
  * grammar.<q>.s.gz through zlib instead of plain files), --sub-batch N (queries per internal batch; default: as many as
- * hold 300 000 query tokens.  Any split writes the same files).
+ * hold 300 000 query tokens.  Any split writes the same files), --long-sentences (accept sentence pairs of 255 tokens and more,
+ * which the reference rejects: source < 1024, target < 2040 tokens; shorter sentences give the same files with or without it;
+ * turns --index-cache off).
  */
 #include "../../include/cgx.h"
 #include <stdio.h>
@@ -22,13 +24,14 @@ static void print_help(void) {
 }
 
 int main(int argc, char **argv) {
-    int minmatchlen = 1, fingerlen = 10, device = 0, shard = 0, nshard = 1, gz = 0, sub_batch = 0; const char *timefile = NULL, *cache = NULL;
+    int minmatchlen = 1, fingerlen = 10, device = 0, shard = 0, nshard = 1, gz = 0, sub_batch = 0, long_sentences = 0; const char *timefile = NULL, *cache = NULL;
     /* pull the long options out first so getopt sees the reference's grammar only */
     char **av = malloc(sizeof(char *) * (size_t)(argc + 1)); int ac = 0;
     for (int i = 0; i < argc; i++) {
         if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--index-cache") && i + 1 < argc) cache = argv[++i];
         else if (!strcmp(argv[i], "--gz") && i + 1 < argc) { gz = atoi(argv[++i]); if (gz < 1 || gz > 9) print_help(); }
+        else if (!strcmp(argv[i], "--long-sentences")) long_sentences = 1;
         else if (!strcmp(argv[i], "--sub-batch") && i + 1 < argc) { sub_batch = atoi(argv[++i]); if (sub_batch < 1) print_help(); }
         else if (!strcmp(argv[i], "--shard") && i + 1 < argc) { if (sscanf(argv[++i], "%d/%d", &shard, &nshard) != 2 || nshard < 1 || shard < 0 || shard >= nshard) print_help(); }
         else av[ac++] = argv[i];
@@ -56,6 +59,7 @@ int main(int argc, char **argv) {
     fclose(qf);
 
     char err[512];
+    if (long_sentences) cache = NULL;                      /* the caches hold the reference's byte positions only */
     cgx_corpus *corpus = cache ? cgx_corpus_load_cache(cache, err, sizeof err) : NULL;
     if (cache && corpus && cgx_corpus_matches_sources(corpus, src, tgt, ali, lex) == 0) {   /* a text file changed since the cache was written: parse again */
         fprintf(stderr, "strmatchcuda: corpus cache %s is older than the text files, rebuilding it\n", cache);
@@ -63,7 +67,7 @@ int main(int argc, char **argv) {
     }
     if (cache && corpus) fprintf(stderr, "strmatchcuda: corpus read from cache %s\n", cache);
     if (!corpus) {
-        corpus = cgx_corpus_load(src, tgt, ali, lex, err, sizeof err);
+        corpus = cgx_corpus_load_opt(src, tgt, ali, lex, long_sentences ? CGX_CORPUS_LONG_SENTENCES : 0, err, sizeof err);
         if (corpus && cache && cgx_corpus_save(corpus, cache) != CGX_OK) fprintf(stderr, "strmatchcuda: could not write the corpus cache %s\n", cache);
     }
     if (!corpus) {

@@ -67,6 +67,11 @@ typedef struct {
     const cgx_lexval *lexv;
     uint32_t nlex;
     const int32_t *sa;       /* optional prebuilt suffix array (NULL: built on the device) */
+    /* Long-sentence mode (opt-in; SURVEY 8(f4): the reference rejects sentences of 255 tokens and more, ExtractPair.cu:2683).
+     * Both NULL = the reference's byte positions.  Both set: per target token min/max aligned source position as 16-bit values
+     * (0xFFFF = unaligned; ltar / rtar are then ignored), and every rlp word carries three more bits for L, three for R and two
+     * for P in its low byte, L and R as position codes -- cgx_rlp_pack() of csrc/cgx_rules.h; cgx_corpus_load_opt builds them. */
+    const uint16_t *ltar16, *rtar16;
 } cgx_index_host;
 
 /* ---- lifetime ---- */
@@ -150,6 +155,8 @@ double cgx_stage_ms(cgx_ctx *ctx, const char *name);
 /* ---- whole-path host driver (what the CLI calls): text files in, grammar files out ---- */
 typedef struct cgx_corpus cgx_corpus;
 cgx_corpus *cgx_corpus_load(const char *src, const char *tgt, const char *align, const char *lex, char *err, size_t errcap);
+#define CGX_CORPUS_LONG_SENTENCES 1   /* accept sentence pairs of 255 tokens and more (source < 1024, target < 2040 tokens): positions wider than the reference's bytes; results for shorter sentences are unchanged */
+cgx_corpus *cgx_corpus_load_opt(const char *src, const char *tgt, const char *align, const char *lex, int flags, char *err, size_t errcap);   /* cgx_corpus_load with options (strmatchcuda --long-sentences); such a corpus is not written to the corpus / index caches */
 void cgx_corpus_free(cgx_corpus *c);
 uint64_t cgx_corpus_checksum(const cgx_corpus *c);               /* FNV-1a over every array and spelling of the loaded corpus */
 int cgx_corpus_save(const cgx_corpus *c, const char *path);      /* the parsed corpus as one binary file (the reference's own index cache is commented out, SuffixArray.c:208-230) */

@@ -131,27 +131,54 @@ void orc_build_sa(const int32_t *str, uint32_t n, int32_t *sa) {
 }
 
 /* ------------------------------------------------------------------ */
+/* positions.  The reference keeps in-sentence positions in unsigned chars (255 = "not aligned"; ExtractPair.cu:2683 rejects
+ * longer sentences).  This restatement computes with ints and NONE instead, which is the same arithmetic for positions < 255
+ * (an unsigned char is promoted to int in every expression of the reference), and reads an alignment word through the
+ * decoders below: the reference layout (L<<24)|(R<<16)|(P<<8) plus, ONLY in the opt-in long-sentence mode
+ * (orc_set_long_sentences, `--long-sentences`; f4 of SURVEY 8), three more bits for L and R and two for P in the low byte
+ * the reference leaves zero: bits 7..5 / 4..2 / 1..0.  L and R are stored as codes that skip every value whose low byte
+ * is 255 (code = p + p / 255), so "low byte == 255" stays the unaligned test and a reference-format word decodes to the same
+ * values as before.  Target-side positions (ltar / rtar) are 16-bit in that mode (0xFFFF = not aligned). */
+#define NONE 0xFFFF
+static int g_long_sentences = 0;
+void orc_set_long_sentences(int on) { g_long_sentences = on != 0; }
+static inline int pos_decode(unsigned lo, unsigned hi) { return lo == 255u ? NONE : (int)(lo + hi * 255u); }
+#define RL(w) pos_decode(((w) >> 24) & 0xFFu, ((w) >> 5) & 7u)
+#define RR(w) pos_decode(((w) >> 16) & 0xFFu, ((w) >> 2) & 7u)
+#define RP(w) ((int)((((w) >> 8) & 0xFFu) | (((w) & 3u) << 8)))
+#define LT(ix, k) ((ix)->ltar16 ? (int)(ix)->ltar16[k] : ((ix)->ltar[k] == 255 ? NONE : (int)(ix)->ltar[k]))
+#define RT(ix, k) ((ix)->rtar16 ? (int)(ix)->rtar16[k] : ((ix)->rtar[k] == 255 ? NONE : (int)(ix)->rtar[k]))
+static inline uint32_t pos_encode(int p) { unsigned c = p == NONE ? 255u : (unsigned)p + (unsigned)p / 255u; return c; }   /* code: low byte + 3 high bits */
+#define ORC_LONG_MAX_SRC 1024      /* P has 10 bits */
+#define ORC_LONG_MAX_TGT 2040      /* codes up to 2046 */
+
+/* ------------------------------------------------------------------ */
 /* alignment: initAlignment, ExtractPair.cu:2639-2739                   */
 /* ------------------------------------------------------------------ */
-static void pack_rlp(orc_index *ix, const uint8_t *Ls, const uint8_t *Rs) {
+static void pack_rlp(orc_index *ix, const int *Ls, const int *Rs, int long_mode) {
     ix->rlp = xcalloc(ix->n, sizeof(uint32_t));
     int q = 1;
     for (uint32_t i = 0; i + 1 < ix->n; i++) {       /* the last entry stays unset in the reference */
         if (q <= ix->nsent && (int32_t)i == ix->sentind[q] - 1) {
             ix->rlp[i] = (uint32_t)ix->tsentind[q];  /* delimiter slot: target offset of the NEXT sentence (:2722-2724) */
             q++;
-        } else {
-            ix->rlp[i] = ((uint32_t)Ls[i] << 24) | ((uint32_t)Rs[i] << 16) | ((uint32_t)ix->P[i] << 8);
+        } else if (!long_mode) {
+            ix->rlp[i] = ((uint32_t)(Ls[i] == NONE ? 255 : Ls[i]) << 24) | ((uint32_t)(Rs[i] == NONE ? 255 : Rs[i]) << 16) | ((uint32_t)ix->P[i] << 8);
+        } else {                                      /* long-sentence mode: position codes, true in-sentence position (q - 1 = sentence of token i) */
+            const uint32_t cl = pos_encode(Ls[i]), cr = pos_encode(Rs[i]), pp = (uint32_t)((int32_t)i - ix->sentind[q - 1]);
+            if (pp >= ORC_LONG_MAX_SRC) { printf("Not possible, too long sentence\n"); exit(1); }
+            ix->rlp[i] = ((cl & 255u) << 24) | ((cr & 255u) << 16) | ((pp & 255u) << 8) | ((cl >> 8) << 5) | ((cr >> 8) << 2) | (pp >> 8);
         }
     }
 }
 static void load_alignment(orc_index *ix, const char *path) {
     FILE *f = fopen(path, "r");
     if (!f) DIE("cannot open %s", path);
-    uint8_t *Ls = xmalloc(ix->n), *Rs = xmalloc(ix->n);
-    memset(Ls, 255, ix->n); memset(Rs, 255, ix->n);
-    ix->ltar = xmalloc(ix->nt); ix->rtar = xmalloc(ix->nt);
-    memset(ix->ltar, 255, ix->nt); memset(ix->rtar, 255, ix->nt);
+    int *Ls = xmalloc((size_t)ix->n * sizeof *Ls), *Rs = xmalloc((size_t)ix->n * sizeof *Rs);
+    for (uint32_t i = 0; i < ix->n; i++) Ls[i] = Rs[i] = NONE;
+    int *lt = xmalloc((size_t)ix->nt * sizeof *lt), *rt = xmalloc((size_t)ix->nt * sizeof *rt);
+    for (uint32_t i = 0; i < ix->nt; i++) lt[i] = rt[i] = NONE;
+    const int max_s = g_long_sentences ? ORC_LONG_MAX_SRC : 255, max_t = g_long_sentences ? ORC_LONG_MAX_TGT : 255;
     char *line = NULL; size_t cap = 0; int q = -1;
     while (getline(&line, &cap, f) != -1) {
         q++;
@@ -164,19 +191,27 @@ static void load_alignment(orc_index *ix, const char *path) {
             tok = strtok_r(NULL, " -", &save);
             if (!tok) { printf("Not possible!\n"); exit(0); }
             int t = atoi(tok);
-            if (s >= 255 || t >= 255 || s < 0 || t < 0) { printf("Not possible, too long sentence\n"); exit(1); } /* :2683 */
+            if (s >= max_s || t >= max_t || s < 0 || t < 0) { printf("Not possible, too long sentence\n"); exit(1); } /* :2683 */
             uint32_t si = (uint32_t)(ix->sentind[q] + s), ti = (uint32_t)(ix->tsentind[q] + t);
             if (si >= ix->n || ti >= ix->nt) DIE("alignment index outside corpus");
-            if (Ls[si] == 255 || Rs[si] == 255) Ls[si] = Rs[si] = (uint8_t)t;
-            else if (t > Rs[si]) Rs[si] = (uint8_t)t;
-            else if (t < Ls[si]) Ls[si] = (uint8_t)t;
-            if (ix->ltar[ti] == 255 || ix->rtar[ti] == 255) ix->ltar[ti] = ix->rtar[ti] = (uint8_t)s;
-            else if (s > ix->rtar[ti]) ix->rtar[ti] = (uint8_t)s;
-            else if (s < ix->ltar[ti]) ix->ltar[ti] = (uint8_t)s;
+            if (Ls[si] == NONE || Rs[si] == NONE) Ls[si] = Rs[si] = t;
+            else if (t > Rs[si]) Rs[si] = t;
+            else if (t < Ls[si]) Ls[si] = t;
+            if (lt[ti] == NONE || rt[ti] == NONE) lt[ti] = rt[ti] = s;
+            else if (s > rt[ti]) rt[ti] = s;
+            else if (s < lt[ti]) lt[ti] = s;
         }
     }
     free(line); fclose(f);
-    pack_rlp(ix, Ls, Rs);
+    /* target-side tables: bytes as in the reference, 16-bit words in long-sentence mode */
+    ix->ltar = xmalloc(ix->nt ? ix->nt : 1); ix->rtar = xmalloc(ix->nt ? ix->nt : 1); ix->ltar16 = ix->rtar16 = NULL;
+    for (uint32_t i = 0; i < ix->nt; i++) { ix->ltar[i] = (uint8_t)(lt[i] == NONE || lt[i] > 254 ? 255 : lt[i]); ix->rtar[i] = (uint8_t)(rt[i] == NONE || rt[i] > 254 ? 255 : rt[i]); }
+    if (g_long_sentences) {
+        ix->ltar16 = xmalloc((size_t)(ix->nt ? ix->nt : 1) * 2); ix->rtar16 = xmalloc((size_t)(ix->nt ? ix->nt : 1) * 2);
+        for (uint32_t i = 0; i < ix->nt; i++) { ix->ltar16[i] = (uint16_t)lt[i]; ix->rtar16[i] = (uint16_t)rt[i]; }
+    }
+    free(lt); free(rt);
+    pack_rlp(ix, Ls, Rs, g_long_sentences);
     free(Ls); free(Rs);
 }
 
@@ -234,13 +269,13 @@ float orc_lex_lookup(const orc_index *ix, int32_t src, int32_t tgt, int which) {
 /* gap validity: checkBoundaryGap, GappyLook.cu:43-126                  */
 /* ------------------------------------------------------------------ */
 int orc_check_gap(const orc_index *ix, uint32_t start, uint32_t ender) {
-    unsigned char L, R, min_L = 255, max_R = 0; int stb = -1, tempind = 0;
+    int L, R, min_L = NONE, max_R = 0; int stb = -1, tempind = 0;
     for (uint32_t k = start; k <= ender; k++) {
-        uint32_t w = ix->rlp[k]; L = (w >> 24) & 0xFF; R = (w >> 16) & 0xFF;
-        if ((L == 255 || R == 255) && (k == start || k == ender)) return 0;
-        else if (L == 255 || R == 255) { /* unaligned inside the gap: ignored */ }
+        uint32_t w = ix->rlp[k]; L = RL(w); R = RR(w);
+        if ((L == NONE || R == NONE) && (k == start || k == ender)) return 0;
+        else if (L == NONE || R == NONE) { /* unaligned inside the gap: ignored */ }
         else if (k == start) {
-            tempind = (int)k - (int)((w >> 8) & 0xFF) - 1;
+            tempind = (int)k - (int)RP(w) - 1;
             stb = tempind == -1 ? 0 : (int)ix->rlp[tempind];
             min_L = L; max_R = R;
         } else { if (min_L > L) min_L = L; if (max_R < R) max_R = R; }
@@ -248,10 +283,10 @@ int orc_check_gap(const orc_index *ix, uint32_t start, uint32_t ender) {
     if (min_L <= max_R && max_R - min_L < ORC_MAX_SPAN) {
         tempind++;
         int ts = min_L + stb, te = max_R + stb;
-        min_L = 255; max_R = 0;
+        min_L = NONE; max_R = 0;
         for (int k = ts; k <= te; k++) {
-            L = ix->ltar[k]; R = ix->rtar[k];
-            if (L == 255 || R == 255) { }
+            L = LT(ix, k); R = RT(ix, k);
+            if (L == NONE || R == NONE) { }
             else if (k == ts) { min_L = L; max_R = R; }
             else { if (min_L > L) min_L = L; if (max_R < R) max_R = R; }
         }
@@ -390,7 +425,9 @@ orc_index *orc_index_from_arrays(const int32_t *str, uint32_t n, const int32_t *
     ix->P = xcalloc(n, 1);
     for (int32_t q = 0; q < nsent; q++) for (int32_t i = sentind[q]; i < sentind[q + 1] - 1; i++) ix->P[i] = (uint8_t)(i - sentind[q]);
     ix->ltar = xmalloc(nt); memcpy(ix->ltar, ltar, nt); ix->rtar = xmalloc(nt); memcpy(ix->rtar, rtar, nt);
-    pack_rlp(ix, lsrc, rsrc);
+    { int *Ls = xmalloc((size_t)n * sizeof *Ls), *Rs = xmalloc((size_t)n * sizeof *Rs);      /* byte tables in, byte layout out */
+      for (uint32_t i = 0; i < n; i++) { Ls[i] = lsrc[i] == 255 ? NONE : lsrc[i]; Rs[i] = rsrc[i] == 255 ? NONE : rsrc[i]; }
+      pack_rlp(ix, Ls, Rs, 0); free(Ls); free(Rs); }
     lexrow *rows = xmalloc((size_t)nlex * sizeof *rows);
     for (uint32_t i = 0; i < nlex; i++) { rows[i].k = lexk[i]; rows[i].v = lexv[i]; rows[i].ord = i; }
     sort_lex(ix, rows, nlex); free(rows);
@@ -414,7 +451,7 @@ void orc_index_free(orc_index *ix) {
     for (int32_t i = 0; ix->tvocab && i < (ix->thash ? ix->ntvocab : ix->ntvocab + 1); i++) free(ix->tvocab[i]);
     free(ix->svocab); free(ix->tvocab); strmap_free(ix->shash); strmap_free(ix->thash);
     free(ix->str); free(ix->P); free(ix->sentind); free(ix->sa); free(ix->rlp); free(ix->tstr); free(ix->tsentind);
-    free(ix->ltar); free(ix->rtar); free(ix->lexk); free(ix->lexv); free(ix->phits); free(ix);
+    free(ix->ltar); free(ix->rtar); free(ix->ltar16); free(ix->rtar16); free(ix->lexk); free(ix->lexv); free(ix->phits); free(ix);
 }
 
 /* ------------------------------------------------------------------ */
@@ -821,23 +858,23 @@ static void generate_blocks(const orc_index *ix, orc_batch *b) {
 /* ------------------------------------------------------------------ */
 /* consistent(), ExtractPair.cu:103-133 */
 static int tight(const orc_index *ix, int start, int end, int start_chk, int end_chk, int src0) {
-    unsigned char L, R, mn = 255, mx = 0;
+    int L, R, mn = NONE, mx = 0;
     for (int k = start; k <= end; k++) {
-        L = ix->ltar[k]; R = ix->rtar[k];
-        if (L == 255 || R == 255) { }
+        L = LT(ix, k); R = RT(ix, k);
+        if (L == NONE || R == NONE) { }
         else if (k == start) { mn = L; mx = R; }
         else { if (mn > L) mn = L; if (mx < R) mx = R; }
     }
     return !(src0 + mn != start_chk || src0 + mx != end_chk);
 }
 /* checkBoundaryFast, ExtractPair.cu:135-194 */
-static int span_fast(const orc_index *ix, uint32_t start, uint32_t ender, unsigned char *mnL, unsigned char *mxR, int *stb, int *tempind) {
-    unsigned char L, R, mn = 255, mx = 0; *stb = -1; *tempind = 0;
+static int span_fast(const orc_index *ix, uint32_t start, uint32_t ender, int *mnL, int *mxR, int *stb, int *tempind) {
+    int L, R, mn = NONE, mx = 0; *stb = -1; *tempind = 0;
     for (uint32_t k = start; k <= ender; k++) {
-        uint32_t w = ix->rlp[k]; L = (w >> 24) & 0xFF; R = (w >> 16) & 0xFF;
-        if ((L == 255 || R == 255) && (k == start || k == ender)) return 0;
-        else if (L == 255 || R == 255) { }
-        else if (k == start) { *tempind = (int)k - (int)((w >> 8) & 0xFF) - 1; *stb = *tempind == -1 ? 0 : (int)ix->rlp[*tempind]; mn = L; mx = R; }
+        uint32_t w = ix->rlp[k]; L = RL(w); R = RR(w);
+        if ((L == NONE || R == NONE) && (k == start || k == ender)) return 0;
+        else if (L == NONE || R == NONE) { }
+        else if (k == start) { *tempind = (int)k - (int)RP(w) - 1; *stb = *tempind == -1 ? 0 : (int)ix->rlp[*tempind]; mn = L; mx = R; }
         else { if (mn > L) mn = L; if (mx < R) mx = R; }
     }
     if (mn <= mx && mx - mn < ORC_MAX_SPAN) { (*tempind)++; *mnL = mn; *mxR = mx; return 1; }
@@ -845,12 +882,12 @@ static int span_fast(const orc_index *ix, uint32_t start, uint32_t ender, unsign
 }
 /* checkBoundaryFast2, ExtractPair.cu:196-250 */
 static int span_fast2(const orc_index *ix, uint32_t start, uint32_t ender, uint32_t *ts, uint32_t *te) {
-    unsigned char L, R, mn = 255, mx = 0; int stb = -1, tempind = 0;
+    int L, R, mn = NONE, mx = 0; int stb = -1, tempind = 0;
     for (uint32_t k = start; k <= ender; k++) {
-        uint32_t w = ix->rlp[k]; L = (w >> 24) & 0xFF; R = (w >> 16) & 0xFF;
-        if ((L == 255 || R == 255) && (k == start || k == ender)) return 0;
-        else if (L == 255 || R == 255) { }
-        else if (k == start) { tempind = (int)k - (int)((w >> 8) & 0xFF) - 1; stb = tempind == -1 ? 0 : (int)ix->rlp[tempind]; mn = L; mx = R; }
+        uint32_t w = ix->rlp[k]; L = RL(w); R = RR(w);
+        if ((L == NONE || R == NONE) && (k == start || k == ender)) return 0;
+        else if (L == NONE || R == NONE) { }
+        else if (k == start) { tempind = (int)k - (int)RP(w) - 1; stb = tempind == -1 ? 0 : (int)ix->rlp[tempind]; mn = L; mx = R; }
         else { if (mn > L) mn = L; if (mx < R) mx = R; }
     }
     *ts = (uint32_t)(mn + stb); *te = (uint32_t)(mx + stb);
@@ -858,17 +895,17 @@ static int span_fast2(const orc_index *ix, uint32_t start, uint32_t ender, uint3
 }
 /* checkBoundary, ExtractPair.cu:252-342: 0 plain false, 1 ok, 2 front unaligned, 3 end unaligned, 4 both */
 static int span_code(const orc_index *ix, uint32_t start, uint32_t ender, uint32_t *ts, uint32_t *te) {
-    unsigned char L, R, mn = 255, mx = 0; int stb = -1, tempind = 0, wrong = 0;
+    int L, R, mn = NONE, mx = 0; int stb = -1, tempind = 0, wrong = 0;
     for (uint32_t k = start; k <= ender; k++) {
-        uint32_t w = ix->rlp[k]; L = (w >> 24) & 0xFF; R = (w >> 16) & 0xFF;
-        if ((L == 255 || R == 255) && (k == start || k == ender)) {
+        uint32_t w = ix->rlp[k]; L = RL(w); R = RR(w);
+        if ((L == NONE || R == NONE) && (k == start || k == ender)) {
             if (start == ender && wrong == 0) wrong = 4;
             else if (wrong == 0 && k == start) wrong = 2;
             else if (wrong == 0 && k == ender) wrong = 3;
             else wrong = 4;
-            if (k == start) { tempind = (int)k - (int)((w >> 8) & 0xFF) - 1; stb = tempind == -1 ? 0 : (int)ix->rlp[tempind]; }
-        } else if (L == 255 || R == 255) { }
-        else if (k == start) { tempind = (int)k - (int)((w >> 8) & 0xFF) - 1; stb = tempind == -1 ? 0 : (int)ix->rlp[tempind]; mn = L; mx = R; }
+            if (k == start) { tempind = (int)k - (int)RP(w) - 1; stb = tempind == -1 ? 0 : (int)ix->rlp[tempind]; }
+        } else if (L == NONE || R == NONE) { }
+        else if (k == start) { tempind = (int)k - (int)RP(w) - 1; stb = tempind == -1 ? 0 : (int)ix->rlp[tempind]; mn = L; mx = R; }
         else { if (mn > L) mn = L; if (mx < R) mx = R; }
     }
     *ts = (uint32_t)(mn + stb); *te = (uint32_t)(mx + stb);
@@ -910,15 +947,15 @@ typedef struct { VEC(orc_rule0) r0; VEC(orc_rule1) r1; VEC(orc_rule2) r2; } rule
 static int gappy_occurrence(const orc_index *ix, uint32_t bnum, uint32_t G, int lm, int current, rulebuf *out) {
     const int32_t *str = ix->str; const uint32_t *RLP = ix->rlp;
     int current_str = ix->sa[current], tempind = 0, stb = -1, ender;
-    unsigned char L, R, min_L = 255, max_R = 0; uint32_t w;
+    int L, R, min_L = NONE, max_R = 0; uint32_t w;
     int abX = 1, Xab = 1, XabX = 1, ab = 1, XabNo = 1, abXNo = 1, next;
     uint8_t XabCount = 0, abXCount = 0;
     uint32_t g1s = 0, g1e = 0, g2s = 0, g2e = 0, ts = 0, te = 0, tmp;
     for (int k = current_str; k < current_str + lm; k++) {           /* :1178-1212 */
-        w = RLP[k]; L = (w >> 24) & 0xFF; R = (w >> 16) & 0xFF;
-        if (k == current_str) { tempind = k - (int)((w >> 8) & 0xFF) - 1; stb = tempind == -1 ? 0 : (int)RLP[tempind]; }
-        if ((L == 255 || R == 255) && (k == current_str || k == current_str + lm - 1)) { ab = 0; if (k == current_str) abXNo = 0; else XabNo = 0; }
-        else if (L == 255 || R == 255) { }
+        w = RLP[k]; L = RL(w); R = RR(w);
+        if (k == current_str) { tempind = k - (int)RP(w) - 1; stb = tempind == -1 ? 0 : (int)RLP[tempind]; }
+        if ((L == NONE || R == NONE) && (k == current_str || k == current_str + lm - 1)) { ab = 0; if (k == current_str) abXNo = 0; else XabNo = 0; }
+        else if (L == NONE || R == NONE) { }
         else { if (min_L > L) min_L = L; if (max_R < R) max_R = R; }
     }
     if (min_L > max_R || max_R - min_L >= ORC_MAX_SPAN) { abX = Xab = XabX = ab = 0; }
@@ -928,12 +965,12 @@ static int gappy_occurrence(const orc_index *ix, uint32_t bnum, uint32_t G, int 
     }
     if (lm + 1 > ORC_MAX_SYMBOLS) { abX = 0; Xab = 0; }
     if (lm + 2 > ORC_MAX_SYMBOLS) XabX = 0;
-    unsigned char i = 1, mnXab = 255, mxXab = 0, mnabX = 255, mxabX = 0, mnXX = 255, mxXX = 0;
+    int i = 1, mnXab = NONE, mxXab = 0, mnabX = NONE, mxabX = 0, mnXX = NONE, mxXX = 0;
     while (lm + i <= ORC_MAX_SPAN && (abXNo || XabNo || XabX)) {        /* :1280 */
         if (Xab && current_str - i >= 0 && str[current_str - i] >= 2) {  /* grow a gap to the left */
             next = 1;
-            w = RLP[current_str - i]; L = (w >> 24) & 0xFF; R = (w >> 16) & 0xFF;
-            if (L == 255 || R == 255) { next = 0; if (i == 1) { Xab = 0; XabX = 0; } }
+            w = RLP[current_str - i]; L = RL(w); R = RR(w);
+            if (L == NONE || R == NONE) { next = 0; if (i == 1) { Xab = 0; XabX = 0; } }
             else { if (mnXab > L) mnXab = L; if (mxXab < R) mxXab = R; }
             if (next && mnXab > mxXab) return 1;
             if (mxXab - mnXab >= ORC_MAX_SPAN) { next = 0; Xab = 0; }
@@ -958,8 +995,8 @@ static int gappy_occurrence(const orc_index *ix, uint32_t bnum, uint32_t G, int 
 
         if (abX && str[ender + i] >= 2) {                               /* grow a gap to the right, :1403 */
             next = 1;
-            w = RLP[ender + i]; L = (w >> 24) & 0xFF; R = (w >> 16) & 0xFF;
-            if (L == 255 || R == 255) { next = 0; if (i == 1) { abX = 0; XabX = 0; } }
+            w = RLP[ender + i]; L = RL(w); R = RR(w);
+            if (L == NONE || R == NONE) { next = 0; if (i == 1) { abX = 0; XabX = 0; } }
             else { if (mnabX > L) mnabX = L; if (mxabX < R) mxabX = R; }
             if (next && mnabX > mxabX) return 1;
             if (mxabX - mnabX >= ORC_MAX_SPAN) { next = 0; abX = 0; }
@@ -984,12 +1021,12 @@ static int gappy_occurrence(const orc_index *ix, uint32_t bnum, uint32_t G, int 
 
         if (XabX && (abX || Xab)) {                                     /* :1514 */
             if (XabCount == i) {                                         /* left gap just became valid: try right gaps 1..abXCount */
-                mnXX = 255; mxXX = 0;
+                mnXX = NONE; mxXX = 0;
                 for (uint8_t ic = 1; XabX && ic <= abXCount; ic++) {
                     next = 1;
                     if (ic + XabCount + lm <= ORC_MAX_SPAN) {
-                        w = RLP[ender + ic]; L = (w >> 24) & 0xFF; R = (w >> 16) & 0xFF;
-                        if (L == 255 || R == 255) { next = 0; if (i == 1) return 1; }
+                        w = RLP[ender + ic]; L = RL(w); R = RR(w);
+                        if (L == NONE || R == NONE) { next = 0; if (i == 1) return 1; }
                         else { if (mnXX > L) mnXX = L; if (mxXX < R) mxXX = R; }
                     } else { next = 0; ic = abXCount + 1; }
                     if (next && mxXX - mnXX >= ORC_MAX_SPAN) { next = 0; ic = abXCount + 1; }
@@ -999,8 +1036,8 @@ static int gappy_occurrence(const orc_index *ix, uint32_t bnum, uint32_t G, int 
                         next = tight(ix, (int)g2s, (int)g2e, ender + 1, ender + ic, tempind);
                     }
                     if (next) {
-                        tmp = mnXX < mnXab ? mnXX : mnXab; if (tmp > min_L) tmp = min_L; ts = (uint32_t)stb + tmp;
-                        tmp = mxXX < mxXab ? mxXab : mxXX; if (tmp < max_R) tmp = max_R; te = (uint32_t)stb + tmp;
+                        tmp = mnXX < mnXab ? mnXX : mnXab; if ((int)tmp > min_L) tmp = (uint32_t)min_L; ts = (uint32_t)stb + tmp;
+                        tmp = mxXX < mxXab ? mxXab : mxXX; if ((int)tmp < max_R) tmp = (uint32_t)max_R; te = (uint32_t)stb + tmp;
                         if (ts > te) return 1;
                         if (te - ts >= ORC_MAX_SPAN) { next = 0; ic = abXCount + 1; }
                         if (next) next = tight(ix, (int)ts, (int)te, current_str - XabCount, ender + ic, tempind);
@@ -1014,12 +1051,12 @@ static int gappy_occurrence(const orc_index *ix, uint32_t bnum, uint32_t G, int 
                 }
             }
             if (XabX && abXCount == i) {                                 /* right gap just became valid: try left gaps 1..XabCount */
-                mnXX = 255; mxXX = 0;
+                mnXX = NONE; mxXX = 0;
                 for (uint8_t ic = 1; XabX && ic <= XabCount; ic++) {
                     next = 1;
                     if (ic + abXCount + lm <= ORC_MAX_SPAN) {
-                        w = RLP[current_str - ic]; L = (w >> 24) & 0xFF; R = (w >> 16) & 0xFF;
-                        if (L == 255 || R == 255) { next = 0; if (i == 1) return 1; }
+                        w = RLP[current_str - ic]; L = RL(w); R = RR(w);
+                        if (L == NONE || R == NONE) { next = 0; if (i == 1) return 1; }
                         else { if (mnXX > L) mnXX = L; if (mxXX < R) mxXX = R; }
                     } else { ic = XabCount + 1; next = 0; }
                     if (next && mxXX - mnXX >= ORC_MAX_SPAN) { ic = XabCount + 1; next = 0; }
@@ -1029,8 +1066,8 @@ static int gappy_occurrence(const orc_index *ix, uint32_t bnum, uint32_t G, int 
                         next = tight(ix, (int)g1s, (int)g1e, current_str - ic, current_str - 1, tempind);
                     }
                     if (next) {
-                        tmp = mnXX < mnabX ? mnXX : mnabX; if (tmp > min_L) tmp = min_L; ts = (uint32_t)stb + tmp;
-                        tmp = mxXX < mxabX ? mxabX : mxXX; if (tmp < max_R) tmp = max_R; te = (uint32_t)stb + tmp;
+                        tmp = mnXX < mnabX ? mnXX : mnabX; if ((int)tmp > min_L) tmp = (uint32_t)min_L; ts = (uint32_t)stb + tmp;
+                        tmp = mxXX < mxabX ? mxabX : mxXX; if ((int)tmp < max_R) tmp = (uint32_t)max_R; te = (uint32_t)stb + tmp;
                         if (ts > te) return 1;
                         if (te - ts >= ORC_MAX_SPAN) { next = 0; ic = XabCount + 1; }
                         if (next) next = tight(ix, (int)ts, (int)te, current_str - ic, ender + abXCount, tempind);
@@ -1073,7 +1110,7 @@ static int twogap_occurrence(const orc_index *ix, const orc_batch *b, uint32_t i
 /* ------------------------------------------------------------------ */
 static int onegap_occurrence(const orc_index *ix, uint32_t id, uint32_t D1, int al, int bl, uint32_t cur, unsigned char firstEnd, rulebuf *out) {
     const int32_t *str = ix->str; const uint32_t *RLP = ix->rlp;
-    unsigned char min_L = 255, max_R = 0, L, R; int stb = -1, tempind = -1, next = 1, left = 1, right = 1;
+    int min_L = NONE, max_R = 0, L, R; int stb = -1, tempind = -1, next = 1, left = 1, right = 1;
     uint32_t g1s, g1e, ts = 0, te = 0, g2s, g2e, w;
     if (cur + firstEnd - bl > ix->n) return 1;
     uint32_t ender = cur + firstEnd;
@@ -1082,7 +1119,7 @@ static int onegap_occurrence(const orc_index *ix, uint32_t id, uint32_t D1, int 
     if (tempind == -1 || stb == -1 || min_L > max_R) return 1;
     g1s = (uint32_t)(min_L + stb); g1e = (uint32_t)(max_R + stb);
     int code = span_code(ix, cur, ender, &ts, &te);
-    min_L = (unsigned char)(ts - (uint32_t)stb); max_R = (unsigned char)(te - (uint32_t)stb);
+    min_L = (int)(ts - (uint32_t)stb); max_R = (int)(te - (uint32_t)stb);
     if (code == 0) next = 0; else if (code == 1) next = 1;
     else if (code == 2) { next = 0; right = 0; } else if (code == 3) { next = 0; left = 0; } else { next = 0; left = 0; right = 0; }
     if ((ts == 0 && te == 0) || min_L > max_R || g1s < ts || g1e > te) return 1;       /* :591-595 */
@@ -1090,14 +1127,14 @@ static int onegap_occurrence(const orc_index *ix, uint32_t id, uint32_t D1, int 
         orc_rule1 r; r.tstart = ts; r.end = (uint8_t)(te - ts); r.gap1 = (uint8_t)(g1s - ts); r.gap1_1 = (uint8_t)(g1e - ts); r.id = (int32_t)id;
         VPUSH(out->r1, r);
     }
-    unsigned char mnL = 255, mxL = 0, mnR = 255, mxR = 0;
+    int mnL = NONE, mxL = 0, mnR = NONE, mxR = 0;
     if (al + bl + 1 + 1 <= ORC_MAX_SYMBOLS) {
         uint32_t og1s = g1s, og1e = g1e; uint8_t i = 1;
         while (firstEnd + 1 + i <= ORC_MAX_SPAN && (left || right)) {
             if (left && (int)(cur - i) >= 0 && str[cur - i] >= 2) {       /* XaXb, :639-757 */
                 next = 1; g1s = g1e = 0;
-                w = RLP[cur - i]; L = (w >> 24) & 0xFF; R = (w >> 16) & 0xFF;
-                if (L == 255 || R == 255) { next = 0; if (i == 1) left = 0; }
+                w = RLP[cur - i]; L = RL(w); R = RR(w);
+                if (L == NONE || R == NONE) { next = 0; if (i == 1) left = 0; }
                 else { if (mnL > L) mnL = L; if (mxL < R) mxL = R; }
                 if (next && mnL > mxL) return 1;
                 if (mxL - mnL >= ORC_MAX_SPAN) { next = 0; left = 0; }
@@ -1115,8 +1152,8 @@ static int onegap_occurrence(const orc_index *ix, uint32_t id, uint32_t D1, int 
             } else left = 0;
             if (right && str[ender + i] >= 2) {                            /* aXbX, :763-877 */
                 next = 1; g2s = g2e = 0;
-                w = RLP[ender + i]; L = (w >> 24) & 0xFF; R = (w >> 16) & 0xFF;
-                if (L == 255 || R == 255) { next = 0; if (i == 1) right = 0; }
+                w = RLP[ender + i]; L = RL(w); R = RR(w);
+                if (L == NONE || R == NONE) { next = 0; if (i == 1) right = 0; }
                 else { if (mnR > L) mnR = L; if (mxR < R) mxR = R; }
                 if (next && mnR > mxR) return 1;
                 if (mxR - mnR >= ORC_MAX_SPAN) { next = 0; right = 0; }

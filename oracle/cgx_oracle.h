@@ -94,6 +94,7 @@ typedef struct {
     int32_t ntvocab;
     char **tvocab;
     uint8_t *ltar, *rtar;
+    uint16_t *ltar16, *rtar16;   /* long-sentence mode only (orc_set_long_sentences): the same tables with 16-bit positions, 0xFFFF = not aligned */
     /* lexical table, sorted by (src,tgt) */
     uint32_t nlex;
     orc_lexkey *lexk;
@@ -155,6 +156,7 @@ orc_index *orc_index_from_arrays(const int32_t *str, uint32_t n, const int32_t *
                                  const orc_lexkey *lexk, const orc_lexval *lexv, uint32_t nlex,
                                  const int32_t *sa);
 void orc_index_free(orc_index *ix);
+void orc_set_long_sentences(int on);   /* before orc_index_load: accept sentences of 255+ tokens (source < 1024, target < 2040); default off = the reference's byte positions */
 void orc_build_sa(const int32_t *str, uint32_t n, int32_t *sa);
 int orc_precompute(orc_index *ix);
 

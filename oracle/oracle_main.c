@@ -1,7 +1,8 @@
 /*
  * oracle_main.c -- TEST INFRASTRUCTURE ONLY.
  * Command line of the CPU oracle; same six positionals as the reference's
- * bin/strmatchcuda (Main.c:35-61) plus optional "--dump <file>" for the intermediate dump.
+ * bin/strmatchcuda (Main.c:35-61) plus optional "--dump <file>" for the intermediate dump and
+ * "--long-sentences" (sentences of 255 tokens and more: positions of up to 1023 / 2039 instead of the reference's bytes).
  */
 #include "cgx_oracle.h"
 #include <stdio.h>
@@ -12,6 +13,7 @@ int main(int argc, char **argv) {
     const char *dump = NULL; const char *pos[6]; int np = 0;
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--dump") && i + 1 < argc) dump = argv[++i];
+        else if (!strcmp(argv[i], "--long-sentences")) orc_set_long_sentences(1);   /* opt-in: wider positions (sentences of 255+ tokens) */
         else if (np < 6) pos[np++] = argv[i];
         else np++;
     }

@@ -174,6 +174,27 @@ def test_cli_query_shards_run_in_several_internal_batches(cgx, fixtures_dir, tmp
     assert op.sha_dir(str(out), nq) == META["mid"]["grammar"]
 
 
+def test_long_sentences_option(cgx, oracle_bin, fixtures_dir, tmp_path):
+    """strmatchcuda --long-sentences (f4; the reference rejects sentences of 255 tokens and more): a corpus of 240..330-token
+    sentence pairs gives the files of the oracle run with the same switch; without the switch it is refused with the
+    reference's message and exit code; and the switch changes nothing for a corpus the reference accepts."""
+    from test_oracle import make_long_fixture, LONG_SPEC
+    exe = os.path.join(ROOT, "bin", "strmatchcuda"); lf = make_long_fixture(fixtures_dir); nq = LONG_SPEC["queries"]
+    want = tmp_path / "want"; want.mkdir(); got = tmp_path / "got"; got.mkdir()
+    subprocess.run([oracle_bin, "--long-sentences"] + op.fixture_args(lf) + [str(want)], check=True, capture_output=True)
+    r = subprocess.run([exe] + op.fixture_args(lf) + [str(got)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1 and "Not possible, too long sentence" in r.stdout and not os.listdir(got)
+    r = subprocess.run([exe, "--long-sentences"] + op.fixture_args(lf) + [str(got)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert op.sha_dir(str(got), nq) == op.sha_dir(str(want), nq)
+    # library interface, and a corpus within the reference's limits
+    fx = make_fixture("tiny", fixtures_dir); files = op.fixture_args(fx); out = tmp_path / "tiny"; out.mkdir()
+    ex = cgx.Extractor(0); corpus = cgx.Corpus.load(files[0], files[2], files[3], files[4], long_sentences=True)
+    ex.upload_corpus(corpus); ex.extract_grammars(corpus, files[1], str(out))
+    assert op.sha_dir(str(out), 7) == META["tiny"]["grammar"]
+    ex.close(); corpus.close()
+
+
 @pytest.mark.parametrize("name", ["tiny", "mid"])
 def test_every_stage_matches_the_oracle(name, cgx, oracle_bin, fixtures_dir, tmp_path):
     fx = make_fixture(name, fixtures_dir); dump = str(tmp_path / "d.bin")

@@ -104,3 +104,27 @@ def test_dump_invariants(oracle_bin, tmp_path):
             assert up[t, l] <= down[t, l]
             if l:
                 assert up[t, l - 1] <= up[t, l] and down[t, l] <= down[t, l - 1]   # nested intervals
+
+
+LONG_SPEC = dict(pairs=120, vocab=160, queries=6, seed=11, lo=240, hi=330)       # sentence pairs of 240..330 tokens: beyond the reference's byte positions
+
+
+def make_long_fixture(base):
+    fx = os.path.join(base, "long")
+    if not os.path.exists(os.path.join(fx, "lex.txt")):
+        gen_fixture.write_fixture(fx, **LONG_SPEC)
+    return fx
+
+
+def test_long_sentence_mode_of_the_oracle(oracle_bin, fixtures_dir, tmp_path):
+    """--long-sentences: wider positions change nothing for sentences the reference accepts (the tiny fixture gives
+    the golden files with the switch on), and a corpus of 240..330-token sentences, which the default mode refuses with the
+    reference's message and exit code (ExtractPair.cu:2683), runs with it."""
+    fx = os.path.join(GOLD, "tiny"); out = tmp_path / "t"; out.mkdir()
+    subprocess.run([oracle_bin, "--long-sentences"] + op.fixture_args(fx) + [str(out)], check=True, capture_output=True)
+    assert op.sha_dir(str(out), 7) == META["tiny"]["grammar"]
+    lf = make_long_fixture(fixtures_dir); o2 = tmp_path / "l"; o2.mkdir()
+    r = subprocess.run([oracle_bin] + op.fixture_args(lf) + [str(o2)], capture_output=True, text=True)
+    assert r.returncode == 1 and "Not possible, too long sentence" in r.stdout
+    r = subprocess.run([oracle_bin, "--long-sentences"] + op.fixture_args(lf) + [str(o2)], capture_output=True, text=True)
+    assert r.returncode == 0 and sum(1 for _ in open(o2 / "grammar.0.s")) > 1000
