@@ -309,3 +309,30 @@ def test_two_gpu_bench_broadcast_paths(bcast):
     assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["index"]["broadcast_bytes"] > 0
     a, b = two["rules_per_s"] * two["ms_per_step"], one["rules_per_s"] * one["ms_per_step"]                     # rules per step x 1000, from rounded fields
     assert abs(a - b) <= 1e-4 * b and two["counts"]["grammar_lines"] > 0
+
+
+def test_two_ranks_on_one_gpu_run_the_product(tmp_path):
+    """The N > 1 flow of the PRODUCT on the one card a test box has: bench.py under torchrun with two gloo ranks that both use
+    cuda:0 (`--single-device`): corpus files shared through /dev/shm, rank 1 receives the index buffer by buffer and rebuilds
+    the derived tables, the queries are split by token count, each rank writes its own grammar files, the per-rank statistics
+    are gathered.  The rule count of a step must equal a single rank's over the same global batch.  (RCCL itself needs two
+    cards: test_two_gpu_bench_broadcast_paths.)"""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--config", "cfg4", "--pairs", "60000", "--queries", "2000", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--fresh-steps", "1"]
+    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    one = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][0])
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                         os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--single-device"] + common, capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    two = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][0])
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["index"]["broadcast_bytes"] > 0 and two["value_fresh_files"] > 0
+    pr = two["per_rank"]
+    assert pr["writer_threads"][0] >= 2 and pr["gpu_chain_ms_per_step"][0] > 0 and pr["gpu_chain_ms_per_step"][1] >= pr["gpu_chain_ms_per_step"][0]
+    a, b = two["rules_per_s"] * two["ms_per_step"], one["rules_per_s"] * one["ms_per_step"]                     # rules per step x 1000, from rounded fields
+    assert abs(a - b) <= 1e-4 * b and two["counts"]["grammar_lines"] > 0
