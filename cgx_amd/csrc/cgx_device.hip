@@ -308,24 +308,6 @@ template <class T> __global__ void k_head_flags(const T *keys, uint32_t *flags, 
     if (i < n) flags[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
 }
 
-// stable sort of n records by the 128-bit key (hi,lo): two LSD radix passes.  On return
-// hi/lo hold the sorted keys (buffers are swapped with freshly allocated ones).
-static int sort128(cgx_ctx *ctx, uint64_t *&hi, uint64_t *&lo, size_t n, unsigned lo_bits, unsigned hi_bits, uint32_t **perm_out = nullptr) {
-    if (perm_out) *perm_out = nullptr;
-    if (n == 0) return CGX_OK;
-    uint32_t *p0 = nullptr, *p1 = nullptr; uint64_t *k1 = nullptr, *k2 = nullptr;
-    TRY(dalloc(ctx, &p0, n)); TRY(dalloc(ctx, &p1, n)); TRY(dalloc(ctx, &k1, n)); TRY(dalloc(ctx, &k2, n));
-    k_iota<<<nblocks(n, 256), 256, 0, ctx->stream>>>(p0, n);
-    TRY(sort_pairs(ctx, lo, k1, p0, p1, n, 0, lo_bits));                   // k1 = sorted lo, p1 = permutation
-    k_gather<<<nblocks(n, 256), 256, 0, ctx->stream>>>(hi, p1, k2, n);      // k2 = hi in lo-order
-    TRY(sort_pairs(ctx, k2, hi, p1, p0, n, 0, hi_bits));                    // hi = sorted hi, p0 = final permutation
-    k_gather<<<nblocks(n, 256), 256, 0, ctx->stream>>>(lo, p0, k1, n);      // k1 = lo in final order
-    HIPCHK(stream_wait(ctx));
-    dfree(lo); lo = k1; dfree(k2); dfree(p1);
-    if (perm_out) *perm_out = p0; else dfree(p0);
-    return CGX_OK;
-}
-
 // ---- sorting inside short id runs --------------------------------------------------------------------------------------
 // The rule and lexicon keys of a batch are "id-major with short runs": work items are laid out unit by unit (block by block,
 // pattern by pattern), so the array is already ordered by its id (`major`, non-decreasing) and one id has at most RS_MAXRUN
