@@ -34,6 +34,7 @@ struct cgx_ctx {
     bool long_pos = false;              // long-sentence mode (cgx_rules.h): alignment words carry extra position bits, target-side tables are 16-bit
     uint16_t *d_ltar16 = nullptr, *d_rtar16 = nullptr;
     cgx_tok8 *d_tok8 = nullptr; uint8_t *d_lr16 = nullptr;   // derived layouts (cgx_rules.h), built by build_layouts
+    uint8_t *d_lrs = nullptr; uint32_t lrs_k = 0;            // lr16 blocks addressed from the source side (cgx_view::lrs); null / 0 when the corpus does not allow them
     int32_t *d_pos1 = nullptr;          // derived: the corpus positions of every token in ascending order, token by token (same buckets as the suffix array's one-token intervals: tokstart)
     uint64_t *d_lexkey = nullptr; float *d_lexv1 = nullptr, *d_lexv2 = nullptr, *d_lexn1 = nullptr, *d_lexn2 = nullptr;
     uint32_t *d_lexrow = nullptr; int32_t *d_lexnullt = nullptr; uint32_t lex_nrow = 0, lex_ntgt = 0;
@@ -44,6 +45,7 @@ struct cgx_ctx {
     cgx_ngslot *d_ng[4] = {nullptr, nullptr, nullptr, nullptr}; uint32_t ng_cap[4] = {0, 0, 0, 0}; unsigned ng_shift[4] = {0, 0, 0, 0};   // l-gram (l = 2..5) -> SA interval
     int gz_level = 0;                   // 1..9: grammar.<q>.s.gz through zlib instead of plain files
     bool occ_order = true;              // one-token driving phrases take their occurrences in corpus order (d_pos1) instead of suffix order (test / A-B hook)
+    bool src_blocks = true;             // the lookups find a sentence's target-side bytes from its source start (d_lrs); 0 = through the delimiter's alignment word (test / A-B hook)
     bool use_layouts = true;            // test hook: 0 = window kernels read the plain str / rlp / ltar / rtar arrays (round-1 access pattern)
     int ngram_max = 5;                  // longest phrase answered from the l-gram tables (1: none, every l >= 2 by binary search)
     bool count_probes = false;          // cgx_sa_lookup also runs the probe-counting variant of its kernel (untimed; "sa_probe_*")

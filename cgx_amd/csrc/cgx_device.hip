@@ -438,7 +438,7 @@ static void free_batch(cgx_ctx *c) {
     c->guard_exits = 0;
 }
 static void free_index(cgx_ctx *c) {
-    dfree(c->d_str); dfree(c->d_sa); dfree(c->d_rlp); dfree(c->d_tstr); dfree(c->d_ltar); dfree(c->d_rtar); dfree(c->d_ltar16); dfree(c->d_rtar16); c->long_pos = false; dfree(c->d_tok8); dfree(c->d_lr16); dfree(c->d_pos1);
+    dfree(c->d_str); dfree(c->d_sa); dfree(c->d_rlp); dfree(c->d_tstr); dfree(c->d_ltar); dfree(c->d_rtar); dfree(c->d_ltar16); dfree(c->d_rtar16); c->long_pos = false; dfree(c->d_tok8); dfree(c->d_lr16); dfree(c->d_lrs); c->lrs_k = 0; dfree(c->d_pos1);
     dfree(c->d_lexkey); dfree(c->d_lexv1); dfree(c->d_lexv2); dfree(c->d_lexn1); dfree(c->d_lexn2); dfree(c->d_lexrow); dfree(c->d_lexnullt); dfree(c->d_lexhkey); dfree(c->d_lexhidx); dfree(c->d_lexslot); dfree(c->d_lexnullv); c->lex_hmask = 0;
     dfree(c->d_tokstart); dfree(c->d_tokrank); dfree(c->d_freq); dfree(c->d_pidx); dfree(c->d_miss);
     dfree(c->d_phit_start); dfree(c->d_phit_len); for (int k = 0; k < 4; k++) { dfree(c->d_ng[k]); c->ng_cap[k] = 0; }
@@ -472,6 +472,7 @@ extern "C" int cgx_set_option(cgx_ctx *c, const char *name, int64_t value) {
     if (!strcmp(name, "gz_level")) { if (value < 0 || value > 9) return CGX_ERR_ARG; c->gz_level = (int)value; return CGX_OK; }
     if (!strcmp(name, "use_layouts")) { c->use_layouts = value != 0; return CGX_OK; }
     if (!strcmp(name, "occ_order")) { c->occ_order = value != 0; return CGX_OK; }
+    if (!strcmp(name, "src_blocks")) { c->src_blocks = value != 0; return CGX_OK; }
     if (!strcmp(name, "count_probes")) { c->count_probes = value != 0; return CGX_OK; }
     if (!strcmp(name, "numa_pin")) { c->numa_pin = value != 0; return CGX_OK; }
     if (!strcmp(name, "prealloc_text")) { c->prealloc_text = value != 0; return CGX_OK; }

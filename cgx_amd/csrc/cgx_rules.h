@@ -47,6 +47,8 @@ struct cgx_view {            // read-only index arrays (device pointers on the G
                              // of a <= 16-word span reads one 64..96-byte run instead of two runs in two arrays
     const uint16_t *ltar16;  // long-sentence mode only (else null): ltar / rtar with 16-bit positions, 0xFFFF = none (then the byte tables and lr16 are unused)
     const uint16_t *rtar16;
+    const uint8_t *lrs;      // lr16 blocks again, but addressed from the SOURCE side: the target words of the sentence whose source starts at
+    uint32_t lrs_k;          // src0 sit at word lrs_k * src0 + (position in the target sentence).  Null when the corpus does not allow it.
 };
 // token / alignment word of corpus position k: from the interleaved array where it exists (one sector serves both), else from the two plain arrays
 CGX_HD int32_t cgx_tok(const cgx_view &v, int64_t k) { return v.tok8 ? v.tok8[k].tok : v.str[k]; }

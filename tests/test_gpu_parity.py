@@ -328,6 +328,21 @@ def test_lookup_output_sizing_paths(opts, cgx, fixtures_dir, tmp_path):
     ex.close(); corpus.close()
 
 
+@pytest.mark.parametrize("name", ["toy", "mid"])
+def test_source_addressed_target_blocks(name, cgx, fixtures_dir, tmp_path):
+    """The lookups find the target-side alignment bytes of a sentence from its SOURCE start (a second copy of the blocks,
+    built with the index when a small factor K fits every sentence pair: target words <= K * (source tokens + 1)); without it
+    they first fetch the sentence's target offset from the delimiter's alignment word.  Both give the golden files, and the
+    fixtures do get the table."""
+    fx = make_fixture(name, fixtures_dir); nq = META[name]["spec"][2]
+    ex, corpus, n = run_product(cgx, fx, str(tmp_path / "a"))
+    assert 1 <= ex.stage_ms("src_blocks_factor") <= 4
+    ex.close(); corpus.close()
+    ex, corpus, n2 = run_product(cgx, fx, str(tmp_path / "b"), src_blocks=0)
+    assert n == n2 and op.sha_dir(str(tmp_path / "a"), nq) == op.sha_dir(str(tmp_path / "b"), nq) == META[name]["grammar"]
+    ex.close(); corpus.close()
+
+
 def test_lexicon_hash_collisions_are_survived(cgx, fixtures_dir, tmp_path):
     """The device lexicon groups rules by (id, hash bits of the target side).  With few hash bits two different target
     sides of one id collide: the device notices (neighbours of a run are compared symbol by symbol) and regroups under

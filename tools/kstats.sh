@@ -10,5 +10,5 @@ python3 - <<P
 import csv
 rows=list(csv.DictReader(open("$GRAFT_REPO_ROOT/gpurun_out/$NAME.csv")))
 for r in rows[:22]:
-    print(r['Name'].split('(')[0].replace('void ','')[:60].ljust(60), r['Calls'], round(float(r['TotalDurationNs'])/1e6/9,1), round(float(r['AverageNs'])/1e6,2))
+    print(r['Name'].split('(')[0].replace('void ','')[:60].ljust(60), r['Calls'], round(float(r["TotalDurationNs"])/1e6/8,1), round(float(r['AverageNs'])/1e6,2))
 P

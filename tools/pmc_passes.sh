@@ -6,7 +6,8 @@ OUT=$1; shift
 REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 mkdir -p "$OUT"; OUT=$(cd "$OUT" && pwd)
 cd /tmp && export TMPDIR=/tmp
-KER='k_look1|k_look2|k_lex_finish|k_fmt_lines|k_extract|k_sa_lookup|k_runsort'
+KER=${PMC_KER:-'k_look1|k_look2|k_lex_finish|k_fmt_lines|k_extract|k_sa_lookup|k_runsort'}
+NOWRITE=--no-write; [ -n "$PMC_WRITE" ] && NOWRITE=--fresh-steps=0      # PMC_WRITE=1: lay out the text and write the files too (k_fmt_lines runs)
 i=0
 for grp in \
   "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VALU" \
@@ -18,7 +19,7 @@ for grp in \
   "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
   if [ -n "$PMC_ONLY" ] && ! echo " $PMC_ONLY " | grep -q " $i "; then continue; fi     # PMC_ONLY="1 2": just those passes
-  timeout -k 10 280 rocprofv3 --pmc $grp --kernel-include-regex "$KER" --output-format csv -d "$OUT/p$i" -- python3 "$REPO/bench.py" --no-write --no-cpu-baseline --steps 1 --warmup 0 "$@" > "$OUT/p$i.log" 2>&1 || echo "pass $i failed" >> "$OUT/fail.txt"
+  timeout -k 10 280 rocprofv3 --pmc $grp --kernel-include-regex "$KER" --output-format csv -d "$OUT/p$i" -- python3 "$REPO/bench.py" $NOWRITE --no-cpu-baseline --steps 1 --warmup 0 "$@" > "$OUT/p$i.log" 2>&1 || echo "pass $i failed" >> "$OUT/fail.txt"
   f=$(find "$OUT/p$i" -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python3 "$REPO/tools/pmc_sum.py" "$f" > "$OUT/p$i.sum.txt"
   rm -rf "$OUT/p$i"
