@@ -343,6 +343,22 @@ def test_source_addressed_target_blocks(name, cgx, fixtures_dir, tmp_path):
     ex.close(); corpus.close()
 
 
+def test_corpus_without_source_addressed_blocks(cgx, oracle_bin, fixtures_dir, tmp_path):
+    """One sentence pair whose target is more than four times its source (one source word, twelve target words) and the
+    source-addressed table is not built (its factor would be 7): the lookups take the delimiter path for the whole corpus,
+    and the files still equal the oracle's on the same corpus."""
+    fx = make_fixture("toy", fixtures_dir); d = tmp_path / "fx"; shutil.copytree(fx, d)
+    first_src = open(d / "corpus.f").readline().split()[0]; tw = open(d / "corpus.e").readline().split()
+    with open(d / "corpus.f", "a") as f: f.write(first_src + "\n")
+    with open(d / "corpus.e", "a") as f: f.write(" ".join((tw * 12)[:12]) + "\n")
+    with open(d / "corpus.a", "a") as f: f.write("0-0 0-1\n")
+    op.run_oracle(oracle_bin, str(d), str(tmp_path / "o"))
+    ex, corpus, n = run_product(cgx, str(d), str(tmp_path / "p"))
+    assert ex.stage_ms("src_blocks_factor") == 0
+    assert op.sha_dir(str(tmp_path / "p"), 7) == op.sha_dir(str(tmp_path / "o"), 7)
+    ex.close(); corpus.close()
+
+
 def test_lexicon_hash_collisions_are_survived(cgx, fixtures_dir, tmp_path):
     """The device lexicon groups rules by (id, hash bits of the target side).  With few hash bits two different target
     sides of one id collide: the device notices (neighbours of a run are compared symbol by symbol) and regroups under
