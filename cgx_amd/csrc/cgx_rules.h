@@ -95,6 +95,35 @@ CGX_HD int cgx_sentence(const cgx_view &v, int k, uint32_t w, int *src0) {
     return prev_delim == -1 ? 0 : (int)cgx_rlpw(v, prev_delim);
 }
 
+#if defined(__HIPCC__)
+// cgx_tight on the lr16 blocks (also the source-addressed copy), te - ts <= 15.  The blocks hold the bytes NORMALISED: a target word
+// that is not aligned has L = 255 and R = 0 (the tables it is built from say 255 / 255), so that it drops out of a minimum of
+// L and a maximum of R by itself; the words past te are forced to the same values with two masks per dword.  What is left is a
+// 16-way unsigned minimum and maximum, taken two 16-bit lanes at a time -- about 50 vector instructions where the byte-by-byte
+// version with its three conditions per word took 150, and this routine is most of what the extraction kernels execute.
+typedef unsigned short cgx_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bool cgx_tight_blocks(const uint8_t *lr16, int ts, int te, int s_chk, int e_chk, int src0) {
+    uint32_t a[5], b[5];
+    CGX_UNROLL
+    for (int i = 0; i < 5; i++) { const uint32_t o = cgx_lr16_off((uint32_t)(ts & ~3) + 4u * (uint32_t)i); a[i] = *(const uint32_t *)(lr16 + o); b[i] = *(const uint32_t *)(lr16 + o + 16); }
+    const unsigned sh = (unsigned)ts & 3u; const int n = te - ts + 1;                    // words in the span, 1..16
+    cgx_u16x2 mn = {0xFFFF, 0xFFFF}, mx = {0, 0};
+    CGX_UNROLL
+    for (int i = 0; i < 4; i++) {
+        uint32_t l4 = __builtin_amdgcn_alignbyte(a[i + 1], a[i], sh), r4 = __builtin_amdgcn_alignbyte(b[i + 1], b[i], sh);
+        const int k = n - 4 * i;                                                        // bytes of this dword inside the span
+        const uint32_t m = k >= 4 ? 0xFFFFFFFFu : k <= 0 ? 0u : (1u << (8 * k)) - 1u;
+        l4 |= ~m; r4 &= m;
+        const uint32_t le = __builtin_amdgcn_perm(0u, l4, 0x0C020C00u), lo_ = __builtin_amdgcn_perm(0u, l4, 0x0C030C01u);   // bytes 0,2 and 1,3 as two 16-bit lanes
+        const uint32_t re = __builtin_amdgcn_perm(0u, r4, 0x0C020C00u), ro_ = __builtin_amdgcn_perm(0u, r4, 0x0C030C01u);
+        mn = __builtin_elementwise_min(mn, __builtin_elementwise_min(__builtin_bit_cast(cgx_u16x2, le), __builtin_bit_cast(cgx_u16x2, lo_)));
+        mx = __builtin_elementwise_max(mx, __builtin_elementwise_max(__builtin_bit_cast(cgx_u16x2, re), __builtin_bit_cast(cgx_u16x2, ro_)));
+    }
+    const int lo = mn.x < mn.y ? mn.x : mn.y, hi = mx.x > mx.y ? mx.x : mx.y;
+    // no aligned word at all: the byte-by-byte version ends with lo = CGX_NOPOS, hi = 0
+    return src0 + (lo == 255 ? CGX_NOPOS : lo) == s_chk && src0 + hi == e_chk;
+}
+#endif
 // Does the target span [ts,te] project back exactly onto source [s_chk,e_chk]?  Unaligned
 // target words inside the span are ignored (ExtractPair.cu:103-133).
 CGX_HD bool cgx_tight(const cgx_view &v, int ts, int te, int s_chk, int e_chk, int src0) {
@@ -108,15 +137,11 @@ CGX_HD bool cgx_tight(const cgx_view &v, int ts, int te, int s_chk, int e_chk, i
     // both byte tables are read with five aligned dword loads each (they are padded) instead of a byte load per
     // word -- the extraction kernels were bound by the number of L1 requests, most of them issued here.
     if (te - ts < 16) {
+        if (v.lr16) return cgx_tight_blocks(v.lr16, ts, te, s_chk, e_chk, src0);
         uint32_t a[5], b[5];
-        if (v.lr16) {
-            CGX_UNROLL
-            for (int i = 0; i < 5; i++) { const uint32_t o = cgx_lr16_off((uint32_t)(ts & ~3) + 4u * (uint32_t)i); a[i] = *(const uint32_t *)(v.lr16 + o); b[i] = *(const uint32_t *)(v.lr16 + o + 16); }
-        } else {
-            const uint32_t *pl = (const uint32_t *)(v.ltar + (ts & ~3)), *pr = (const uint32_t *)(v.rtar + (ts & ~3));
-            CGX_UNROLL
-            for (int i = 0; i < 5; i++) { a[i] = pl[i]; b[i] = pr[i]; }
-        }
+        const uint32_t *pl = (const uint32_t *)(v.ltar + (ts & ~3)), *pr = (const uint32_t *)(v.rtar + (ts & ~3));
+        CGX_UNROLL
+        for (int i = 0; i < 5; i++) { a[i] = pl[i]; b[i] = pr[i]; }
         const unsigned sh = (unsigned)ts & 3u; const int last = te - ts;
         CGX_UNROLL
         for (int i = 0; i < 4; i++) {
