@@ -137,6 +137,14 @@ def test_grammar_files_do_not_depend_on_batching(world):
         n3 = ex.extract_grammars_ids(host, qoff, qtok, dirs[2], 0)
         ex.set_option("sub_batch", 0); ex.set_option("chunk_items", 1 << 26)
         assert n3 == n_all and _sha_dir(dirs[2], nq) == ref
+        # the derived layouts of the lookups switched off (occurrences in suffix order, the sentence's target offset through
+        # the delimiter instead of the source-addressed blocks): at this size the table exists, and both ways agree
+        assert 1 <= ex.stage_ms("src_blocks_factor") <= 4
+        shutil.rmtree(dirs[2]); os.mkdir(dirs[2])
+        ex.set_option("src_blocks", 0); ex.set_option("occ_order", 0)
+        n4 = ex.extract_grammars_ids(host, qoff, qtok, dirs[2], 0)
+        ex.set_option("src_blocks", 1); ex.set_option("occ_order", 1)
+        assert n4 == n_all and _sha_dir(dirs[2], nq) == ref
     finally:
         shutil.rmtree(out, ignore_errors=True)
 
