@@ -483,9 +483,12 @@ CGX_HD int64_t cgx_lex_find(const cgx_lexview &t, int32_t src, int32_t tgt) {
 }
 
 // values of the (src,tgt) row: v[0..3] = v1, v2, n1, n2.  false when the pair is not in the table.
-CGX_HD bool cgx_lex_get(const cgx_lexview &t, int32_t src, int32_t tgt, float *v) {
+// SLOTS: the caller knows the view has the packed slots (the MaxLex kernel is compiled for that case alone: with the general
+// routine inlined at its three call sites the kernel carried the row search and the index hash along through every divergent loop)
+template <bool SLOTS>
+CGX_HD bool cgx_lex_get_t(const cgx_lexview &t, int32_t src, int32_t tgt, float *v) {
     if (src < -1 || tgt < -1) return false;
-    if (t.hslot) {
+    if (SLOTS || t.hslot) {
         if (src == -1 && tgt >= 0) {
             if ((uint32_t)tgt >= t.ntgt) return false;
             const cgx_lexnull e = t.nullv[tgt];
@@ -509,6 +512,7 @@ CGX_HD bool cgx_lex_get(const cgx_lexview &t, int32_t src, int32_t tgt, float *v
     v[0] = t.v1[m]; v[1] = t.v2[m]; v[2] = t.n1[m]; v[3] = t.n2[m];
     return true;
 }
+CGX_HD bool cgx_lex_get(const cgx_lexview &t, int32_t src, int32_t tgt, float *v) { return cgx_lex_get_t<false>(t, src, tgt, v); }
 
 // MaxLexFgivenE / MaxLexEgivenF of one rule (kind 0: one gap, 1: two gaps, 2: contiguous).
 // The reference adds -log10(max) per word in float; the log of every table value is
@@ -520,8 +524,9 @@ CGX_HD bool cgx_lex_get(const cgx_lexview &t, int32_t src, int32_t tgt, float *v
 // position, strict '>'), and the two sums are still added in ascending word order, so the
 // floats are identical.
 #define CGX_MAXLEX_SRC 5
-CGX_HD void cgx_maxlex(const cgx_lexview &t, const int32_t *tstr, const int32_t *src, int nsrc, uint32_t tstart,
-                       int end, int gap1, int gap1_1, int gap2, int gap2_1, int kind, float *fe, float *ef) {
+template <bool SLOTS>
+CGX_HD void cgx_maxlex_t(const cgx_lexview &t, const int32_t *tstr, const int32_t *src, int nsrc, uint32_t tstart,
+                         int end, int gap1, int gap1_1, int gap2, int gap2_1, int kind, float *fe, float *ef) {
     float fgivene = 0.0f, egivenf = 0.0f;
     const int t0 = (int)tstart, tend = t0 + end, g1s = t0 + gap1, g1e = t0 + gap1_1, g2s = t0 + gap2, g2e = t0 + gap2_1;
     if (nsrc <= CGX_MAXLEX_SRC) {
@@ -534,12 +539,12 @@ CGX_HD void cgx_maxlex(const cgx_lexview &t, const int32_t *tstr, const int32_t 
             const int32_t tw = tstr[jj];
             float mx1 = 0.0f, ng1 = 0.0f;
             float q[4];
-            if (cgx_lex_get(t, -1, tw, q) && q[0] > mx1) { mx1 = q[0]; ng1 = q[2]; }
+            if (cgx_lex_get_t<SLOTS>(t, -1, tw, q) && q[0] > mx1) { mx1 = q[0]; ng1 = q[2]; }
         CGX_UNROLL
             for (int j = 0; j < CGX_MAXLEX_SRC; j++) {
                 if (j >= nsrc) break;
-                if (first && cgx_lex_get(t, src[j], -1, q) && q[1] > mx2[j]) { mx2[j] = q[1]; ng2[j] = q[3]; }
-                if (cgx_lex_get(t, src[j], tw, q)) {
+                if (first && cgx_lex_get_t<SLOTS>(t, src[j], -1, q) && q[1] > mx2[j]) { mx2[j] = q[1]; ng2[j] = q[3]; }
+                if (cgx_lex_get_t<SLOTS>(t, src[j], tw, q)) {
                     if (q[0] > mx1) { mx1 = q[0]; ng1 = q[2]; }
                     if (q[1] > mx2[j]) { mx2[j] = q[1]; ng2[j] = q[3]; }
                 }
@@ -575,6 +580,10 @@ CGX_HD void cgx_maxlex(const cgx_lexview &t, const int32_t *tstr, const int32_t 
         egivenf += mx > 0.0f ? neg : CGX_MAXSCORE;
     }
     *fe = fgivene; *ef = egivenf;
+}
+CGX_HD void cgx_maxlex(const cgx_lexview &t, const int32_t *tstr, const int32_t *src, int nsrc, uint32_t tstart,
+                       int end, int gap1, int gap1_1, int gap2, int gap2_1, int kind, float *fe, float *ef) {
+    cgx_maxlex_t<false>(t, tstr, src, nsrc, tstart, end, gap1, gap1_1, gap2, gap2_1, kind, fe, ef);
 }
 
 #endif
