@@ -457,7 +457,6 @@ struct cgx_lexview {
     // optional packed copies for MaxLex: the four values next to the key (one 32-byte slot per probe instead of
     // key + index + four arrays), and (NULL, tgt) as a direct {v1, n1} table (v1 < 0: absent)
     const struct cgx_lexslot *hslot = nullptr; const struct cgx_lexnull *nullv = nullptr;
-    const struct cgx_lexnull *snullv = nullptr;   // (src, NULL) as a direct table too: {v2, n2} per src + 1 (v1 < 0: absent)
 };
 struct cgx_lexslot { uint64_t key; float v1, v2, n1, n2; uint64_t pad; };
 struct cgx_lexnull { float v1, n1; };
@@ -498,12 +497,6 @@ CGX_HD bool cgx_lex_get_t(const cgx_lexview &t, int32_t src, int32_t tgt, float 
             return true;
         }
         if ((uint32_t)(src + 1) >= t.nrow) return false;
-        if (tgt == -1 && src >= 0 && t.snullv) {
-            const cgx_lexnull e = t.snullv[src + 1];
-            if (e.v1 < 0.0f) return false;
-            v[0] = 0.0f; v[1] = e.v1; v[2] = 0.0f; v[3] = e.n1;   // only v2/n2 are read for (src, NULL)
-            return true;
-        }
         const uint64_t want = cgx_lexkey_pack(src, tgt);
         if (want == 0) return false;
         uint32_t slot = (uint32_t)((want * 0x9E3779B97F4A7C15ull) >> t.hshift) & t.hmask;
