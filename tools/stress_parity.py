@@ -39,10 +39,12 @@ def run_case(cgx_amd, shape, verbose=True):
         fx = os.path.join(tmp, "fx"); gen_fixture.write_fixture(fx, pairs, vocab, nq, seed, lo=lo, hi=hi)
         files = [os.path.join(fx, n) for n in ("corpus.f", "query.f", "corpus.e", "corpus.a", "lex.txt")]
         od, pd = os.path.join(tmp, "o"), os.path.join(tmp, "p"); os.mkdir(od); os.mkdir(pd)
-        t0 = time.time(); subprocess.run([oracle] + files + [od], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL); t_or = time.time() - t0
+        long_mode = bool(opts.get("long_sentences"))                # not a library option: both sides run with their long-sentence switch
+        t0 = time.time(); subprocess.run([oracle] + (["--long-sentences"] if long_mode else []) + files + [od], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL); t_or = time.time() - t0
         ex = cgx_amd.Extractor(0)
-        for k, v in opts.items(): ex.set_option(k, int(v))
-        corpus = cgx_amd.Corpus.load(files[0], files[2], files[3], files[4]); ex.upload_corpus(corpus)
+        for k, v in opts.items():
+            if k != "long_sentences": ex.set_option(k, int(v))
+        corpus = cgx_amd.Corpus.load(files[0], files[2], files[3], files[4], long_sentences=long_mode); ex.upload_corpus(corpus)
         t0 = time.time(); n = ex.extract_grammars(corpus, files[1], pd); ex.flush(); t_gpu = time.time() - t0
         c = ex.counts()
         same = sha_dir(od, nq) == sha_dir(pd, nq)
@@ -82,6 +84,10 @@ def main():
         for i in range(args.fuzz):
             lo = r.choice([1, 2, 4, 8, 15]); hi = lo + r.choice([3, 10, 25, 60])
             opts = {k: r.choice(v) for k, v in menu.items() if r.random() < 0.25}
+            if not args.big and r.random() < 0.2:               # long-sentence mode, half of the time on sentences the reference would refuse
+                opts["long_sentences"] = 1
+                if r.random() < 0.5:
+                    shapes.append((r.choice([300, 800]), r.choice([130, 900]), r.choice([10, 25]), 1000 * args.seed + i, 200, r.choice([260, 330]), opts)); continue
             if args.big: shapes.append((r.choice([50000, 150000]), r.choice([150, 1000, 30000]), r.choice([100, 300]), 1000 * args.seed + i, lo, hi, opts))
             else: shapes.append((r.choice([1500, 4000, 9000, 25000]), r.choice([101, 105, 130, 250, 900, 5000]), r.choice([20, 60, 130]), 1000 * args.seed + i, lo, hi, opts))
     if args.opt: shapes = [s_[:6] + (dict(o.split("=") for o in args.opt),) for s_ in shapes]
