@@ -314,15 +314,16 @@ template <class T> __global__ void k_head_flags(const T *keys, uint32_t *flags, 
 // records (a unit has at most 300 / 65 / 70 sampled occurrences).  Only the order INSIDE each id run is missing, and the id
 // need not even be part of the key.  A device-wide radix sort spends 7-10 passes over the whole array on that (round 2: 24 ms
 // per batch for the rule keys, 16 ms for the lexicon keys).  Here, two kernels, one read and one write of the array:
-//   k_runsort_block   a block takes 256 consecutive records into LDS; every record counts the records of ITS run inside the block
+//   k_runsort_block   a block takes RS_BLOCK consecutive records into LDS; every record counts the records of ITS run inside the block
 //                     that sort before it (ties by position: stable) and goes to that rank.  Runs that lie inside one block --
-//                     nearly all of them -- are done; the work per record is its run's length, at most 256.
+//                     nearly all of them -- are done; the work per record is its run's length.  (1024 records per block: 256 made the
+//                     first kernel 15 % faster and the second twice as slow, 15.6 ms per batch in all against 13.7.)
 //   k_runsort_fix     one wave per block boundary that cuts a run: the run's pieces (each sorted by the first kernel) are loaded
 //                     into LDS and ranked against each other.
 // (Measured and dropped on the way, profiles/r3l, r3m: a bitonic network over 2048-record tiles with halos -- 66 barrier stages,
 // 68 us per tile; a counting rank sort over such tiles -- per-thread tails on 300-record runs; rocPRIM's segmented radix sort --
 // 5 ms per 6.7e7 keys in 1e7 segments.  All three were slower than the radix sort they were to replace.)
-#define RS_BLOCK 256
+#define RS_BLOCK 1024
 #define RS_MAXRUN 320
 template <bool VAL>
 __global__ __launch_bounds__(RS_BLOCK) void k_runsort_block(const uint32_t *__restrict__ major, const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin,
