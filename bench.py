@@ -309,6 +309,8 @@ def main():
     spool = tempfile.mkdtemp(prefix="cgx_bench_r%d_" % rank, dir=base) if write else None
     # a chunk is also at most one internal batch of the library (300 000 query tokens by default): the per-batch timers and
     # tallies read after each chunk then describe the whole chunk, and every configuration runs the same pipeline
+    if args.sub_batch > 0:
+        chunk = min(chunk, args.sub_batch)                      # smaller batches are submitted as chunks here, so that the per-batch timers below still describe what ran
     chunks = make_chunks(qoff, len(qtok), chunk)
     chunk = max(b - a for a, b in chunks)
     whole = len(chunks) == 1
