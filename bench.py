@@ -149,7 +149,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; nccl (= RCCL over xGMI) for real runs, gloo only to rehearse N>1 on a one-GPU box")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--bcast", choices=("torch", "c"), default="torch", help="index broadcast: torch = torch.distributed.broadcast (RCCL) on a staging tensor per buffer; c = the library's own cgx_broadcast_index on an RCCL communicator made here (what a C host would call)")
-    ap.add_argument("--sub-batch", type=int, default=0, help="queries per internal batch inside one call (0 = automatic)")
+    ap.add_argument("--sub-batch", type=int, default=0, help="at most this many queries per batch (submitted as chunks of a step; 0 = automatic: as many as fit the spool, at most one step)")
     ap.add_argument("--no-numa-pin", action="store_true", help="do not bind the writer threads to the GPU's NUMA node")
     ap.add_argument("--sync-write", action="store_true", help="write each chunk's files before starting the next chunk")
     ap.add_argument("--fresh-steps", type=int, default=None, help="extra timed steps AFTER the contract's K steps that write every chunk into a NEW directory (value_fresh_files); default 3 (1 when a step is several chunks), 0 = skip")
