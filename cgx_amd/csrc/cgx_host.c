@@ -166,7 +166,7 @@ static void *piece_parse_job(void *arg) { sidepiece *pc = arg; pc->rc = piece_pa
 static void *piece_place_job(void *arg) {
     sidepiece *pc = arg;
     for (size_t k = 0; k < pc->ntok; k++) pc->str_out[pc->tok_off + k] = pc->tok[k] == 1 ? 1 : pc->l2g[pc->tok[k]];
-    if (pc->want_P) memcpy(pc->P_out + pc->tok_off, pc->P, pc->ntok);
+    if (pc->want_P && pc->ntok) memcpy(pc->P_out + pc->tok_off, pc->P, pc->ntok);      /* an empty piece has no P array */
     for (size_t k = 0; k < pc->nsent; k++) pc->sent_out[pc->sent_off + k] = (int32_t)(pc->tok_off + (size_t)pc->sent[k]);
     return NULL;
 }

@@ -114,3 +114,14 @@ def test_corpus_cache_is_not_trusted(cgx, fixtures_dir, tmp_path):
     open(path, "wb").write(bad)
     with pytest.raises(cgx.CgxError, match="source token id"):
         cgx.Corpus.load_cache(path)
+
+
+def test_mutated_inputs_never_fault(cgx):
+    """tools/fuzz_loaders.py: mutated corpus files and cache files come back as a corpus or as an error message (the same sweep
+    runs under ASan / UBSan with tools/asan_host.sh; here the product build, in a child process so that a fault is a test failure)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_loaders.py"), "--cases", "80", "--seed", "5"], capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-2000:]
+    assert b"fuzz_loaders: 80 cases" in r.stdout
