@@ -43,8 +43,8 @@ struct cgx_view {            // read-only index arrays (device pointers on the G
     uint32_t n;
     // derived device-only layouts (built after upload, rebuilt on replicas):
     const cgx_tok8 *tok8;    // str and rlp interleaved: a 16-token window is ONE 128-byte run instead of two 64-byte runs in two arrays
-    const uint8_t *lr16;     // ltar/rtar in blocks of 16 target words: 16 L bytes, then their 16 R bytes -- the back-projection test
-                             // of a <= 16-word span reads one 64..96-byte run instead of two runs in two arrays
+    const uint8_t *lr16;     // ltar/rtar in overlapping 64-byte blocks, one per 8 target words (cgx_lr_block): the back-projection test
+                             // of a <= 16-word span reads ONE block with three 16-byte loads instead of a run in each of two arrays
     const uint16_t *ltar16;  // long-sentence mode only (else null): ltar / rtar with 16-bit positions, 0xFFFF = none (then the byte tables and lr16 are unused)
     const uint16_t *rtar16;
     const uint8_t *lrs;      // lr16 blocks again, but addressed from the SOURCE side: the target words of the sentence whose source starts at
@@ -53,8 +53,6 @@ struct cgx_view {            // read-only index arrays (device pointers on the G
 // token / alignment word of corpus position k: from the interleaved array where it exists (one sector serves both), else from the two plain arrays
 CGX_HD int32_t cgx_tok(const cgx_view &v, int64_t k) { return v.tok8 ? v.tok8[k].tok : v.str[k]; }
 CGX_HD uint32_t cgx_rlpw(const cgx_view &v, int64_t k) { return v.tok8 ? v.tok8[k].rlp : v.rlp[k]; }
-// address of the dword holding the L bytes of target words w..w+3 (w a multiple of 4) in the lr16 layout; the R bytes sit 16 bytes further
-CGX_HD uint32_t cgx_lr16_off(uint32_t w) { return ((w >> 4) << 5) | (w & 15u); }
 
 // running min/max of aligned target positions over a set of source tokens
 #define CGX_NOPOS 0xFFFF     // "no position yet": above every position (the reference starts its unsigned chars at 255, above every position IT allows)
@@ -102,10 +100,21 @@ CGX_HD int cgx_sentence(const cgx_view &v, int k, uint32_t w, int *src0) {
 // 16-way unsigned minimum and maximum, taken two 16-bit lanes at a time -- about 50 vector instructions where the byte-by-byte
 // version with its three conditions per word took 150, and this routine is most of what the extraction kernels execute.
 typedef unsigned short cgx_u16x2 __attribute__((ext_vector_type(2)));
+// The block layout of lr16 and lrs: one 64-byte block per EIGHT words, holding the L bytes of the 24 words from its first one on,
+// then their 24 R bytes (16 bytes unused).  A span of <= 16 words that starts in block i ends in block i, so the bytes a
+// back-projection test needs -- a[i], b[i] = L and R of words (ts & ~3) + 4i .. + 3 -- come with THREE aligned 16-byte loads of one
+// line.  (Blocks of 16 words without overlap made that ten 4-byte loads over two blocks; what a kernel pays the L1 for is load
+// instructions per lane, hardly less for a line it already asked for: tools/micro/gather_coop)
+__device__ __forceinline__ void cgx_lr_block(const uint8_t *tab, int ts, uint32_t (&a)[5], uint32_t (&b)[5]) {
+    const uint4 *p = (const uint4 *)(tab + ((size_t)((uint32_t)ts >> 3) << 6));
+    const uint4 q0 = p[0], q1 = p[1], q2 = p[2];           // L of words 0..15 | L 16..23, R 0..7 | R 8..23
+    const bool up = (ts & 4) != 0;                          // the span starts in the block's second dword
+    a[0] = up ? q0.y : q0.x; a[1] = up ? q0.z : q0.y; a[2] = up ? q0.w : q0.z; a[3] = up ? q1.x : q0.w; a[4] = up ? q1.y : q1.x;
+    b[0] = up ? q1.w : q1.z; b[1] = up ? q2.x : q1.w; b[2] = up ? q2.y : q2.x; b[3] = up ? q2.z : q2.y; b[4] = up ? q2.w : q2.z;
+}
 __device__ __forceinline__ bool cgx_tight_blocks(const uint8_t *lr16, int ts, int te, int s_chk, int e_chk, int src0) {
     uint32_t a[5], b[5];
-    CGX_UNROLL
-    for (int i = 0; i < 5; i++) { const uint32_t o = cgx_lr16_off((uint32_t)(ts & ~3) + 4u * (uint32_t)i); a[i] = *(const uint32_t *)(lr16 + o); b[i] = *(const uint32_t *)(lr16 + o + 16); }
+    cgx_lr_block(lr16, ts, a, b);
     const unsigned sh = (unsigned)ts & 3u; const int n = te - ts + 1;                    // words in the span, 1..16
     cgx_u16x2 mn = {0xFFFF, 0xFFFF}, mx = {0, 0};
     CGX_UNROLL
