@@ -515,7 +515,9 @@ def report(ex, args, cfg, L):
                 e.update(traffic=int(tr), traffic_GBps=round(tr / (ms * 1e-3) / 1e9, 1), sectors_per_occurrence=round(kk["TCC_EA0_RDREQ_per_batch"] / w, 2),
                          traffic_counter_raw=int(raw), traffic_bounds=[int(raw), int(kk["TCC_EA0_RDREQ_per_batch"] * 128.0 + kk["TCC_EA0_WRREQ_per_batch"] * 64.0)], bytes_per_read_request_assumed=bpr,
                          traffic_frac_of_peak=round(tr / (ms * 1e-3) / 1e9 / 8000.0, 4),     # what the HBM actually moved for this kernel, as a fraction of 8 TB/s
-                         windows_per_s=round(w / (ms * 1e-3), 1), microbench_random_128B_runs_per_s=pk["random_read_peak"]["runs_per_s_128B"])   # tools/micro/gather_bw on the same card: a comparison, not a bound (neighbouring occurrences share sectors in the L2)
+                         windows_per_s=round(w / (ms * 1e-3), 1), microbench_random_128B_runs_per_s=pk["random_read_peak"]["runs_per_s_128B"],   # tools/micro/gather_bw on the same card, one run per lane: a comparison, not a bound (neighbouring occurrences share sectors in the L2)
+                         microbench_random_128B_runs_per_s_eight_lanes_per_run=pk["random_read_peak"].get("runs_per_s_128B_eight_lanes_per_run_8B_offsets"),   # tools/micro/gather_coop: the way the kernels read their windows now (runs at random 8-byte offsets)
+                         dram_read_requests_per_s=round(kk["TCC_EA0_RDREQ_per_batch"] / (ms * 1e-3), 1))   # against 3.0e10 (64-byte) .. 5.2e10 (16-byte) random reads per second of the card: the bound that applies
             by_time.append(e)
     div = steps * 1.0
     out = {
