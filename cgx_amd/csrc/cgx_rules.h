@@ -17,6 +17,7 @@
 #ifndef CGX_RULES_H
 #define CGX_RULES_H
 #include <stdint.h>
+#include <stddef.h>
 
 #if defined(__HIPCC__)
 #define CGX_HD __host__ __device__ __forceinline__
@@ -93,6 +94,29 @@ CGX_HD int cgx_sentence(const cgx_view &v, int k, uint32_t w, int *src0) {
     return prev_delim == -1 ? 0 : (int)cgx_rlpw(v, prev_delim);
 }
 
+// The block layout of lr16 and lrs: one 64-byte block per EIGHT words, holding the L bytes of the 24 words from its first one on,
+// then their 24 R bytes (16 bytes unused).  A span of <= 16 words that starts in block i ends in block i, so the bytes a
+// back-projection test needs -- a[i], b[i] = L and R of words (ts & ~3) + 4i .. + 3 -- come with THREE aligned 16-byte loads of one
+// line.  (Blocks of 16 words without overlap made that ten 4-byte loads over two blocks; what a kernel pays the L1 for is load
+// instructions per lane, hardly less for a line it already asked for: tools/micro/gather_coop, DESIGN section 3.)
+// cgx_lr_block_put writes one word into the (up to three) blocks that hold it, normalised for cgx_tight_blocks: not aligned = (255, 0).
+// Both compile for the host too (tests/cpu_sim checks the addressing against the plain tables).
+struct __attribute__((aligned(16))) cgx_q16 { uint32_t x, y, z, w; };   // the blocks are 64-byte aligned
+CGX_HD void cgx_lr_block_put(uint8_t *out, size_t w, uint8_t L, uint8_t R) {
+    const bool none = L == 255 || R == 255;
+    for (size_t t = 0; t < 3 && t <= (w >> 3); t++) {
+        uint8_t *blk = out + (((w >> 3) - t) << 6); const size_t o = (w & 7) + 8 * t;
+        blk[o] = none ? 255 : L; blk[24 + o] = none ? 0 : R;
+    }
+}
+CGX_HD void cgx_lr_block(const uint8_t *tab, int ts, uint32_t (&a)[5], uint32_t (&b)[5]) {
+    const cgx_q16 *p = (const cgx_q16 *)(tab + ((size_t)((uint32_t)ts >> 3) << 6));     // 64-byte aligned: three 16-byte loads on the device
+    const cgx_q16 q0 = p[0], q1 = p[1], q2 = p[2];         // L of words 0..15 | L 16..23, R 0..7 | R 8..23
+    const bool up = (ts & 4) != 0;                          // the span starts in the block's second dword
+    a[0] = up ? q0.y : q0.x; a[1] = up ? q0.z : q0.y; a[2] = up ? q0.w : q0.z; a[3] = up ? q1.x : q0.w; a[4] = up ? q1.y : q1.x;
+    b[0] = up ? q1.w : q1.z; b[1] = up ? q2.x : q1.w; b[2] = up ? q2.y : q2.x; b[3] = up ? q2.z : q2.y; b[4] = up ? q2.w : q2.z;
+}
+
 #if defined(__HIPCC__)
 // cgx_tight on the lr16 blocks (also the source-addressed copy), te - ts <= 15.  The blocks hold the bytes NORMALISED: a target word
 // that is not aligned has L = 255 and R = 0 (the tables it is built from say 255 / 255), so that it drops out of a minimum of
@@ -100,18 +124,6 @@ CGX_HD int cgx_sentence(const cgx_view &v, int k, uint32_t w, int *src0) {
 // 16-way unsigned minimum and maximum, taken two 16-bit lanes at a time -- about 50 vector instructions where the byte-by-byte
 // version with its three conditions per word took 150, and this routine is most of what the extraction kernels execute.
 typedef unsigned short cgx_u16x2 __attribute__((ext_vector_type(2)));
-// The block layout of lr16 and lrs: one 64-byte block per EIGHT words, holding the L bytes of the 24 words from its first one on,
-// then their 24 R bytes (16 bytes unused).  A span of <= 16 words that starts in block i ends in block i, so the bytes a
-// back-projection test needs -- a[i], b[i] = L and R of words (ts & ~3) + 4i .. + 3 -- come with THREE aligned 16-byte loads of one
-// line.  (Blocks of 16 words without overlap made that ten 4-byte loads over two blocks; what a kernel pays the L1 for is load
-// instructions per lane, hardly less for a line it already asked for: tools/micro/gather_coop, DESIGN section 3.)
-__device__ __forceinline__ void cgx_lr_block(const uint8_t *tab, int ts, uint32_t (&a)[5], uint32_t (&b)[5]) {
-    const uint4 *p = (const uint4 *)(tab + ((size_t)((uint32_t)ts >> 3) << 6));
-    const uint4 q0 = p[0], q1 = p[1], q2 = p[2];           // L of words 0..15 | L 16..23, R 0..7 | R 8..23
-    const bool up = (ts & 4) != 0;                          // the span starts in the block's second dword
-    a[0] = up ? q0.y : q0.x; a[1] = up ? q0.z : q0.y; a[2] = up ? q0.w : q0.z; a[3] = up ? q1.x : q0.w; a[4] = up ? q1.y : q1.x;
-    b[0] = up ? q1.w : q1.z; b[1] = up ? q2.x : q1.w; b[2] = up ? q2.y : q2.x; b[3] = up ? q2.z : q2.y; b[4] = up ? q2.w : q2.z;
-}
 __device__ __forceinline__ bool cgx_tight_blocks(const uint8_t *lr16, int ts, int te, int s_chk, int e_chk, int src0) {
     uint32_t a[5], b[5];
     cgx_lr_block(lr16, ts, a, b);

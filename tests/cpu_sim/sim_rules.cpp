@@ -39,6 +39,24 @@ int main(int argc, char **argv) {
     const orc_prerange *pidx = arr<orc_prerange>(d, "pidx"); const orc_prehit *ph = arr<orc_prehit>(d, "phits");
     int bad = 0; unsigned guards = 0;
 
+    // ---- the 64-byte target-side blocks (lr16 / lrs): built with cgx_lr_block_put, read with cgx_lr_block; for every start and
+    // every length <= 16 the bytes a back-projection test sees must be those of the plain tables (normalised) ----
+    {
+        const size_t nt = d["ltar"].size();
+        std::vector<uint8_t> blk(((nt + 64) / 8 + 8) * 64 + 64, 0xFF);
+        uint8_t *tab = blk.data() + ((64 - ((uintptr_t)blk.data() & 63)) & 63);
+        for (size_t w = 0; w < nt; w++) cgx_lr_block_put(tab, w, v.ltar[w], v.rtar[w]);
+        for (size_t ts = 0; ts + 16 <= nt && bad == 0; ts++) {
+            uint32_t a[5], b[5]; cgx_lr_block(tab, (int)ts, a, b);
+            for (int k = 0; k < 16; k++) {
+                const size_t w = ts + k; const int idx = (int)(ts & 3) + k;
+                const uint8_t L = (uint8_t)(a[idx / 4] >> (8 * (idx & 3))), R = (uint8_t)(b[idx / 4] >> (8 * (idx & 3)));
+                const bool none = v.ltar[w] == 255 || v.rtar[w] == 255;
+                if (L != (none ? 255 : v.ltar[w]) || R != (none ? 0 : v.rtar[w])) { printf("lr block: word %zu of the span at %zu reads (%d,%d), tables say (%d,%d)\n", w, ts, L, R, v.ltar[w], v.rtar[w]); bad++; break; }
+            }
+        }
+    }
+
     // ---- frequent-pair sweep (k_precomp) ----
     {
         const int32_t *freq = arr<int32_t>(d, "freq"); const int32_t *miss = arr<int32_t>(d, "miss");
