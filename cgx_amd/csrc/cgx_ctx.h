@@ -34,6 +34,7 @@ struct cgx_ctx {
     bool long_pos = false;              // long-sentence mode (cgx_rules.h): alignment words carry extra position bits, target-side tables are 16-bit
     uint16_t *d_ltar16 = nullptr, *d_rtar16 = nullptr;
     cgx_tok8 *d_tok8 = nullptr; uint8_t *d_lr16 = nullptr;   // derived layouts (cgx_rules.h), built by build_layouts
+    double append_ms = 0.0;             // GPU time of the launches of the append passes since the caller last zeroed it (append_pass)
     uint8_t *d_lrs = nullptr; uint32_t lrs_k = 0;            // lr16 blocks addressed from the source side (cgx_view::lrs); null / 0 when the corpus does not allow them
     int32_t *d_pos1 = nullptr;          // derived: the corpus positions of every token in ascending order, token by token (same buckets as the suffix array's one-token intervals: tokstart)
     uint64_t *d_lexkey = nullptr; float *d_lexv1 = nullptr, *d_lexv2 = nullptr, *d_lexn1 = nullptr, *d_lexn2 = nullptr;

@@ -279,12 +279,23 @@ static int append_pass(cgx_ctx *ctx, uint64_t units, uint64_t chunk, uint64_t W,
         unsigned long long init = n0; TRY(h2d(ctx, total, &init, 1));
         reset();
         appender ap{out.p, out.cap, total, ctx->pool_cap < POOL_N ? (ctx->pool_cap ? ctx->pool_cap : 1u) : POOL_N};
+        // the launches alone between two events of their own (ctx->append_ms, summed over the attempts): a timer around the whole
+        // pass also holds the host round trips before and after them, and in a run whose writer threads use up the process's CPU
+        // quota the thread that feeds the GPU can be held there for tens of milliseconds (profiles/r3cd_cfg5_builds_...json)
+        hipEvent_t ea = nullptr, eb = nullptr;
+        bool timed = hipEventCreate(&ea) == hipSuccess;
+        if (timed && hipEventCreate(&eb) != hipSuccess) { (void)hipEventDestroy(ea); timed = false; }
+        if (timed) (void)hipEventRecord(ea, ctx->stream);
         for (uint64_t w0 = 0; w0 < units; w0 += chunk) {
             uint64_t nw = units - w0 < chunk ? units - w0 : chunk;
             launch(w0, nw, ap);
         }
-        HIPCHK(hipGetLastError());
-        unsigned long long got = 0; TRY(d2h(ctx, &got, total, 1));
+        if (timed) (void)hipEventRecord(eb, ctx->stream);
+        const hipError_t launch_err = hipGetLastError();
+        unsigned long long got = 0; const int rc_got = launch_err == hipSuccess ? d2h(ctx, &got, total, 1) : CGX_ERR_HIP;      // d2h waits for the stream: both events have happened
+        if (timed) { float ms = 0.0f; if (rc_got == CGX_OK && hipEventElapsedTime(&ms, ea, eb) == hipSuccess) ctx->append_ms += (double)ms; (void)hipEventDestroy(ea); (void)hipEventDestroy(eb); }
+        if (launch_err != hipSuccess) { dfree(total); return fail(ctx, CGX_ERR_HIP, "append pass launch", launch_err); }
+        if (rc_got != CGX_OK) { dfree(total); return rc_got; }
         if (got <= out.cap) { out.n = (size_t)got; break; }
         if (attempt) { snprintf(ctx->err, sizeof ctx->err, "append pass overflowed twice"); dfree(total); return CGX_ERR_STATE; }
         want = (size_t)got;
