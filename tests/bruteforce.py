@@ -27,24 +27,63 @@ import numpy as np
 MAX_SPAN = 15
 
 
+NOPOS = 1 << 30              # "no position yet" for a running minimum (the reference starts its unsigned chars at 255, above every position it allows)
+
+
 class Corpus:
+    NA = 255                 # "not aligned" in the position arrays (the reference's byte tables); from_text uses a value above every position
+
     def __init__(self, str_, rlp, ltar, rtar):
         self.s = np.asarray(str_, np.int64); n = len(self.s)
         rlp = np.asarray(rlp, np.uint32)[:n]
         self.L = ((rlp >> 24) & 255).astype(np.int64); self.R = ((rlp >> 16) & 255).astype(np.int64); self.P = ((rlp >> 8) & 255).astype(np.int64)
-        self.rlp = rlp
+        self.rlp = rlp; self.tb = None
         self.ltar = np.asarray(ltar, np.int64); self.rtar = np.asarray(rtar, np.int64)
+        self._delims()
+
+    def _delims(self):
+        n = len(self.s)
         delim = np.nonzero(self.s < 2)[0]
         # next_delim[i] = first index >= i holding a token < 2
         nd = np.full(n + 1, n, np.int64); nd[delim] = delim
         self.next_delim = np.minimum.accumulate(nd[::-1])[::-1]
 
+    @classmethod
+    def from_text(cls, str_, target_file, align_file):
+        """The same object built from the alignment TEXT (one line of `i-j` links per sentence pair, ExtractPair.cu:2639-2739)
+        instead of from packed alignment words: positions are plain integers of any size, so this also serves corpora whose
+        sentences are longer than the reference's byte positions allow (the opt-in long-sentence mode).
+        Token ids come from `str_` (1 closes a sentence); the target side only contributes its sentence lengths."""
+        c = cls.__new__(cls); c.NA = NOPOS
+        c.s = np.asarray(str_, np.int64); n = len(c.s)
+        c.L = np.full(n, NOPOS, np.int64); c.R = np.full(n, NOPOS, np.int64); c.P = np.zeros(n, np.int64); c.tb = np.zeros(n, np.int64); c.rlp = None
+        tlens = [len(line.split()) for line in open(target_file)]
+        links = [[tuple(int(x) for x in w.split("-")) for w in line.split()] for line in open(align_file)]
+        nt = sum(tlens) + len(tlens) + 4
+        c.ltar = np.full(nt, NOPOS, np.int64); c.rtar = np.full(nt, NOPOS, np.int64)
+        k = 0; tb = 0
+        for tl, lk in zip(tlens, links):
+            a = k
+            while k < n and c.s[k] >= 2:
+                c.P[k] = k - a; c.tb[k] = tb; k += 1
+            c.tb[k] = tb
+            sl = k - a; k += 1                                   # past the delimiter
+            for i, j in lk:
+                assert 0 <= i < sl and 0 <= j < tl, "alignment link outside its sentence pair"
+                c.L[a + i] = j if c.L[a + i] == NOPOS else min(c.L[a + i], j); c.R[a + i] = j if c.R[a + i] == NOPOS else max(c.R[a + i], j)
+                c.ltar[tb + j] = i if c.ltar[tb + j] == NOPOS else min(c.ltar[tb + j], i); c.rtar[tb + j] = i if c.rtar[tb + j] == NOPOS else max(c.rtar[tb + j], i)
+            tb += tl + 1                                         # the target side has a delimiter per sentence too
+        c._delims()
+        return c
+
     def aligned(self, k):
-        return self.L[k] != 255 and self.R[k] != 255
+        return self.L[k] != self.NA and self.R[k] != self.NA
 
     def sentence(self, k):
         """(index of the first token of k's sentence, target offset of that sentence)"""
         src0 = int(k - self.P[k])
+        if self.tb is not None:
+            return src0, int(self.tb[k])
         return src0, (0 if src0 == 0 else int(self.rlp[src0 - 1]))
 
     def target_span(self, s, e):
@@ -62,7 +101,7 @@ class Corpus:
         if hi - lo >= MAX_SPAN:
             return None
         src0, tb = self.sentence(s)
-        back = [(self.ltar[j], self.rtar[j]) for j in range(tb + lo, tb + hi + 1) if self.ltar[j] != 255 and self.rtar[j] != 255]
+        back = [(self.ltar[j], self.rtar[j]) for j in range(tb + lo, tb + hi + 1) if self.ltar[j] != self.NA and self.rtar[j] != self.NA]
         if not back:
             return None
         if src0 + min(b[0] for b in back) != s or src0 + max(b[1] for b in back) != e:
@@ -324,10 +363,10 @@ def per_query_ids(nq, pairs):
 # ---- alignment helpers of the extension rules ------------------------------------------------------------------------
 def _back(c, ts, te, s_chk, e_chk, src0):
     """consistent() (ExtractPair.cu:103-133): the aligned target words of [ts,te] project onto exactly [s_chk,e_chk]"""
-    lo, hi = 255, 0
+    lo, hi = NOPOS, 0
     for j in range(ts, te + 1):
         l, r = int(c.ltar[j]), int(c.rtar[j])
-        if l != 255 and r != 255:
+        if l != c.NA and r != c.NA:
             lo = min(lo, l); hi = max(hi, r)
     return src0 + lo == s_chk and src0 + hi == e_chk
 
@@ -335,7 +374,7 @@ def _back(c, ts, te, s_chk, e_chk, src0):
 class _Side:
     """a gap growing one token at a time away from a phrase: running [min L, max R] of its aligned tokens"""
     def __init__(self):
-        self.lo, self.hi = 255, 0
+        self.lo, self.hi = NOPOS, 0
 
     def add(self, c, k):
         if not c.aligned(k):
@@ -350,7 +389,7 @@ def block_extension_rules(c, cs, m):
     ender = cs + m - 1
     src0, tb = c.sentence(cs)
     ab = True; open_abx = True; open_xab = True                # "NoSuccess" flags: the side has not emitted yet
-    mn, mx = 255, 0
+    mn, mx = NOPOS, 0
     for k in range(cs, ender + 1):                              # :1176-1212
         if not c.aligned(k):
             if k == cs or k == ender:

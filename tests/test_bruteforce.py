@@ -134,3 +134,45 @@ def test_hip_path_agrees_with_the_definitions(name, oracle_bin, fixtures_dir, tm
                           ex.fetch("hits1"), ex.fetch("s2"), ex.fetch("c2d"), ex.fetch("hits2"), ex.fetch("blocks"), ex.fetch("r0"), ex.fetch("r1"), k["sep1"], ex.fetch("r2"), k["sep2a"], k["sep2b"], max_patterns=limit, pick=pick)
     assert done > 100 and k["guard_exits"] == 0
     ex.close()
+
+
+def _text_corpus(d, fx):
+    return bf.Corpus.from_text(d["str"][:d["hdr"]["n"]], os.path.join(fx, "corpus.e"), os.path.join(fx, "corpus.a"))
+
+
+def test_alignment_built_from_the_text_equals_the_packed_words(oracle_bin, fixtures_dir, tmp_path):
+    """bf.Corpus.from_text reads the alignment file itself (plain integer positions); on corpora the reference accepts it must
+    give what the packed alignment words and byte tables of the loaders give -- L, R, P, the sentences' target offsets, ltar, rtar."""
+    for name in ("tiny", "toy"):
+        fx = make_fixture(name, fixtures_dir); dump = str(tmp_path / ("d_%s.bin" % name))
+        op.run_oracle(oracle_bin, fx, str(tmp_path / ("o_" + name)), dump)
+        d = op.read_dump(dump); n, nt = d["hdr"]["n"], d["hdr"]["nt"]
+        a = bf.Corpus(d["str"][:n], d["rlp"], d["ltar"], d["rtar"]); b = _text_corpus(d, fx)
+        words = np.nonzero(a.s[:n - 2] >= 2)[0]                  # without the two closing sentinels of the token array (Start.cu:300-312)
+        na = lambda x, c: np.where(np.asarray(x) == c.NA, -1, np.asarray(x))
+        assert (na(a.L[words], a) == na(b.L[words], b)).all() and (na(a.R[words], a) == na(b.R[words], b)).all() and (a.P[words] == b.P[words]).all()
+        assert all(a.sentence(int(k)) == b.sentence(int(k)) for k in words[::7])
+        m = min(len(a.ltar), len(b.ltar), nt)
+        la, ra = na(a.ltar[:m], a), na(a.rtar[:m], a); lb, rb = na(b.ltar[:m], b), na(b.rtar[:m], b)
+        un = (la < 0) | (ra < 0)                                # the byte tables mark a word as not aligned in either table
+        assert ((lb < 0) == un).all() and (la[~un] == lb[~un]).all() and (ra[~un] == rb[~un]).all()
+
+
+def test_long_sentence_mode_of_the_oracle_agrees_with_the_definitions(oracle_bin, fixtures_dir, tmp_path):
+    """SURVEY 8(f4), the opt-in mode for sentences of 255 tokens and more: the oracle run with --long-sentences on a corpus of
+    240..330-token sentence pairs against the definitions, with the alignment taken from the TEXT (plain integers: no byte
+    positions, no position codes) -- hit sets, frequent pairs, ab / aXb / aXbXc and the extension rules."""
+    import subprocess
+    from test_oracle import make_long_fixture
+    fx = make_long_fixture(fixtures_dir); dump = str(tmp_path / "d.bin"); out = tmp_path / "o"; out.mkdir()
+    subprocess.run([oracle_bin, "--long-sentences"] + op.fixture_args(fx) + [str(out), "--dump", dump], check=True, capture_output=True)
+    d = op.read_dump(dump); h = d["hdr"]
+    c = _text_corpus(d, fx)
+    assert int(c.P.max()) >= 255                                # the corpus really is beyond byte positions
+    p1d = d["p1"][d["s1"]["position"]]; c2d = d["p2"]["pat"][:, 0][d["s2"]["position"]]
+    pick = sorted(set(range(150)) | set(int(x) for x in np.random.default_rng(5).integers(0, max(h["d1"], 1), 600)))
+    done = bf.check_batch(c, d["sa"], d["freq"], _phits(d["pidx"], d["phits"]["start"], d["phits"]["length"]), d["s1"], p1d, d["hits1"],
+                          d["s2"], c2d, d["hits2"], d["blocks"], d["r0"], d["r1"], h["sep1"], d["r2"], h["sep2a"], h["sep2b"], max_patterns=150, pick=pick)
+    assert done > 100
+    hits_of = bf.hit_lists(d["s1"], d["hits1"], d["pidx"], d["phits"]["start"], d["phits"]["length"])
+    assert bf.check_extension_rules(c, d["sa"], d["blocks"], d["s1"], hits_of, d["r1"], h["sep1"], d["r2"], h["sep2a"], h["sep2b"]) > 1000
