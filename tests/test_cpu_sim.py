@@ -24,3 +24,33 @@ def test_writer_float_formatting_equals_printf(tmp_path):
                     "-Wl,--unresolved-symbols=ignore-all", "-o", exe], check=True)
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0 and "F6 OK" in r.stdout, r.stdout
+
+
+def test_window_transpose_algebra():
+    """load_window / cgx_win_load (cgx_search.inc, cgx_extract.inc): the eight lanes of a group fetch the group's eight windows
+    one after the other -- load j gives lane k piece k of window j -- and three butterfly stages (masks 4, 2, 1: a lane whose
+    bit is set sends r[j] and receives into r[j], the others send r[j | m] and receive into r[j | m]) must leave lane k with
+    piece p of ITS window in r[p].  The same stage rule, restated on an 8 x 8 array of labels; and the piece a backward walk can
+    reach: memory piece k is piece 7 - k counted from the driving phrase."""
+    r = [[(j, k) for k in range(8)] for j in range(8)]       # r[j][k] = (window, piece) held by lane k in register j
+    for m in (4, 2, 1):
+        new = [row[:] for row in r]
+        for j in range(8):
+            if j & m:
+                continue
+            for k in range(8):
+                up = bool(k & m)
+                send = lambda lane: r[j][lane] if (lane & m) else r[j | m][lane]        # what `lane` puts on the exchange
+                got = send(k ^ m)
+                if up:
+                    new[j][k] = got
+                else:
+                    new[j | m][k] = got
+        r = new
+    for k in range(8):
+        for p in range(8):
+            assert r[p][k] == (k, p), (k, p, r[p][k])
+    # backward window: memory entries base .. base + 15 with base = edge - 15; entry e of the walk is memory entry 15 - e, so
+    # memory piece k (entries 2k, 2k + 1) holds walk entries 15 - 2k, 14 - 2k = piece 7 - k of the walk
+    for k in range(8):
+        assert {(15 - 2 * k) // 2, (14 - 2 * k) // 2} == {7 - k}
