@@ -52,7 +52,7 @@ ABI = [
     "cgx_upload_queries", "cgx_sa_lookup", "cgx_gappy_search", "cgx_make_blocks", "cgx_set_blocks", "cgx_extract", "cgx_lexicon", "cgx_lex_features", "cgx_fetch",
     "cgx_stage_ms", "cgx_corpus_load", "cgx_corpus_free", "cgx_corpus_checksum", "cgx_corpus_save", "cgx_corpus_load_cache", "cgx_corpus_matches_sources", "cgx_corpus_upload", "cgx_extract_grammars", "cgx_extract_grammars_shard", "cgx_shard_bounds", "cgx_extract_grammars_ids",
     "cgx_corpus_from_ids", "cgx_host_ms", "cgx_flush", "cgx_fetch_pinned", "cgx_pinned_next_batch", "cgx_upload_vocab", "cgx_upload_score_tables", "cgx_set_query_blocks",
-    "cgx_format", "cgx_text_info", "cgx_text_segments", "cgx_text_segments_begin", "cgx_text_offsets", "cgx_text_read", "cgx_text_read_begin", "cgx_text_read_wait", "cgx_pinned_alloc", "cgx_pinned_free", "cgx_assemble_files", "cgx_corpus_load_opt",
+    "cgx_format", "cgx_text_info", "cgx_text_encoding", "cgx_assemble_files_enc", "cgx_text_segments", "cgx_text_segments_begin", "cgx_text_offsets", "cgx_text_read", "cgx_text_read_begin", "cgx_text_read_wait", "cgx_pinned_alloc", "cgx_pinned_free", "cgx_assemble_files", "cgx_corpus_load_opt",
 ]
 
 
@@ -329,6 +329,14 @@ class Extractor:
         finally:
             self.lib.cgx_pinned_free(buf)
         return text, qseg, so[:int(ns.value)], sl[:int(ns.value)], qtext
+
+    def text_encoding(self, slot):
+        """0: the slot holds plain text; 1: gzip members, one per emission group (option gz_level with gz_device)."""
+        self.lib.cgx_text_encoding.argtypes = [C.c_void_p, C.c_int]
+        rc = self.lib.cgx_text_encoding(self.h, slot)
+        if rc < 0:
+            self._chk(rc, "cgx_text_encoding")
+        return rc
 
     def fetch(self, name):
         nb = self.lib.cgx_fetch(self.h, name.encode(), None, 0)

@@ -44,7 +44,10 @@ struct cgx_ctx {
     int32_t *d_tokstart = nullptr; int8_t *d_tokrank = nullptr; int32_t *d_freq = nullptr;
     uint32_t *d_pidx = nullptr; int32_t *d_miss = nullptr; uint32_t *d_phit_start = nullptr; uint8_t *d_phit_len = nullptr;
     cgx_ngslot *d_ng[4] = {nullptr, nullptr, nullptr, nullptr}; uint32_t ng_cap[4] = {0, 0, 0, 0}; unsigned ng_shift[4] = {0, 0, 0, 0};   // l-gram (l = 2..5) -> SA interval
-    int gz_level = 0;                   // 1..9: grammar.<q>.s.gz through zlib instead of plain files
+    int gz_level = 0;                   // 1..9: grammar.<q>.s.gz instead of plain files
+    bool gz_device = true;              // with gz_level and the device formatter: the formatter emits the gzip members itself (cgx_fmt.h); 0 = the host's zlib at gz_level compresses the plain text
+    uint32_t *d_gztab = nullptr;        // CRC tables of the member trailers (GZ_TAB_WORDS words)
+    bool text_gz[2] = {false, false};   // what the text slot holds: gzip members / plain text
     bool occ_order = true;              // one-token driving phrases take their occurrences in corpus order (d_pos1) instead of suffix order (test / A-B hook)
     bool src_blocks = true;             // the lookups find a sentence's target-side bytes from its source start (d_lrs); 0 = through the delimiter's alignment word (test / A-B hook)
     bool use_layouts = true;            // test hook: 0 = window kernels read the plain str / rlp / ltar / rtar arrays (round-1 access pattern)

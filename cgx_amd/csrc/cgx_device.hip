@@ -463,7 +463,7 @@ extern "C" void cgx_destroy(cgx_ctx *c) {
     free_batch(c); free_index(c);
     for (int a = 0; a < 2; a++) if (c->arena[a]) { (void)hipHostFree(c->arena[a]); c->arena[a] = nullptr; }
     for (int a = 0; a < 2; a++) { dfree(c->d_text[a]); dfree(c->d_qtext[a]); dfree(c->d_seg_off[a]); dfree(c->d_seg_len[a]); dfree(c->d_qseg[a]); }
-    dfree(c->d_spool); dfree(c->d_soff); dfree(c->d_tpool); dfree(c->d_toff); dfree(c->d_aa); dfree(c->d_bb); dfree(c->d_fs);
+    dfree(c->d_spool); dfree(c->d_soff); dfree(c->d_tpool); dfree(c->d_toff); dfree(c->d_aa); dfree(c->d_bb); dfree(c->d_fs); dfree(c->d_gztab);
     if (c->sync_ev) (void)hipEventDestroy(c->sync_ev);
     for (int r = 0; r < CGX_COPY_STREAMS; r++) if (c->copy_streams[r]) (void)hipStreamDestroy(c->copy_streams[r]);
     for (int r = 0; r < CGX_MAX_READERS; r++) if (c->copy_done[r]) (void)hipEventDestroy(c->copy_done[r]);
@@ -482,6 +482,7 @@ extern "C" int cgx_set_option(cgx_ctx *c, const char *name, int64_t value) {
     if (!strcmp(name, "use_bigrams")) { c->ngram_max = value != 0 ? 5 : 1; return CGX_OK; }       /* round-1 name: 0 = every l >= 2 by binary search */
     if (!strcmp(name, "ngram_tables")) { if (value < 1 || value > 5) return CGX_ERR_ARG; c->ngram_max = (int)value; return CGX_OK; }
     if (!strcmp(name, "gz_level")) { if (value < 0 || value > 9) return CGX_ERR_ARG; c->gz_level = (int)value; return CGX_OK; }
+    if (!strcmp(name, "gz_device")) { c->gz_device = value != 0; return CGX_OK; }
     if (!strcmp(name, "use_layouts")) { c->use_layouts = value != 0; return CGX_OK; }
     if (!strcmp(name, "occ_order")) { c->occ_order = value != 0; return CGX_OK; }
     if (!strcmp(name, "src_blocks")) { c->src_blocks = value != 0; return CGX_OK; }
@@ -514,6 +515,7 @@ extern "C" int64_t cgx__option(cgx_ctx *c, const char *name) {
     if (!strcmp(name, "auto_batch_tokens")) return c->auto_batch_tokens;
     if (!strcmp(name, "numa_pin")) return (int64_t)c->numa_pin;
     if (!strcmp(name, "gz_level")) return (int64_t)c->gz_level;
+    if (!strcmp(name, "gz_device")) return (int64_t)c->gz_device;
     if (!strcmp(name, "write_period")) return c->write_period;
     if (!strcmp(name, "write_count")) return c->write_count;
     return 0;

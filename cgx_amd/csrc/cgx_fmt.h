@@ -1,0 +1,389 @@
+// cgx_fmt.h -- one grammar line as text, and the same line as DEFLATE symbols.
+//
+// Replaces the reference's fprintf loops (printGapMode / print_query_GPU_Gappy, PrintResults.c:339-577).  Everything here is
+// a pure function of read-only tables, marked CGX_HD so the same text compiles for gfx950 (hipcc) and, for the CPU unit test
+// under tests/cpu_sim only (gz_sim.cpp: the gzip members are inflated by zlib and compared with the plain text), for the host.
+// The product links only the device instantiation (cgx_format.inc).
+//
+// "%f": value * 10^6 is exact in double for a float input, rounded to nearest-even, printed as integer part '.' six digits --
+// bit-identical to glibc printf (tests/cpu_sim/f6test.c checks the same arithmetic on the host).  aa / bb / SampleCountF are
+// taken from tables computed by the host libm (they depend on two small integers only).
+#ifndef CGX_FMT_H
+#define CGX_FMT_H
+#include <stdint.h>
+#include <math.h>
+#include "../../include/cgx.h"
+#include "cgx_rules.h"
+
+#define FMT_TABN 302
+struct fmt_view {
+    const cgx_lexent *lex[3]; const int32_t *rng[3];           // [kind]: 0 contiguous, 1 one gap, 2 two gaps
+    const cgx_block *blocks; const cgx_gappat *p1d; const int32_t *c2d; const uint32_t *one2;
+    const int32_t *str, *tstr;
+    const char *spool, *tpool; const uint32_t *soff, *toff; uint32_t ns, nt;
+    const float *aa, *bb, *fs;                                  // host-libm tables [FMT_TABN*FMT_TABN], [FMT_TABN], [FMT_TABN]
+    uint32_t G, D1, D2;
+};
+// Two sinks run the same formatting routine: one counts, one writes.  The writing sink stores whole 8-byte words
+// wherever the text allows it (string literals, the ".dddddd" of a %f, word spellings): a line of ~200 characters
+// costs ~45 store requests instead of ~200 single-byte ones, and the byte stores were what bounded the kernel.
+// `wide(v, n)` stores the 8 bytes of v but advances only n <= 8: the surplus bytes land on positions this same lane
+// overwrites next (every such field is followed by at least 8 more characters of the same line), never on another
+// line.  Global memory accepts unaligned 8-byte stores on gfx950.
+typedef uint64_t __attribute__((aligned(1), may_alias)) u64_unaligned;
+struct CountSink {
+    uint32_t n;
+    CGX_HD void put(char) { n++; }
+    CGX_HD void puts(const char *, uint32_t len) { n += len; }
+    CGX_HD void wide(uint64_t, uint32_t len) { n += len; }
+    CGX_HD void word(const char *, uint32_t len) { n += len; }
+};
+struct MemSink {
+    char *p;
+    CGX_HD void put(char c) { *p++ = c; }
+    CGX_HD void puts(const char *s, uint32_t len) { for (uint32_t i = 0; i < len; i++) *p++ = s[i]; }
+    CGX_HD void wide(uint64_t v, uint32_t len) { *(u64_unaligned *)p = v; p += len; }
+    // a spelling from the padded word pool: 8 bytes at a time, the last chunk may carry bytes of the next pool entry
+    CGX_HD void word(const char *s, uint32_t len) {
+        uint32_t i = 0;
+        for (; i + 8 <= len; i += 8) *(u64_unaligned *)(p + i) = *(const u64_unaligned *)(s + i);
+        if (i < len) *(u64_unaligned *)(p + i) = *(const u64_unaligned *)(s + i);
+        p += len;
+    }
+};
+
+CGX_HD long long fmt_rn(double v) {                              // round to nearest, ties to even
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __double2ll_rn(v);
+#else
+    return llrint(v);
+#endif
+}
+// decimal digits, most significant first, without a per-thread digit buffer (a private array here is turned into
+// 252 bytes of LDS per thread by the compiler, which capped the kernel at two blocks per CU)
+template <class S> CGX_HD void fmt_uint(S &o, uint64_t v) {
+    uint64_t p = 1;
+    while (v / p >= 10) p *= 10;
+    for (; p; p /= 10) o.put((char)('0' + (int)((v / p) % 10)));
+}
+// A 32-bit number: the digit count from comparisons, the digits by constant divisions, least significant first, each put at
+// its place in one or two 8-byte words that leave as one or two insertions.  This is how a word WITHOUT a spelling is written
+// (its id after 's' / 't') -- every word of a corpus that was handed over as ids (cgx_extract_grammars_ids: the bench's corpora),
+// so it is no cold path there; fmt_uint spends two 64-bit divisions per digit on it.  (The kernel's time did not move with this:
+// 22.4 ms before and after -- DESIGN section 3 has the leave-one-out timings of the formatter.)
+template <class S> CGX_HD void fmt_u32(S &o, uint32_t v) {
+    const uint32_t n = 1u + (v >= 10u) + (v >= 100u) + (v >= 1000u) + (v >= 10000u) + (v >= 100000u) + (v >= 1000000u) + (v >= 10000000u) + (v >= 100000000u) + (v >= 1000000000u);
+    uint64_t w0 = 0, w1 = 0;
+    CGX_UNROLL
+    for (uint32_t k = 0; k < 10; k++) {
+        if (k < n) {
+            const uint64_t d = (uint64_t)('0' + v % 10u); v /= 10u;
+            const uint32_t at = n - 1u - k;                         // place counted from the most significant digit
+            if (at < 8u) w0 |= d << (8u * at); else w1 |= d << (8u * (at - 8u));
+        }
+    }
+    o.wide(w0, n < 8u ? n : 8u);
+    if (n > 8u) o.wide(w1, n - 8u);
+}
+template <class S> CGX_HD void fmt_word(S &o, const char *pool, const uint32_t *off, uint32_t nwords, char fallback, int32_t id) {
+    if (id >= 0 && (uint32_t)id < nwords) { uint32_t a = off[id], b = off[id + 1]; if (b > a) { o.word(pool + a, b - a); return; } }
+    o.put(fallback); if (id < 0) { o.put('-'); id = -id; } fmt_u32(o, (uint32_t)id);
+}
+template <class S> CGX_HD bool fmt_f6(S &o, float x) {
+    double v = (double)x;
+    if (!(fabs(v) < 9.0e12)) { o.put('?'); return false; }      // never produced by this path; reported so the host formats instead
+    if (signbit(v)) { o.put('-'); v = -v; }
+    unsigned long long m = (unsigned long long)fmt_rn(v * 1e6);
+    unsigned long long ip = m / 1000000ull; uint32_t fp = (uint32_t)(m % 1000000ull);
+    if (ip < 10) o.put((char)('0' + (int)ip)); else fmt_uint(o, ip);
+    uint64_t w = '.';                                           // ".dddddd" as one little-endian word (7 characters)
+    CGX_UNROLL
+    for (int i = 6; i >= 1; i--) { w |= (uint64_t)('0' + fp % 10) << (8 * i); fp /= 10; }
+    o.wide(w, 7);
+    return true;
+}
+// the number of characters fmt_f6 writes for x, without the divisions
+CGX_HD uint32_t fmt_f6_len(float x) {
+    double v = (double)x;
+    if (!(fabs(v) < 9.0e12)) return 1u;
+    uint32_t n = 8u;
+    if (signbit(v)) { n++; v = -v; }
+    const unsigned long long m = (unsigned long long)fmt_rn(v * 1e6);
+    for (unsigned long long t = 10000000ull; m >= t; t *= 10ull) n++;      // m < 9.1e18: t stays below 1e19
+    return n;
+}
+// a string literal: 8 bytes per store, the tail as one (overlapping) 8-byte store when the literal has >= 8 characters
+template <class S, uint32_t N> CGX_HD void fmt_lit(S &o, const char (&s)[N]) {
+    constexpr uint32_t n = N - 1;
+    if (n < 4) { for (uint32_t i = 0; i < n; i++) o.put(s[i]); return; }     // " ||| " is always followed by three more characters of its line
+    uint32_t i = 0;
+    CGX_UNROLL
+    for (; i + 8 <= n; i += 8) { uint64_t v = 0; for (int k = 0; k < 8; k++) v |= (uint64_t)(uint8_t)s[i + k] << (8 * k); o.wide(v, 8); }
+    if (i < n) { uint64_t v = 0; for (uint32_t k = 0; k < n - i; k++) v |= (uint64_t)(uint8_t)s[i + k] << (8 * k); o.wide(v, n - i); }
+}
+#define FMT_LIT(o, lit) fmt_lit(o, lit)
+template <class S> CGX_HD void fmt_gap(S &o, char d) {      // "[X,d]": never the end of a line
+    o.wide((uint64_t)'[' | ((uint64_t)'X' << 8) | ((uint64_t)',' << 16) | ((uint64_t)(uint8_t)d << 24) | ((uint64_t)']' << 32), 5);
+}
+template <class S> CGX_HD void fmt_block(S &o, const fmt_view &F, uint32_t bn) {
+    cgx_block k = F.blocks[bn];
+    for (int i = 0; i < k.matchlen; i++) { if (i) o.put(' '); fmt_word(o, F.spool, F.soff, F.ns, 's', F.str[k.string_start + i]); }
+}
+template <class S> CGX_HD void fmt_pattern(S &o, const fmt_view &F, uint32_t one, char gapdigit, bool lead_space) {
+    const cgx_gappat *p = &F.p1d[one];                          // read in place: a private copy indexed by j would be spilled to LDS (promoted alloca)
+    const int n = p->number;
+    for (int j = 0; j < n; j++) {
+        const int32_t sym = p->pat[j];
+        if (j || lead_space) o.put(' ');
+        if (sym >= 0) fmt_word(o, F.spool, F.soff, F.ns, 's', sym); else fmt_gap(o, gapdigit);
+    }
+}
+// source side from the converted id (ExtractPair.c:743-796, 1021-1123)
+template <class S> CGX_HD void fmt_source(S &o, const fmt_view &F, int kind, uint32_t cid) {
+    const uint32_t G = F.G, D1 = F.D1, D2 = F.D2;
+    if (kind == 0) { fmt_block(o, F, cid); return; }
+    if (kind == 1) {
+        if (cid < G) { fmt_gap(o, '1'); o.put(' '); fmt_block(o, F, cid); }
+        else if (cid < 2 * G) { fmt_block(o, F, cid - G); o.put(' '); fmt_gap(o, '1'); }
+        else fmt_pattern(o, F, cid - 2 * G, '1', false);
+        return;
+    }
+    if (cid < G) { fmt_gap(o, '1'); o.put(' '); fmt_block(o, F, cid); o.put(' '); fmt_gap(o, '2'); }
+    else if (cid < G + D2) { fmt_pattern(o, F, F.one2[cid - G], '1', false); o.put(' '); fmt_gap(o, '2'); o.put(' '); fmt_word(o, F.spool, F.soff, F.ns, 's', F.c2d[cid - G]); }
+    else if (cid < G + D2 + D1) { fmt_gap(o, '1'); fmt_pattern(o, F, cid - G - D2, '2', true); }
+    else { fmt_pattern(o, F, cid - G - D2 - D1, '1', false); o.put(' '); fmt_gap(o, '2'); }
+}
+// target side of a lexicon line (ExtractPair.c:813-837, 1141-1163)
+template <class S> CGX_HD void fmt_target(S &o, const fmt_view &F, int kind, const cgx_lexent &e) {
+    uint32_t t0 = e.tstart, t1 = t0 + e.end, ga = t0 + e.gap1, gb = t0 + e.gap1_1, gc = t0 + e.gap2, gd = t0 + e.gap2_1; bool first = true;
+    for (uint32_t jj = t0; jj <= t1; jj++) {
+        if (!first) o.put(' ');
+        first = false;
+        if (kind >= 1 && jj >= ga && jj <= gb) { fmt_gap(o, '1'); jj = gb; }
+        else if (kind >= 2 && jj >= gc && jj <= gd) { fmt_gap(o, '2'); jj = gd; }
+        else fmt_word(o, F.tpool, F.toff, F.nt, 't', F.tstr[jj]);
+    }
+}
+template <class S> CGX_HD bool fmt_line(S &o, const fmt_view &F, int kind, const cgx_lexent &e) {
+    bool ok = true;
+    FMT_LIT(o, "[X] ||| "); fmt_source(o, F, kind, (uint32_t)e.id); FMT_LIT(o, " ||| ");
+    fmt_target(o, F, kind, e);
+    if (e.paircount >= FMT_TABN || e.fsample >= FMT_TABN || e.fsample == 0) ok = false;
+    uint32_t pc = e.paircount < FMT_TABN ? e.paircount : 0, f = e.fsample < FMT_TABN ? e.fsample : 0;
+    FMT_LIT(o, " ||| EgivenFCoherent="); ok &= fmt_f6(o, F.aa[pc * FMT_TABN + f]);
+    FMT_LIT(o, " SampleCountF="); ok &= fmt_f6(o, F.fs[f]);
+    FMT_LIT(o, " CountEF="); ok &= fmt_f6(o, F.bb[pc]);
+    FMT_LIT(o, " MaxLexFgivenE="); ok &= fmt_f6(o, e.fe);
+    FMT_LIT(o, " MaxLexEgivenF="); ok &= fmt_f6(o, e.ef);
+    FMT_LIT(o, " IsSingletonF="); o.put(e.f == 1 ? '1' : '0');
+    FMT_LIT(o, " IsSingletonFE="); o.put(e.paircount == 1 ? '1' : '0'); o.put('\n');
+    return ok;
+}
+
+// ---- emission groups ----
+// Every (kind, converted id) belongs to exactly one CANONICAL item: the four items a block always emits together (4p .. 4p+3),
+// the three of a one-gap pattern (4G + 3id ..), the one of a two-gap pattern (4G + 3D1 + id), PrintResults.c:451-570.  The unique
+// text is laid out in canonical order, so the items a file emits back to back are neighbours in it and leave as one piece.
+CGX_HD void canon_item(uint32_t c, uint32_t G, uint32_t D1, uint32_t D2, int *kind, uint32_t *cid) {
+    if (c < 4 * G) { const uint32_t p = c >> 2; const int sub = (int)(c & 3); *kind = sub <= 1 ? 1 : sub == 2 ? 2 : 0; *cid = sub == 0 ? p + G : p; return; }
+    c -= 4 * G;
+    if (c < 3 * D1) { const uint32_t id = c / 3; const int sub = (int)(c % 3); *kind = sub == 0 ? 1 : 2; *cid = sub == 0 ? 2 * G + id : sub == 1 ? G + D2 + id : G + D2 + D1 + id; return; }
+    *kind = 2; *cid = G + (c - 3 * D1);
+}
+// group of canonical item c, and the first canonical item of group g (g = G + D1 + D2 gives the number of items)
+CGX_HD uint32_t canon_group(uint32_t c, uint32_t G, uint32_t D1) { if (c < 4 * G) return c >> 2; c -= 4 * G; return c < 3 * D1 ? G + c / 3 : G + D1 + (c - 3 * D1); }
+CGX_HD uint32_t canon_group_first(uint32_t g, uint32_t G, uint32_t D1) { if (g < G) return 4 * g; g -= G; return g < D1 ? 4 * G + 3 * g : 4 * G + 3 * D1 + (g - D1); }
+
+// =====================================================================================================================
+// The same line as DEFLATE symbols: grammar.<q>.s.gz without a compressor.
+//
+// SURVEY 8(f3) asks for optional gz output because at eight GPUs file I/O bounds the path; the reference writes one fprintf
+// per rule (PrintResults.c:407-577).  A general compressor searches for repetitions; the formatter KNOWS them: a line repeats
+// its predecessor's "[X] ||| source ||| ", every feature name, and most feature values.  So the formatter emits the symbols
+// itself -- back-references (length, distance) where it knows the bytes stood one line earlier, literals elsewhere, the fixed
+// Huffman code of RFC 1951 3.2.6 -- and no hash chains, no window, no second look at the text are needed.
+//
+//  * One gzip MEMBER (RFC 1952) per emission group (the four items of a contiguous phrase, the three of a one-gap pattern,
+//    the one of a two-gap pattern): a grammar file is a series of whole groups, RFC 1952 2.2 allows a file to be a series of
+//    members, so a file stays a concatenation of pieces of the batch's unique text and phrases shared by thousands of
+//    queries are still formatted, compressed and sent once.  Members do not see each other: a back-reference never leaves
+//    its group.
+//  * Every line is one fixed-Huffman block followed by an empty stored block (the "sync flush" of zlib): the stored block's
+//    header pads to a byte boundary, so lines begin on bytes and the byte-offset machinery of the plain text (count -> scan ->
+//    write, one lane per line) serves unchanged.  It costs 5-6 bytes per line; a bit-granular layout would save them.
+//  * CRC-32 of a member: every line computes the CRC of its own text (byte-wise, 1 KB table in LDS) and multiplies it by
+//    x^(8 * bytes that follow it in the member) mod P (zlib's crc32_combine as a product of table entries); the member's CRC
+//    is the XOR of its lines' contributions, folded and written with ISIZE by k_gz_trailers.
+// What a line may refer to: its predecessor in the same group (prefix through the source side when both lines belong to the
+// same item, "[X] ||| " otherwise; the tail from " ||| EgivenFCoherent=" on, name by name, a value only when it equals the
+// predecessor's), and itself (" ||| " and, in a group's first line, " IsSingletonF" / " MaxLex").  Target words are literals.
+// =====================================================================================================================
+CGX_HD uint32_t gz_brev(uint32_t x, uint32_t nbits) {            // the low nbits of x, reversed (Huffman codes are packed starting with their most significant bit)
+#if defined(__clang__)
+    return __builtin_bitreverse32(x) >> (32u - nbits);
+#else
+    uint32_t r = 0; for (uint32_t i = 0; i < nbits; i++) r |= ((x >> i) & 1u) << (nbits - 1u - i); return r;
+#endif
+}
+CGX_HD uint32_t gz_log2(uint32_t x) { return 31u - (uint32_t)__builtin_clz(x); }   // x > 0
+
+// bit sinks: the counting pass only adds, the writing pass packs LSB-first and hands whole 32-bit words to a byte sink
+struct BitCount {
+    uint32_t n;
+    CGX_HD void bits(uint32_t, uint32_t len) { n += len; }
+    CGX_HD void align() { n = (n + 7u) & ~7u; }
+    CGX_HD uint32_t bytes() const { return n >> 3; }             // after align()
+    CGX_HD void finish() {}
+};
+template <class S> struct BitOut {
+    S &o; uint64_t acc; uint32_t nb, n;
+    CGX_HD explicit BitOut(S &s) : o(s), acc(0), nb(0), n(0) {}
+    CGX_HD void bits(uint32_t code, uint32_t len) {              // len <= 16, code < 2^len
+        acc |= (uint64_t)code << nb; nb += len; n += len;
+        if (nb >= 32u) { o.wide(acc & 0xFFFFFFFFull, 4); acc >>= 32; nb -= 32u; }
+    }
+    CGX_HD void align() { const uint32_t pad = (8u - (nb & 7u)) & 7u; bits(0, pad); }
+    CGX_HD uint32_t bytes() const { return n >> 3; }
+    CGX_HD void finish() { if (nb) { o.wide(acc, nb >> 3); acc = 0; nb = 0; } }   // after align(): whole bytes only (at most 3)
+};
+
+#define GZ_POLY 0xEDB88320u
+// a(x) * b(x) mod P in the reflected representation (x^0 = 0x80000000), as zlib's multmodp
+CGX_HD uint32_t gz_multmodp(uint32_t a, uint32_t b) {
+    uint32_t m = 1u << 31, p = 0;
+    for (;;) {
+        if (a & m) { p ^= b; if ((a & (m - 1u)) == 0) break; }
+        m >>= 1;
+        b = (b & 1u) ? (b >> 1) ^ GZ_POLY : b >> 1;
+    }
+    return p;
+}
+// tables, 5 x 256 words: [0] the byte-wise CRC table; [1 + j][d] = x^(8 * d * 256^j) mod P, j = 0..3
+#define GZ_TAB_WORDS (5 * 256)
+CGX_HD uint32_t gz_x8n(const uint32_t *tab, uint64_t nbytes) {   // x^(8 * nbytes) mod P, nbytes < 2^32
+    uint32_t r = tab[256 + (nbytes & 255u)];
+    CGX_UNROLL
+    for (int j = 1; j < 4; j++) { const uint32_t d = (uint32_t)(nbytes >> (8 * j)) & 255u; if (d) r = gz_multmodp(tab[256 * (j + 1) + d], r); }
+    return r;
+}
+inline void gz_make_tables(uint32_t *tab) {                      // host only
+    for (uint32_t i = 0; i < 256; i++) { uint32_t c = i; for (int k = 0; k < 8; k++) c = (c & 1u) ? (c >> 1) ^ GZ_POLY : c >> 1; tab[i] = c; }
+    uint32_t x8 = 0x80000000u; for (int k = 0; k < 8; k++) x8 = (x8 & 1u) ? (x8 >> 1) ^ GZ_POLY : x8 >> 1;    // x^8
+    uint32_t step = x8;
+    for (int j = 0; j < 4; j++) {
+        uint32_t *t = tab + 256 * (j + 1); t[0] = 0x80000000u;
+        for (uint32_t d = 1; d < 256; d++) t[d] = gz_multmodp(t[d - 1], step);
+        step = gz_multmodp(t[255], step);                        // x^(8 * 256^(j+1))
+    }
+}
+
+// The deflate sink: the interface of the byte sinks above, plus match() / lit() to say what the bytes that follow are.
+template <class B, bool CRC> struct GzSink {
+    B &b; const uint32_t *tab;
+    uint32_t pos, mlen, mdist, crc; bool inm, bad;
+    CGX_HD GzSink(B &bits, const uint32_t *crc_table) : b(bits), tab(crc_table), pos(0), mlen(0), mdist(0), crc(0xFFFFFFFFu), inm(false), bad(false) {}
+    CGX_HD void emit_match(uint32_t len, uint32_t dist) {        // 3 <= len <= 257, 1 <= dist <= 32768
+        const uint32_t l = len - 3u; uint32_t sym, eb = 0;
+        if (l < 8u) sym = 257u + l; else { eb = gz_log2(l) - 2u; sym = 261u + 4u * eb + ((l >> eb) & 3u); }
+        if (sym < 280u) b.bits(gz_brev(sym - 256u, 7), 7); else b.bits(gz_brev(0xC0u + (sym - 280u), 8), 8);
+        if (eb) b.bits(l & ((1u << eb) - 1u), eb);
+        const uint32_t dd = dist - 1u; uint32_t dc, deb = 0;
+        if (dd < 4u) dc = dd; else { const uint32_t k = gz_log2(dd); deb = k - 1u; dc = 2u * k + ((dd >> deb) & 1u); }
+        b.bits(gz_brev(dc, 5), 5);
+        if (deb) b.bits(dd & ((1u << deb) - 1u), deb);
+    }
+    CGX_HD void flush() { if (mlen) { if (mlen < 3u) bad = true; else emit_match(mlen, mdist); mlen = 0; } }
+    // the bytes that follow stood `dist` bytes earlier in this member / are new
+    CGX_HD void match(uint32_t dist) { if (inm && dist == mdist) return; flush(); inm = dist >= 1u && dist <= 32768u; mdist = dist; }
+    CGX_HD void lit() { flush(); inm = false; }
+    CGX_HD void feed(uint64_t v, uint32_t n) {                   // the low n <= 8 bytes of v
+        pos += n;
+        if (CRC) { uint64_t w = v; for (uint32_t i = 0; i < n; i++) { crc = tab[(crc ^ (uint32_t)w) & 255u] ^ (crc >> 8); w >>= 8; } }
+        if (inm) { mlen += n; if (mlen >= 258u) { emit_match(255u, mdist); mlen -= 255u; } }      // what stays pending is again >= 3
+        else for (uint32_t i = 0; i < n; i++) { const uint32_t c = (uint32_t)(v >> (8u * i)) & 255u; if (c < 144u) b.bits(gz_brev(0x30u + c, 8), 8); else b.bits(gz_brev(0x100u + c, 9), 9); }
+    }
+    CGX_HD void put(char c) { feed((uint64_t)(uint8_t)c, 1); }
+    CGX_HD void puts(const char *s, uint32_t len) { for (uint32_t i = 0; i < len; i++) put(s[i]); }
+    CGX_HD void wide(uint64_t v, uint32_t len) { feed(v, len); }
+    CGX_HD void word(const char *s, uint32_t len) {
+        for (uint32_t i = 0; i < len; i += 8) { const uint32_t n = len - i < 8 ? len - i : 8; feed(*(const u64_unaligned *)(s + i), n); }
+    }
+};
+
+// what a line knows about its place in its member
+struct gz_place {
+    bool first, last;        // first / last line of its emission group
+    bool same_item;          // the line before it belongs to the same canonical item: same source side
+    uint32_t prev_len;       // characters of the line before it (first == false)
+    float pv[5]; bool pf1, pf2;   // that line's five feature values and two flags
+};
+CGX_HD void gz_place_prev(gz_place &P, const fmt_view &F, const cgx_lexent &pe) {
+    const uint32_t pc = pe.paircount < FMT_TABN ? pe.paircount : 0, f = pe.fsample < FMT_TABN ? pe.fsample : 0;
+    P.pv[0] = F.aa[pc * FMT_TABN + f]; P.pv[1] = F.fs[f]; P.pv[2] = F.bb[pc]; P.pv[3] = pe.fe; P.pv[4] = pe.ef;
+    P.pf1 = pe.f == 1; P.pf2 = pe.paircount == 1;
+}
+CGX_HD bool gz_same_bits(float a, float b) { union { float f; uint32_t u; } x, y; x.f = a; y.f = b; return x.u == y.u; }
+#define GZ_MIN_LINE 16u      // the byte sink of the writing kernel needs every line to reach past its first 16-byte unit
+// One line of a member.  Returns false when the line cannot be represented (the batch is then formatted on the host).
+// Bytes: [gzip header, first line only] fixed block { symbols, end of block } empty stored block(s) [8 bytes for CRC-32 and ISIZE, last line only]
+template <class B, bool CRC> CGX_HD bool fmt_line_gz(B &b, GzSink<B, CRC> &z, const fmt_view &F, int kind, const cgx_lexent &e, const gz_place &P) {
+    bool ok = true;
+    if (P.first) { b.bits(0x8B1Fu, 16); b.bits(8u, 8); b.bits(0, 8); b.bits(0, 16); b.bits(0, 16); b.bits(0, 8); b.bits(3u, 8); }   // ID1 ID2 CM FLG MTIME XFL OS (RFC 1952 2.3)
+    b.bits(2u, 3);                                               // BFINAL = 0, BTYPE = 01 (fixed Huffman codes)
+    const bool prev = !P.first;
+    if (prev && P.same_item) { z.match(P.prev_len); FMT_LIT(z, "[X] ||| "); fmt_source(z, F, kind, (uint32_t)e.id); FMT_LIT(z, " ||| "); }
+    else {
+        if (prev) z.match(P.prev_len); else z.lit();
+        FMT_LIT(z, "[X] ||| "); z.lit(); fmt_source(z, F, kind, (uint32_t)e.id);
+        z.match(z.pos - 3u); FMT_LIT(z, " ||| ");                // the " ||| " of this line's own "[X] ||| "
+    }
+    z.lit(); fmt_target(z, F, kind, e);
+    if (e.paircount >= FMT_TABN || e.fsample >= FMT_TABN || e.fsample == 0) ok = false;
+    const uint32_t pc = e.paircount < FMT_TABN ? e.paircount : 0, f = e.fsample < FMT_TABN ? e.fsample : 0;
+    const float v0 = F.aa[pc * FMT_TABN + f], v1 = F.fs[f], v2 = F.bb[pc];
+    const bool f1 = e.f == 1, f2 = e.paircount == 1;
+    if (prev) {
+        // rem = characters of the previous line from the point that corresponds to this one: the distance is pos + rem
+        const uint32_t l0 = fmt_f6_len(P.pv[0]), l1 = fmt_f6_len(P.pv[1]), l2 = fmt_f6_len(P.pv[2]), l3 = fmt_f6_len(P.pv[3]), l4 = fmt_f6_len(P.pv[4]);
+        uint32_t rem = 106u + l0 + l1 + l2 + l3 + l4;
+        z.match(z.pos + rem); FMT_LIT(z, " ||| EgivenFCoherent="); rem -= 21u;
+        if (!gz_same_bits(v0, P.pv[0])) z.lit(); ok &= fmt_f6(z, v0); rem -= l0;
+        z.match(z.pos + rem); FMT_LIT(z, " SampleCountF="); rem -= 14u;
+        if (!gz_same_bits(v1, P.pv[1])) z.lit(); ok &= fmt_f6(z, v1); rem -= l1;
+        z.match(z.pos + rem); FMT_LIT(z, " CountEF="); rem -= 9u;
+        if (!gz_same_bits(v2, P.pv[2])) z.lit(); ok &= fmt_f6(z, v2); rem -= l2;
+        z.match(z.pos + rem); FMT_LIT(z, " MaxLexFgivenE="); rem -= 15u;
+        if (!gz_same_bits(e.fe, P.pv[3])) z.lit(); ok &= fmt_f6(z, e.fe); rem -= l3;
+        z.match(z.pos + rem); FMT_LIT(z, " MaxLexEgivenF="); rem -= 15u;
+        if (!gz_same_bits(e.ef, P.pv[4])) z.lit(); ok &= fmt_f6(z, e.ef); rem -= l4;
+        z.match(z.pos + rem); FMT_LIT(z, " IsSingletonF="); rem -= 14u;
+        if (f1 != P.pf1) z.lit(); z.put(f1 ? '1' : '0'); rem -= 1u;
+        z.match(z.pos + rem); FMT_LIT(z, " IsSingletonFE=");
+        if (f2 != P.pf2) z.lit(); z.put(f2 ? '1' : '0'); z.put('\n');    // the line feed alone would be a match of one character: it goes the way of the flag
+    } else {
+        z.match(z.pos - 3u); FMT_LIT(z, " ||| "); z.lit(); FMT_LIT(z, "EgivenFCoherent="); ok &= fmt_f6(z, v0);
+        FMT_LIT(z, " SampleCountF="); ok &= fmt_f6(z, v1);
+        FMT_LIT(z, " CountEF="); ok &= fmt_f6(z, v2);
+        FMT_LIT(z, " MaxLexFgivenE="); const uint32_t at = z.pos; ok &= fmt_f6(z, e.fe);
+        z.match(z.pos - at + 15u); FMT_LIT(z, " MaxLex"); z.lit(); FMT_LIT(z, "EgivenF="); ok &= fmt_f6(z, e.ef);
+        FMT_LIT(z, " IsSingletonF="); z.put(f1 ? '1' : '0');
+        z.match(15u); FMT_LIT(z, " IsSingletonF"); z.lit(); z.put('E'); z.put('='); z.put(f2 ? '1' : '0'); z.put('\n');
+    }
+    z.lit();
+    if (z.bad) ok = false;
+    b.bits(0, 7);                                                // end of block (symbol 256)
+    // An empty stored block (BTYPE = 00, LEN = 0, NLEN = ~0) pads to a byte boundary; the last line's closes the deflate stream
+    // (BFINAL = 1).  A line that would stay below GZ_MIN_LINE bytes (one that repeats its predecessor almost entirely) takes
+    // more of them: an open one to reach the boundary, 5-byte ones to fill, and the closing one.
+    const uint32_t trailer = P.last ? 8u : 0u, fin = P.last ? 1u : 0u;
+    if (((b.n + 3u + 7u) >> 3) + 4u + trailer >= GZ_MIN_LINE) { b.bits(fin, 3); b.align(); b.bits(0, 16); b.bits(0xFFFFu, 16); }
+    else {
+        b.bits(0, 3); b.align(); b.bits(0, 16); b.bits(0xFFFFu, 16);
+        while (b.bytes() + 5u + trailer < GZ_MIN_LINE) { b.bits(0, 8); b.bits(0, 16); b.bits(0xFFFFu, 16); }
+        b.bits(fin, 8); b.bits(0, 16); b.bits(0xFFFFu, 16);
+    }
+    if (P.last) { b.bits(0, 16); b.bits(0, 16); b.bits(0, 16); b.bits(0, 16); }   // CRC-32 and ISIZE: filled in by k_gz_trailers
+    b.finish();
+    return ok;
+}
+#endif

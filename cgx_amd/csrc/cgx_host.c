@@ -1190,6 +1190,7 @@ typedef struct pending {
     batch *b;                                              /* host-formatter path: the batch whose lexicon the threads format */
     int dev, slot, hb; int32_t nq, first; char *outdir;
     uint64_t ubytes, nseg, fbytes, lines; double ms, wait_ms, file_ms;
+    int gz, members; int64_t period, count;                 /* the options as they were when the batch was submitted (the writer thread runs later, beside the next batch) */
 } pending;
 static wstate *get_wstate(cgx_ctx *ctx) {
     wstate *ws = cgx__get_host_state(ctx);
@@ -1228,7 +1229,7 @@ static void pin_to_device_node(cgx_ctx *ctx) {
 typedef struct {
     cgx_ctx *ctx; int tid, rc; int32_t nq, first; const char *outdir; int32_t *next_q;
     const char *utext; const uint64_t *qseg, *seg_off; const uint32_t *seg_len;
-    double file_ms; uint64_t calls; int gz; int64_t period, count;
+    double file_ms; uint64_t calls; int gz, members; int64_t period, count;     /* gz: host zlib level for plain text; members: the text already is gzip members */
 } devjob;
 /* optional gzip output (option "gz_level" 1..9): grammar.<q>.s.gz, the same bytes through zlib's deflate */
 static int write_one_file_gz(devjob *w, int32_t q) {
@@ -1242,15 +1243,18 @@ static int write_one_file_gz(devjob *w, int32_t q) {
     if (gzclose(f) != Z_OK) bad = 1;
     return bad ? CGX_ERR_IO : CGX_OK;
 }
+/* a gzip member that holds nothing (what gzclose writes for a file without rules): header, an empty final block, CRC-32 0, ISIZE 0 */
+static const unsigned char GZ_EMPTY_MEMBER[20] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 3, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 static int write_one_file(devjob *w, int32_t q, struct iovec *iov) {
-    if (w->gz) return write_one_file_gz(w, q);
+    if (w->gz && !w->members) return write_one_file_gz(w, q);
     char fn[4096];
-    snprintf(fn, sizeof fn, "%s/grammar.%d.s", w->outdir, w->first + q);
+    snprintf(fn, sizeof fn, w->members ? "%s/grammar.%d.s.gz" : "%s/grammar.%d.s", w->outdir, w->first + q);
     const uint64_t s0 = w->qseg[q], s1 = w->qseg[q + 1];
     /* overwrite in place and cut to length: same bytes as fopen(fn,"w"), but an existing file keeps its pages */
     int fd = open(fn, s0 == s1 ? O_WRONLY | O_CREAT | O_TRUNC : O_WRONLY | O_CREAT, 0644);
     if (fd < 0) return CGX_ERR_IO;
     int bad = 0; uint64_t pos = 0;
+    if (w->members && s0 == s1 && write(fd, GZ_EMPTY_MEMBER, sizeof GZ_EMPTY_MEMBER) != (ssize_t)sizeof GZ_EMPTY_MEMBER) bad = 1;
     for (uint64_t s = s0; s < s1 && !bad;) {
         int n = 0; uint64_t want = 0;
         for (; s < s1 && n < IOV_MAX; s++, n++) { iov[n].iov_base = (void *)(w->utext + w->seg_off[s]); iov[n].iov_len = w->seg_len[s]; want += w->seg_len[s]; }
@@ -1307,7 +1311,7 @@ static int dev_write_files(pending *pw) {
     cgx__set_host_ms(ctx, "writer_threads", nt);             /* reported beside the timings (bench.py) */
     devjob jobs[MAX_WRITERS]; pthread_t th[MAX_WRITERS]; int started[MAX_WRITERS]; int32_t next = 0; int rc = CGX_OK;
     for (int t = 0; t < nt; t++) { memset(&jobs[t], 0, sizeof jobs[t]); jobs[t].ctx = ctx; jobs[t].tid = t; jobs[t].nq = nq; jobs[t].first = pw->first; jobs[t].outdir = pw->outdir; jobs[t].next_q = &next;
-                                   jobs[t].utext = hb->utext; jobs[t].qseg = hb->qseg; jobs[t].seg_off = hb->segoff; jobs[t].seg_len = hb->seglen; jobs[t].rc = CGX_OK; jobs[t].gz = (int)cgx__option(ctx, "gz_level"); jobs[t].period = cgx__option(ctx, "write_period"); jobs[t].count = cgx__option(ctx, "write_count"); }
+                                   jobs[t].utext = hb->utext; jobs[t].qseg = hb->qseg; jobs[t].seg_off = hb->segoff; jobs[t].seg_len = hb->seglen; jobs[t].rc = CGX_OK; jobs[t].gz = pw->gz; jobs[t].members = pw->members; jobs[t].period = pw->period; jobs[t].count = pw->count; }
     started[0] = 1;
     for (int t = 1; t < nt; t++) started[t] = !pthread_create(&th[t], NULL, dev_write_worker, &jobs[t]);   /* a thread that cannot start: the others take its share */
     dev_write_worker(&jobs[0]);
@@ -1327,11 +1331,15 @@ static int dev_write_files(pending *pw) {
  * replays one recorded batch from several processes at once to measure what one host can write. */
 int cgx_assemble_files(const char *utext, const uint64_t *qseg, const uint64_t *seg_off, const uint32_t *seg_len, int32_t nq, int32_t first,
                        const char *outdir, int nthreads, double *file_ms) {
-    if (!utext || !qseg || !seg_off || !seg_len || nq < 0 || !outdir) return CGX_ERR_ARG;
+    return cgx_assemble_files_enc(utext, qseg, seg_off, seg_len, nq, first, outdir, nthreads, file_ms, CGX_TEXT_PLAIN);
+}
+int cgx_assemble_files_enc(const char *utext, const uint64_t *qseg, const uint64_t *seg_off, const uint32_t *seg_len, int32_t nq, int32_t first,
+                           const char *outdir, int nthreads, double *file_ms, int encoding) {
+    if (!utext || !qseg || !seg_off || !seg_len || nq < 0 || !outdir || (encoding != CGX_TEXT_PLAIN && encoding != CGX_TEXT_GZIP_MEMBERS)) return CGX_ERR_ARG;
     int nt = nthreads < 1 ? 1 : nthreads > MAX_WRITERS ? MAX_WRITERS : nthreads; if (nt > nq) nt = nq > 0 ? nq : 1;
     devjob jobs[MAX_WRITERS]; pthread_t th[MAX_WRITERS]; int started[MAX_WRITERS]; int32_t next = 0; int rc = CGX_OK;
     for (int t = 0; t < nt; t++) { memset(&jobs[t], 0, sizeof jobs[t]); jobs[t].tid = t; jobs[t].nq = nq; jobs[t].first = first; jobs[t].outdir = outdir; jobs[t].next_q = &next;
-                                   jobs[t].utext = utext; jobs[t].qseg = qseg; jobs[t].seg_off = seg_off; jobs[t].seg_len = seg_len; jobs[t].rc = CGX_OK; }
+                                   jobs[t].utext = utext; jobs[t].qseg = qseg; jobs[t].seg_off = seg_off; jobs[t].seg_len = seg_len; jobs[t].rc = CGX_OK; jobs[t].members = encoding == CGX_TEXT_GZIP_MEMBERS; }
     started[0] = 1;
     for (int t = 1; t < nt; t++) started[t] = !pthread_create(&th[t], NULL, dev_write_worker, &jobs[t]);
     dev_write_worker(&jobs[0]);
@@ -1391,6 +1399,8 @@ static int submit_output(cgx_ctx *ctx, batch *b, int dev, int slot, int32_t nq, 
     if (!pw) return CGX_ERR_NOMEM;
     pw->ws = ws; pw->ctx = ctx; pw->b = b; pw->dev = dev; pw->slot = slot; pw->nq = nq; pw->first = first; pw->outdir = strdup(outdir);
     pw->hb = ws->n && ws->inflight[0]->hb == 0 ? 1 : 0;      /* the buffer set the batch still in flight does not use */
+    pw->gz = b ? b->gz_level : (int)cgx__option(ctx, "gz_level"); pw->period = b ? b->write_period : cgx__option(ctx, "write_period"); pw->count = b ? b->write_count : cgx__option(ctx, "write_count");
+    pw->members = dev && cgx_text_encoding(ctx, slot) == CGX_TEXT_GZIP_MEMBERS;
     if (!pw->outdir) { free(pw); return CGX_ERR_NOMEM; }
     if (dev && (rc = dev_copy_begin(pw)) != CGX_OK) {         /* copies already enqueued target buffers that stay allocated: drain them */
         for (int r = 0; r < READERS_PER_SLOT; r++) (void)cgx_text_read_wait(ctx, slot * READERS_PER_SLOT + r);

@@ -78,7 +78,7 @@ typedef struct {
 cgx_ctx *cgx_create(int device);                       /* replaces suffixArraySearchInit (SuffixArray.cu:769) */
 void cgx_destroy(cgx_ctx *ctx);                        /* replaces suffixArraySearchFinalize*, extractPairFinalize */
 const char *cgx_last_error(cgx_ctx *ctx);
-int cgx_set_option(cgx_ctx *ctx, const char *name, int64_t value); /* "k1_limit" (default 128), "chunk_items", "force_host_lexicon", "async_write", "prealloc_text" (default 0; 1 = a caller that will submit several batches with async_write asks for both text buffers to be allocated at the first one), "use_bigrams" (default 1), "use_lex_hash" (default 1), "device_format" (default 1), "sub_batch" (queries per internal batch of cgx_extract_grammars*; 0 = automatic: at most "auto_batch_tokens" (default 300000) query tokens per internal batch; with async_write the writer of one sub-batch overlaps the GPU work of the next), "write_period" / "write_count" (with a period P > 0 only the files of queries g with g % P < count are written, g = index in the whole query list; rules are counted for all, and an internal batch without such a query lays out no text: full-count runs that sample their output), "src_blocks" (default 1; 0 = the lookups locate a sentence's target-side alignment bytes through the delimiter's alignment word instead of the source-addressed copy of the blocks: A/B and test hook), "wide_hits2", "look_rec_cap", "pool_cap", "fault_inject", "append_slack", "append_guess_milli" (test hooks for the lookup output sizing) */
+int cgx_set_option(cgx_ctx *ctx, const char *name, int64_t value); /* "k1_limit" (default 128), "chunk_items", "force_host_lexicon", "async_write", "prealloc_text" (default 0; 1 = a caller that will submit several batches with async_write asks for both text buffers to be allocated at the first one), "use_bigrams" (default 1), "use_lex_hash" (default 1), "device_format" (default 1), "gz_level" (0 = plain grammar.<q>.s; 1..9 = grammar.<q>.s.gz) and "gz_device" (default 1: with the device formatter the gzip members are produced on the GPU and gz_level only switches them on; 0 = the host's zlib compresses the plain text at gz_level), "sub_batch" (queries per internal batch of cgx_extract_grammars*; 0 = automatic: at most "auto_batch_tokens" (default 300000) query tokens per internal batch; with async_write the writer of one sub-batch overlaps the GPU work of the next), "write_period" / "write_count" (with a period P > 0 only the files of queries g with g % P < count are written, g = index in the whole query list; rules are counted for all, and an internal batch without such a query lays out no text: full-count runs that sample their output), "src_blocks" (default 1; 0 = the lookups locate a sentence's target-side alignment bytes through the delimiter's alignment word instead of the source-addressed copy of the blocks: A/B and test hook), "wide_hits2", "look_rec_cap", "pool_cap", "fault_inject", "append_slack", "append_guess_milli" (test hooks for the lookup output sizing) */
 
 /* ---- index: upload, device suffix-array construction, frequent-pair precomputation ---- */
 int cgx_upload_index(cgx_ctx *ctx, const cgx_index_host *ix);   /* H2D of the index (SuffixArray.cu:1396-1412, ExtractPair.cu:3279-3282) */
@@ -123,6 +123,13 @@ int cgx_format(cgx_ctx *ctx, uint64_t *total_bytes, uint64_t *total_lines, int *
  * pieces of it: piece s = bytes [seg_off[s], seg_off[s] + seg_len[s]) of the unique text; the file of query q is the concatenation of
  * pieces qseg[q] .. qseg[q+1]-1 in that order (PrintResults.c:451-570 emission order) and is qtext[q+1] - qtext[q] bytes long. */
 int cgx_text_info(cgx_ctx *ctx, int slot, uint64_t *unique_bytes, uint64_t *nseg, uint64_t *file_bytes);
+/* With option "gz_level" > 0 (and "gz_device", default 1) the slot holds the same text as GZIP MEMBERS (RFC 1952) made by the formatter itself,
+ * one member per emission group, so a file is still the concatenation of its pieces: grammar.<q>.s.gz is a series of members that
+ * zcat / gzread / Python's gzip read as the plain file (the reference writes one fprintf per rule, PrintResults.c:407-577).
+ * Offsets, lengths and sizes above are then compressed bytes.  Returns CGX_TEXT_PLAIN or CGX_TEXT_GZIP_MEMBERS, or < 0. */
+#define CGX_TEXT_PLAIN 0
+#define CGX_TEXT_GZIP_MEMBERS 1
+int cgx_text_encoding(cgx_ctx *ctx, int slot);
 int cgx_text_segments(cgx_ctx *ctx, int slot, uint64_t *qseg /* nq+1 */, uint64_t *seg_off /* nseg */, uint32_t *seg_len /* nseg */);
 int cgx_text_segments_begin(cgx_ctx *ctx, int slot, uint64_t *qseg, uint64_t *seg_off, uint32_t *seg_len, int reader); /* the same copies, only enqueued on side stream `reader`; cgx_text_read_wait(reader) waits for them */
 int cgx_text_offsets(cgx_ctx *ctx, int slot, uint64_t *qtext);                       /* nq+1 cumulative file sizes: file q has qtext[q+1] - qtext[q] bytes */
@@ -134,6 +141,9 @@ int cgx_text_read_wait(cgx_ctx *ctx, int reader);                               
  * (no GPU, no context needed; what the writer of cgx_extract_grammars* runs after the DMA).  *file_ms = mean busy time per thread */
 int cgx_assemble_files(const char *utext, const uint64_t *qseg, const uint64_t *seg_off, const uint32_t *seg_len, int32_t nq, int32_t first,
                        const char *outdir, int nthreads, double *file_ms);
+/* the same with the encoding of the text (cgx_text_encoding): gzip members are written as grammar.<first+q>.s.gz, a query without rules as one empty member */
+int cgx_assemble_files_enc(const char *utext, const uint64_t *qseg, const uint64_t *seg_off, const uint32_t *seg_len, int32_t nq, int32_t first,
+                           const char *outdir, int nthreads, double *file_ms, int encoding);
 void *cgx_pinned_alloc(size_t bytes);
 void cgx_pinned_free(void *p);
 

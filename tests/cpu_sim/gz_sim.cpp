@@ -1,0 +1,178 @@
+// TEST ONLY: the formatter's gzip members (cgx_amd/csrc/cgx_fmt.h) built for the host.
+// Random lexicons over a random vocabulary are laid out group by group exactly as k_fmt_lines_gz / k_gz_trailers do it
+// (plain count -> gz count -> gz write -> CRC fold), every member is inflated by zlib and compared with the plain text
+// of its group, and the whole buffer is read back as one multi-member gzip stream.  Never calls the device ABI.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include <zlib.h>
+#include "../../cgx_amd/csrc/cgx_fmt.h"
+
+static uint64_t rs = 88172645463325252ull;
+static uint32_t rnd() { rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17; return (uint32_t)(rs >> 11); }
+static uint32_t rr(uint32_t n) { return rnd() % n; }
+
+struct Case {
+    std::vector<char> spool, tpool; std::vector<uint32_t> soff, toff;
+    std::vector<int32_t> str, tstr; std::vector<cgx_block> blocks; std::vector<cgx_gappat> p1d; std::vector<int32_t> c2d; std::vector<uint32_t> one2;
+    std::vector<float> aa, bb, fs;
+    std::vector<cgx_lexent> lex[3]; std::vector<int32_t> rng[3];
+    uint32_t G, D1, D2;
+    fmt_view F;
+};
+static void make_vocab(std::vector<char> &pool, std::vector<uint32_t> &off, uint32_t n, bool utf8) {
+    off.assign(n + 1, 0);
+    for (uint32_t i = 0; i < n; i++) {
+        off[i] = (uint32_t)pool.size();
+        if (rr(7) == 0) continue;                               // a word without a spelling: printed as s<id> / t<id>
+        uint32_t len = 1 + rr(rr(4) ? 9 : 40);
+        for (uint32_t k = 0; k < len; k++) { char c; if (utf8 && rr(9) == 0) c = (char)(0x80 + rr(0x7F)); else c = (char)('a' + rr(26)); pool.push_back(c); }
+    }
+    off[n] = (uint32_t)pool.size();
+    for (int k = 0; k < 16; k++) pool.push_back('#');           // the word sinks read whole 8-byte words
+}
+static void make_case(Case &c, uint32_t G, uint32_t D1, uint32_t D2, uint32_t ns, uint32_t nt, bool utf8, uint32_t maxlines) {
+    c.G = G; c.D1 = D1; c.D2 = D2;
+    make_vocab(c.spool, c.soff, ns, utf8); make_vocab(c.tpool, c.toff, nt, utf8);
+    c.str.resize(4096); for (auto &x : c.str) x = (int32_t)rr(ns + 3);                 // ids past the vocabulary print as numbers too
+    c.tstr.resize(8192); for (auto &x : c.tstr) x = (int32_t)rr(nt + 3);
+    c.blocks.resize(G); for (auto &b : c.blocks) { b.start = 0; b.end = 0; b.matchlen = 1 + (int32_t)rr(5); b.string_start = (int32_t)rr(4000); }
+    c.p1d.resize(D1 ? D1 : 1);
+    for (auto &p : c.p1d) { int a = 1 + (int)rr(2), bn = 1 + (int)rr(2); p.number = (uint8_t)(a + 1 + bn); int j = 0; for (int k = 0; k < a; k++) p.pat[j++] = (int32_t)rr(ns); p.pat[j++] = -1; for (int k = 0; k < bn; k++) p.pat[j++] = (int32_t)rr(ns); while (j < 5) p.pat[j++] = -2; }
+    c.c2d.resize(D2 ? D2 : 1); c.one2.resize(D2 ? D2 : 1);
+    for (uint32_t i = 0; i < D2; i++) { c.c2d[i] = (int32_t)rr(ns); c.one2[i] = D1 ? rr(D1) : 0; }
+    c.aa.assign(FMT_TABN * FMT_TABN, 0.f); c.bb.assign(FMT_TABN, 0.f); c.fs.assign(FMT_TABN, 0.f);
+    for (int p = 0; p < FMT_TABN; p++) { c.bb[p] = (float)log10((double)(1 + p)); c.fs[p] = (float)log10((double)(1 + p)); for (int f = 1; f < FMT_TABN; f++) c.aa[p * FMT_TABN + f] = p ? -log10f((float)p / (float)f) : 0.f; }
+    const uint32_t nid[3] = {G, 2 * G + D1, G + 2 * D1 + D2};
+    static const float vals[] = {0.30103f, 1.5f, 99.0f, 12.25f, 0.0f, 3.1415927f, 123.456f, 1e-7f, 7.0f, 2.4771213f};
+    for (int kind = 0; kind < 3; kind++) {
+        c.rng[kind].assign(2 * (size_t)nid[kind] + 2, -1);
+        for (uint32_t id = 0; id < nid[kind]; id++) {
+            uint32_t n = rr(3) == 0 ? 0 : 1 + rr(rr(5) == 0 ? maxlines : 6);
+            if (!n) continue;
+            c.rng[kind][2 * id] = (int32_t)c.lex[kind].size(); c.rng[kind][2 * id + 1] = (int32_t)(c.lex[kind].size() + n - 1);
+            const uint16_t fsample = (uint16_t)(1 + rr(301));
+            for (uint32_t k = 0; k < n; k++) {
+                cgx_lexent e; memset(&e, 0, sizeof e);
+                e.id = (int32_t)id; e.kind = (uint8_t)kind; e.tstart = rr(8000); e.end = (uint8_t)rr(rr(6) ? 4 : 15);
+                e.gap1 = e.gap1_1 = e.gap2 = e.gap2_1 = 200;
+                if (kind >= 1) { e.gap1 = (uint8_t)rr(e.end + 1); e.gap1_1 = (uint8_t)(e.gap1 + rr(e.end - e.gap1 + 1)); }
+                if (kind >= 2 && e.gap1_1 + 2 <= e.end) { e.gap2 = (uint8_t)(e.gap1_1 + 2 + rr(e.end - e.gap1_1 - 1)); e.gap2_1 = (uint8_t)(e.gap2 + rr(e.end - e.gap2 + 1)); }
+                e.fsample = fsample; e.paircount = (uint16_t)(rr(3) ? 1 : 1 + rr(fsample < 40 ? fsample : 40)); e.f = (uint16_t)(rr(2) ? 1 : 1 + rr(300));
+                e.fe = rr(3) ? vals[rr(10)] : (float)rr(2000000) / 65536.0f; e.ef = rr(3) ? vals[rr(10)] : (float)rr(2000000) / 32768.0f;
+                if (k && rr(4) == 0) { cgx_lexent p = c.lex[kind].back(); p.id = e.id; if (rr(2)) p.tstart = e.tstart; c.lex[kind].push_back(p); continue; }   // (nearly) the line before it once more
+                c.lex[kind].push_back(e);
+            }
+        }
+    }
+    fmt_view &F = c.F;
+    for (int k = 0; k < 3; k++) { F.lex[k] = c.lex[k].data(); F.rng[k] = c.rng[k].data(); }
+    F.blocks = c.blocks.data(); F.p1d = c.p1d.data(); F.c2d = c.c2d.data(); F.one2 = c.one2.data(); F.str = c.str.data(); F.tstr = c.tstr.data();
+    F.spool = c.spool.data(); F.tpool = c.tpool.data(); F.soff = c.soff.data(); F.toff = c.toff.data(); F.ns = ns; F.nt = nt;
+    F.aa = c.aa.data(); F.bb = c.bb.data(); F.fs = c.fs.data(); F.G = G; F.D1 = D1; F.D2 = D2;
+}
+
+static int inflate_member(const unsigned char *src, size_t n, std::string &out, size_t *used) {
+    z_stream s; memset(&s, 0, sizeof s);
+    if (inflateInit2(&s, 16 + MAX_WBITS) != Z_OK) return -1;
+    s.next_in = (Bytef *)src; s.avail_in = (uInt)n;
+    unsigned char buf[65536]; int rc;
+    do { s.next_out = buf; s.avail_out = sizeof buf; rc = inflate(&s, Z_NO_FLUSH); if (rc != Z_OK && rc != Z_STREAM_END) { fprintf(stderr, "inflate: %d %s\n", rc, s.msg ? s.msg : ""); inflateEnd(&s); return -1; } out.append((char *)buf, sizeof buf - s.avail_out); } while (rc != Z_STREAM_END);
+    *used = n - s.avail_in; inflateEnd(&s);
+    return 0;
+}
+
+static uint64_t g_short_lines;
+static int run_case(uint32_t G, uint32_t D1, uint32_t D2, uint32_t ns, uint32_t nt, bool utf8, uint32_t maxlines, uint64_t *nlines_out, uint64_t *plain_out, uint64_t *gz_out) {
+    Case c; make_case(c, G, D1, D2, ns, nt, utf8, maxlines);
+    const fmt_view &F = c.F;
+    const uint32_t NC = 4 * G + 3 * D1 + D2, NG = G + D1 + D2;
+    // canonical items -> lines (k_fmt_canon_lines / k_fmt_canon_ent)
+    std::vector<uint32_t> cstart(NC + 1, 0), line_ent, line_c;
+    for (uint32_t ci = 0; ci < NC; ci++) {
+        int kind; uint32_t cid; canon_item(ci, G, D1, D2, &kind, &cid);
+        cstart[ci] = (uint32_t)line_ent.size();
+        const int32_t dn = F.rng[kind][2 * (size_t)cid], up = F.rng[kind][2 * (size_t)cid + 1];
+        if (dn < 0 || up < 0) continue;
+        for (int32_t l = dn; l <= up; l++) { line_ent.push_back(((uint32_t)kind << 30) | (uint32_t)l); line_c.push_back(ci); }
+    }
+    const uint32_t NU = (uint32_t)line_ent.size(); cstart[NC] = NU;
+    uint32_t tab[GZ_TAB_WORDS]; gz_make_tables(tab);
+    // pass 1: plain lengths; the plain text itself is the expectation
+    std::vector<uint32_t> len_u(NU); std::vector<uint64_t> U(NU + 1, 0); std::vector<std::string> plain(NU);
+    for (uint32_t l = 0; l < NU; l++) {
+        const int kind = (int)(line_ent[l] >> 30); const cgx_lexent &e = F.lex[kind][line_ent[l] & 0x3FFFFFFFu];
+        CountSink cs{0}; fmt_line(cs, F, kind, e); len_u[l] = cs.n;
+        std::vector<char> buf(cs.n + 16); MemSink ms{buf.data()}; if (!fmt_line(ms, F, kind, e)) { fprintf(stderr, "plain line not representable\n"); return 1; }
+        if ((uint32_t)(ms.p - buf.data()) != cs.n) { fprintf(stderr, "plain count != plain write\n"); return 1; }
+        plain[l].assign(buf.data(), cs.n); U[l + 1] = U[l] + cs.n;
+    }
+    auto place = [&](uint32_t l, gz_place &P) {
+        const uint32_t ci = line_c[l], g = canon_group(ci, G, D1), l0 = cstart[canon_group_first(g, G, D1)], l1 = cstart[canon_group_first(g + 1, G, D1)];
+        memset(&P, 0, sizeof P);
+        P.first = l == l0; P.last = l + 1 == l1; P.same_item = l > cstart[ci];
+        if (!P.first) { const int pk = (int)(line_ent[l - 1] >> 30); gz_place_prev(P, F, F.lex[pk][line_ent[l - 1] & 0x3FFFFFFFu]); P.prev_len = len_u[l - 1]; }
+        return l1;
+    };
+    // pass 2: compressed lengths
+    std::vector<uint32_t> len_c(NU); std::vector<uint64_t> off(NU + 1, 0);
+    for (uint32_t l = 0; l < NU; l++) {
+        const int kind = (int)(line_ent[l] >> 30); const cgx_lexent &e = F.lex[kind][line_ent[l] & 0x3FFFFFFFu];
+        gz_place P; place(l, P);
+        BitCount bc{0}; GzSink<BitCount, false> z(bc, nullptr);
+        if (!fmt_line_gz(bc, z, F, kind, e, P)) { fprintf(stderr, "gz count: line %u not representable\n", l); return 1; }
+        if (z.pos != len_u[l]) { fprintf(stderr, "gz sink saw %u characters, the plain line has %u\n", z.pos, len_u[l]); return 1; }
+        if (bc.n & 7u) { fprintf(stderr, "line %u does not end on a byte\n", l); return 1; }
+        len_c[l] = bc.bytes(); off[l + 1] = off[l] + len_c[l];
+        if (len_c[l] == GZ_MIN_LINE || len_c[l] == GZ_MIN_LINE + 1) g_short_lines++;   // most of these took the padding blocks
+        if (len_c[l] < GZ_MIN_LINE) { fprintf(stderr, "line %u has %u bytes\n", l, len_c[l]); return 1; }
+    }
+    // pass 3: write, CRC contributions
+    std::vector<unsigned char> text(off[NU] + 64, 0xAA); std::vector<uint32_t> contrib(NU);
+    for (uint32_t l = 0; l < NU; l++) {
+        const int kind = (int)(line_ent[l] >> 30); const cgx_lexent &e = F.lex[kind][line_ent[l] & 0x3FFFFFFFu];
+        gz_place P; const uint32_t l1 = place(l, P);
+        MemSink ms{(char *)text.data() + off[l]}; BitOut<MemSink> bo(ms); GzSink<BitOut<MemSink>, true> z(bo, tab);
+        if (!fmt_line_gz(bo, z, F, kind, e, P)) { fprintf(stderr, "gz write: line %u not representable\n", l); return 1; }
+        if ((uint64_t)(ms.p - (char *)text.data()) != off[l + 1]) { fprintf(stderr, "gz count %u != gz write %ld at line %u\n", len_c[l], (long)(ms.p - (char *)text.data() - (long)off[l]), l); return 1; }
+        contrib[l] = gz_multmodp(gz_x8n(tab, U[l1] - U[l + 1]), z.crc ^ 0xFFFFFFFFu);
+    }
+    // trailers (k_gz_trailers) and the check: every member by itself
+    uint64_t members = 0;
+    for (uint32_t g = 0; g < NG; g++) {
+        const uint32_t l0 = cstart[canon_group_first(g, G, D1)], l1 = cstart[canon_group_first(g + 1, G, D1)];
+        if (l0 == l1) continue;
+        uint32_t crc = 0; for (uint32_t l = l0; l < l1; l++) crc ^= contrib[l];
+        const uint32_t isize = (uint32_t)(U[l1] - U[l0]);
+        unsigned char *t = text.data() + off[l1] - 8;
+        for (int k = 0; k < 8; k++) if (t[k] != 0) { fprintf(stderr, "trailer bytes of group %u not zero\n", g); return 1; }
+        for (int k = 0; k < 4; k++) { t[k] = (unsigned char)(crc >> (8 * k)); t[4 + k] = (unsigned char)(isize >> (8 * k)); }
+        std::string want; for (uint32_t l = l0; l < l1; l++) want += plain[l];
+        if ((uint32_t)crc32(0, (const Bytef *)want.data(), (uInt)want.size()) != crc) { fprintf(stderr, "CRC fold of group %u is wrong\n", g); return 1; }
+        std::string got; size_t used = 0;
+        if (inflate_member(text.data() + off[l0], (size_t)(off[l1] - off[l0]), got, &used)) { fprintf(stderr, "group %u does not inflate\n", g); return 1; }
+        if (used != off[l1] - off[l0]) { fprintf(stderr, "group %u: member is %zu bytes, laid out as %llu\n", g, used, (unsigned long long)(off[l1] - off[l0])); return 1; }
+        if (got != want) { fprintf(stderr, "group %u inflates to other text\n", g); return 1; }
+        members++;
+    }
+    // the whole buffer as one series of members (what a grammar file made of several pieces is)
+    std::string all, want_all; for (uint32_t l = 0; l < NU; l++) want_all += plain[l];
+    for (size_t at = 0; at < off[NU];) { size_t used = 0; if (inflate_member(text.data() + at, (size_t)off[NU] - at, all, &used)) return 1; at += used; }
+    if (all != want_all) { fprintf(stderr, "the series of members inflates to other text\n"); return 1; }
+    *nlines_out += NU; *plain_out += U[NU]; *gz_out += off[NU];
+    (void)members;
+    return 0;
+}
+
+int main(int argc, char **argv) {
+    const int rounds = argc > 1 ? atoi(argv[1]) : 6;
+    uint64_t nl = 0, pb = 0, gb = 0;
+    for (int r = 0; r < rounds; r++) {
+        if (run_case(40 + rr(40), 60 + rr(60), 50 + rr(50), 500, 700, (r & 1) != 0, r == 2 ? 1200 : 40, &nl, &pb, &gb)) { printf("GZ SIM FAILED in round %d\n", r); return 1; }
+    }
+    if (run_case(3, 0, 0, 20, 20, false, 5, &nl, &pb, &gb) || run_case(0, 2, 0, 20, 20, false, 5, &nl, &pb, &gb) || run_case(0, 0, 0, 20, 20, false, 5, &nl, &pb, &gb)) { printf("GZ SIM FAILED on a degenerate case\n"); return 1; }
+    printf("GZ SIM OK: %llu lines (%llu at the minimum length), %llu bytes of text as %llu bytes of gzip members (%.3f)\n", (unsigned long long)nl, (unsigned long long)g_short_lines, (unsigned long long)pb, (unsigned long long)gb, pb ? (double)gb / (double)pb : 0.0);
+    return 0;
+}

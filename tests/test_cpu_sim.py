@@ -26,6 +26,17 @@ def test_writer_float_formatting_equals_printf(tmp_path):
     assert r.returncode == 0 and "F6 OK" in r.stdout, r.stdout
 
 
+def test_formatter_gzip_members_inflate_to_the_plain_text(tmp_path):
+    """cgx_amd/csrc/cgx_fmt.h built for the host with ASan/UBSan: the DEFLATE symbols the formatter emits for random lexicons
+    (counting pass == writing pass, every gzip member inflated by zlib == the plain text of its emission group, the CRC fold ==
+    zlib's crc32, the whole buffer == one multi-member stream), with ASCII and with non-ASCII spellings, short and long groups."""
+    exe = str(tmp_path / "gz_sim")
+    subprocess.run(["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize=alignment", "-std=c++17",
+                    os.path.join(ROOT, "tests", "cpu_sim", "gz_sim.cpp"), "-lz", "-o", exe], check=True)
+    r = subprocess.run([exe, "8"], capture_output=True, text=True)
+    assert r.returncode == 0 and "GZ SIM OK" in r.stdout, r.stdout + r.stderr
+
+
 def test_window_transpose_algebra():
     """load_window / cgx_win_load (cgx_search.inc, cgx_extract.inc): the eight lanes of a group fetch the group's eight windows
     one after the other -- load j gives lane k piece k of window j -- and three butterfly stages (masks 4, 2, 1: a lane whose

@@ -98,21 +98,64 @@ def test_cli_is_a_drop_in(cgx, oracle_bin, fixtures_dir, tmp_path):
     assert r.returncode == 0 and "It is not valid" in r.stderr          # PrintResults.c:443-446
 
 
-@pytest.mark.parametrize("device_format", [1, 0])
-def test_gzip_output_holds_the_same_bytes(device_format, cgx, fixtures_dir, tmp_path):
-    """Option gz_level / strmatchcuda --gz N: grammar.<q>.s.gz, whose content is the golden file (both writers)."""
+def _gunzip_three_ways(path):
+    """The bytes of a .gz file as Python's gzip, the zcat program and zlib's gzread give them; all three must agree."""
+    import ctypes as C
     import gzip
+    a = gzip.open(path, "rb").read()
+    b = subprocess.run(["zcat", str(path)], capture_output=True, check=True).stdout
+    z = C.CDLL("libz.so.1"); z.gzopen.restype = C.c_void_p; z.gzopen.argtypes = [C.c_char_p, C.c_char_p]
+    z.gzread.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]; z.gzclose.argtypes = [C.c_void_p]
+    f = z.gzopen(str(path).encode(), b"rb"); assert f
+    buf = C.create_string_buffer(1 << 20); c = bytearray()
+    while True:
+        n = z.gzread(f, buf, len(buf))
+        assert n >= 0
+        if n == 0:
+            break
+        c += buf.raw[:n]
+    assert z.gzclose(f) == 0
+    assert a == b == bytes(c), path
+    return a
+
+
+@pytest.mark.parametrize("writer", ["gpu_members", "host_zlib_on_unique_text", "host_formatter_zlib"])
+@pytest.mark.parametrize("name", ["toy", "mid"])
+def test_gzip_output_holds_the_same_bytes(name, writer, cgx, fixtures_dir, tmp_path):
+    """Option gz_level / strmatchcuda --gz N: grammar.<q>.s.gz, whose content is the golden file, for the three writers: gzip
+    members emitted by the GPU formatter itself (the default with the device formatter), the host's zlib over the pieces of the
+    plain unique text (gz_device = 0), the host formatter's zlib.  Read back with Python's gzip, zcat and zlib's gzread."""
     import hashlib
-    fx = make_fixture("toy", fixtures_dir)
-    ex, corpus, n = run_product(cgx, fx, str(tmp_path / "z"), gz_level=6, device_format=device_format)
-    got = [hashlib.sha256(gzip.open(tmp_path / "z" / ("grammar.%d.s.gz" % q), "rb").read()).hexdigest() for q in range(7)]
-    assert got == META["toy"]["grammar"] and not os.path.exists(tmp_path / "z" / "grammar.0.s")
+    fx = make_fixture(name, fixtures_dir); nq = META[name]["spec"][2]
+    opts = dict(gpu_members=dict(gz_level=6), host_zlib_on_unique_text=dict(gz_level=6, gz_device=0), host_formatter_zlib=dict(gz_level=6, device_format=0))[writer]
+    ex, corpus, n = run_product(cgx, fx, str(tmp_path / "z"), **opts)
+    got = [hashlib.sha256(_gunzip_three_ways(tmp_path / "z" / ("grammar.%d.s.gz" % q))).hexdigest() for q in range(nq)]
+    assert got == META[name]["grammar"] and not os.path.exists(tmp_path / "z" / "grammar.0.s")
+    if writer == "gpu_members":
+        assert ex.stage_ms("fmt_gz") == 1.0 and 0 < ex.stage_ms("fmt_unique_bytes") < 0.6 * ex.stage_ms("fmt_plain_unique_bytes")
     ex.close(); corpus.close()
-    if device_format:
+    if writer == "gpu_members" and name == "toy":
         out = tmp_path / "cli"; out.mkdir()
         r = subprocess.run([os.path.join(ROOT, "bin", "strmatchcuda"), "--gz", "1"] + op.fixture_args(fx) + [str(out)], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr
-        assert [hashlib.sha256(gzip.open(out / ("grammar.%d.s.gz" % q), "rb").read()).hexdigest() for q in range(7)] == META["toy"]["grammar"]
+        assert [hashlib.sha256(_gunzip_three_ways(out / ("grammar.%d.s.gz" % q))).hexdigest() for q in range(7)] == META["toy"]["grammar"]
+
+
+def test_gzip_members_edge_cases(cgx, oracle_bin, tmp_path):
+    """Queries without rules become one empty gzip member; async writer, sub-batches and the sampling options keep working
+    with members; the staged API says what a slot holds."""
+    fx = os.path.join(ROOT, "tests", "golden", "tiny"); d = tmp_path / "fx"; d.mkdir()
+    for n in ("corpus.f", "corpus.e", "corpus.a", "lex.txt"):
+        shutil.copy(os.path.join(fx, n), d / n)
+    (d / "query.f").write_text("\nOOV1 OOV2\ns1\ns1 s1 s1 s1 s1 s1\ns0 s2 OOV s1 s0\n\n")
+    op.run_oracle(oracle_bin, str(d), str(tmp_path / "o"))
+    for k, opts in enumerate((dict(), dict(async_write=1, sub_batch=2))):
+        ex, corpus, n = run_product(cgx, str(d), str(tmp_path / ("p%d" % k)), gz_level=1, **opts)
+        ex.flush()
+        for q in range(6):
+            assert _gunzip_three_ways(tmp_path / ("p%d" % k) / ("grammar.%d.s.gz" % q)) == open(tmp_path / "o" / ("grammar.%d.s" % q), "rb").read()
+        assert os.path.getsize(tmp_path / ("p%d" % k) / "grammar.0.s.gz") == 20          # the empty member
+        ex.close(); corpus.close()
 
 
 def test_staged_text_api_reassembles_the_files(cgx, oracle_bin, fixtures_dir, tmp_path):
@@ -147,6 +190,21 @@ def test_staged_text_api_reassembles_the_files(cgx, oracle_bin, fixtures_dir, tm
     assert got == META["toy"]["grammar"]
     assert nlines == sum(sum(1 for _ in open(tmp_path / "o" / ("grammar.%d.s" % q), "rb")) for q in range(nq))
     assert len(text) < nbytes                                            # shared lines are stored once
+    assert ex.text_encoding(slot) == 0
+    # the same through the members: every piece is a series of whole gzip members
+    import gzip
+    ex.set_option("gz_level", 1)
+    zbytes, zlines, zslot = ex.format()
+    assert ex.text_encoding(zslot) == 1 and zlines == nlines and zbytes < nbytes // 2
+    ztext, qseg, seg_off, seg_len, qtext = ex.text(zslot, nq)
+    zgot = []
+    for q in range(nq):
+        body = b"".join(ztext[int(seg_off[s]):int(seg_off[s]) + int(seg_len[s])] for s in range(int(qseg[q]), int(qseg[q + 1])))
+        assert len(body) == int(qtext[q + 1] - qtext[q])
+        for s in range(int(qseg[q]), int(qseg[q + 1])):                  # a piece by itself is a valid file too
+            gzip.decompress(ztext[int(seg_off[s]):int(seg_off[s]) + int(seg_len[s])])
+        zgot.append(hashlib.sha256(gzip.decompress(body) if body else b"").hexdigest())
+    assert zgot == META["toy"]["grammar"]
     ex.close()
 
 
