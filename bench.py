@@ -107,6 +107,37 @@ def usable_cpus():
     return n
 
 
+def save_corpus_for_cpu(corpus, qs, args):
+    """The benchmark's own corpus arrays and the first queries of its first batch as .npy files for the CPU leg on the full corpus
+    (tools/cpu_baseline.py --full-dir); the suffix array and the frequent-pair tables are added after the timed region."""
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+    d = tempfile.mkdtemp(prefix="cgx_bench_cpu_full_", dir=base)
+    for k in ("str", "sentind", "tstr", "tsentind", "lsrc", "rsrc", "ltar", "rtar", "lexk", "lexv"):
+        np.save(os.path.join(d, k + ".npy"), np.ascontiguousarray(corpus[k]))
+    nqs = min(len(qs["qoff"]), args.cpu_full_queries * 20)       # the one-core leg's queries plus the workers' shares
+    qo = np.asarray(qs["qoff"][:nqs], np.int64); end = int(qs["qoff"][nqs]) if nqs < len(qs["qoff"]) else len(qs["qtok"])
+    np.save(os.path.join(d, "qoff.npy"), qo); np.save(os.path.join(d, "qtok.npy"), np.ascontiguousarray(qs["qtok"][:end], np.int32))
+    return d
+
+
+def run_cpu_full_corpus(ex, full_dir, args):
+    """After the timed regions: the GPU-built suffix array and frequent-pair tables join the corpus files, and the CPU restatement runs
+    the first queries of the first batch against the WHOLE benchmark corpus (one core, then all cores), in its own process."""
+    try:
+        for k in ("sa", "freq", "pidx", "miss", "phit_start", "phit_len"):
+            np.save(os.path.join(full_dir, k + ".npy"), ex.fetch(k))
+        cmd = [sys.executable, os.path.join(ROOT, "tools", "cpu_baseline.py"), "--full-dir", full_dir, "--full-queries", str(args.cpu_full_queries), "--full-seconds", str(args.cpu_full_seconds)]
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=4 * args.cpu_full_seconds + 240)
+        for line in reversed(p.stdout.strip().splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+        return {"error": "full-corpus CPU leg printed no result (exit %s): %s" % (p.returncode, p.stderr[-300:])}
+    except Exception as e:
+        return {"error": repr(e)}
+    finally:
+        shutil.rmtree(full_dir, ignore_errors=True)
+
+
 def start_cpu_baseline(args, cfg):
     """tools/cpu_baseline.py in its own process (never touches the GPU); the result is collected later."""
     cmd = [sys.executable, os.path.join(ROOT, "tools", "cpu_baseline.py"), "--pairs", str(min(args.cpu_pairs, cfg["pairs"])), "--vocab", str(cfg["vocab"]),
@@ -145,6 +176,8 @@ def main():
     ap.add_argument("--cpu-pairs", type=int, default=200000, help="sentence pairs of the CPU baseline's sample corpus")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="seconds of timed CPU work per baseline leg (one core, all cores)")
     ap.add_argument("--cpu-full-sa-seconds", type=float, default=150.0, help="the CPU baseline process also runs the reference's own suffixArrayConstruct on the WHOLE corpus (one core, beside its other legs), for at most this long (0: skip)")
+    ap.add_argument("--cpu-full-queries", type=int, default=64, help="the CPU baseline ALSO runs this many queries of the first timed batch against the benchmark's own corpus (GPU-built suffix array and frequent-pair tables handed to the CPU restatement), on one core and then on all cores, after the timed region (0: skip; only for N = 1 and corpora of at least 1M pairs)")
+    ap.add_argument("--cpu-full-seconds", type=float, default=60.0, help="time cap per leg of the full-corpus CPU baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; nccl (= RCCL over xGMI) for real runs, gloo only to rehearse N>1 on a one-GPU box")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -153,6 +186,8 @@ def main():
     ap.add_argument("--no-numa-pin", action="store_true", help="do not bind the writer threads to the GPU's NUMA node")
     ap.add_argument("--sync-write", action="store_true", help="write each chunk's files before starting the next chunk")
     ap.add_argument("--fresh-steps", type=int, default=None, help="extra timed steps AFTER the contract's K steps that write every chunk into a NEW directory (value_fresh_files); default 3 (1 when a step is several chunks), 0 = skip")
+    ap.add_argument("--query-sets", type=int, default=3, help="distinct query batches (different seeds) the steps rotate through: step i runs set i %% N, so capacity guesses, tables and file sizes change from step to step as in a serving run")
+    ap.add_argument("--gz-steps", type=int, default=None, help="extra timed steps AFTER the contract's K steps with grammar.<q>.s.gz output, the gzip members made by the GPU formatter (value_gz); default min(K, 5), 0 = skip")
     ap.add_argument("--no-write", action="store_true", help="count the rules on the GPU, lay out no text, write no files (kernel-side study; not the headline)")
     ap.add_argument("--option", action="append", default=[], help="name=value passed to cgx_set_option (repeatable)")
     args = ap.parse_args()
@@ -275,10 +310,19 @@ def main():
     t_index = time.perf_counter() - t0
 
     # ---- queries: weak = every rank gets cfg.queries; strong = cfg.queries in all, split by token count ----
+    # Several distinct batches (seeds s, s + 1000, ..): step i runs batch i % nsets.
     global_q = cfg["queries"] * world if cfg["scaling"] == "weak" else cfg["queries"]
-    gq_off, gq_tok = synth.make_queries(corpus, global_q, args.seed + 3087)
-    first, qoff, qtok = shard.take_shard(gq_off, gq_tok, rank, world)
-    qoff = np.asarray(qoff, np.int64); nq = len(qoff)
+    nsets = max(1, args.query_sets); qsets = []
+    for k in range(nsets):
+        gq_off, gq_tok = synth.make_queries(corpus, global_q, args.seed + 3087 + 1000 * k)
+        first_k, qoff_k, qtok_k = shard.take_shard(gq_off, gq_tok, rank, world)
+        qsets.append({"first": first_k, "qoff": np.asarray(qoff_k, np.int64), "qtok": qtok_k})
+    first, qoff, qtok = qsets[0]["first"], qsets[0]["qoff"], qsets[0]["qtok"]; nq = len(qoff)
+    nq_max = max(len(q["qoff"]) for q in qsets)
+    if args.cpu_full_queries > 0 and rank == 0 and world == 1 and not args.no_cpu_baseline and cfg["pairs"] >= 1_000_000:
+        full_dir = save_corpus_for_cpu(corpus, qsets[0], args)  # the CPU leg on the benchmark's own corpus reads these after the timed region
+    else:
+        full_dir = None
     del corpus, gq_off, gq_tok
     if world > 1:
         dist.barrier()
@@ -294,49 +338,60 @@ def main():
     base = None
     for d in cands:
         try:
-            if shutil.disk_usage(d).free / max(local_world, 1) >= min(per_rank, nq * EST_BYTES_PER_QUERY):
+            if shutil.disk_usage(d).free / max(local_world, 1) >= min(per_rank, nq_max * EST_BYTES_PER_QUERY):
                 base = d; break
         except OSError:
             pass
     write = not args.no_write and base is not None
-    chunk = nq
+    chunk = nq_max
     if write:
         fit = int(per_rank / (EST_BYTES_PER_QUERY * 1.15))
-        chunk = args.chunk_queries if args.chunk_queries > 0 else min(nq, fit)
-        if chunk < min(nq, 64):
+        chunk = args.chunk_queries if args.chunk_queries > 0 else min(nq_max, fit)
+        if chunk < min(nq_max, 64):
             write = False                                       # no room for a useful spool: count the rules on the GPU instead (reported)
-            chunk = nq
+            chunk = nq_max
     spool = tempfile.mkdtemp(prefix="cgx_bench_r%d_" % rank, dir=base) if write else None
     # a chunk is also at most one internal batch of the library (300 000 query tokens by default): the per-batch timers and
     # tallies read after each chunk then describe the whole chunk, and every configuration runs the same pipeline
     if args.sub_batch > 0:
         chunk = min(chunk, args.sub_batch)                      # smaller batches are submitted as chunks here, so that the per-batch timers below still describe what ran
-    chunks = make_chunks(qoff, len(qtok), chunk)
-    chunk = max(b - a for a, b in chunks)
-    whole = len(chunks) == 1
+    for q in qsets:
+        q["chunks"] = make_chunks(q["qoff"], len(q["qtok"]), chunk)
+    chunks = qsets[0]["chunks"]
+    chunk = max(b - a for q in qsets for a, b in q["chunks"])
+    whole = all(len(q["chunks"]) == 1 for q in qsets)
     spool_bytes = [0]
 
     stage_names = ("sa_lookup", "blocks", "gappy", "extract", "lexicon", "format", "fmt_count", "fmt_write", "look1_kernel", "look2_kernel")
     host_names = ("write", "write_wait_d2h", "write_file", "total", "t_upload_sa", "t_blocks", "t_gappy", "t_extract", "t_lexicon", "t_format", "t_flush_wait")
-    acc = {"on": False, "kernel_ms": [], "stage": {k: 0.0 for k in stage_names}, "host": {k: 0.0 for k in host_names},
-           "look1_items": 0.0, "look2_items": 0.0, "h1": 0, "h2": 0, "batches": 0}      # summed over every batch (chunk) of the timed steps
+    def new_acc():
+        return {"on": False, "kernel_ms": [], "stage": {k: 0.0 for k in stage_names}, "host": {k: 0.0 for k in host_names},
+                "look1_items": 0.0, "look2_items": 0.0, "h1": 0, "h2": 0, "batches": 0, "ubytes": 0.0, "pbytes": 0.0, "fbytes": 0.0}      # summed over every batch (chunk) of the timed steps
+    acc = new_acc()
+    step_no = [0]
 
-    def run_chunk(a, b, outdir=None):
-        t0_, t1_ = int(qoff[a]), (int(qoff[b]) if b < nq else len(qtok))
-        n = ex.extract_grammars_ids(host, (qoff[a:b] - t0_).astype(np.int32), qtok[t0_:t1_], outdir or spool, first + a if whole else 0)
+    def run_chunk(a, b, outdir=None, qs=None):
+        # With several chunks per step the chunks reuse the file slots grammar.0.s ..: first_query_index is 0 for each of them, so the
+        # library's write_period / write_count sampling (an index into the whole query list) would be chunk-local here; the bench does not use it.
+        qs = qs or qsets[0]; qo, qt = qs["qoff"], qs["qtok"]
+        t0_, t1_ = int(qo[a]), (int(qo[b]) if b < len(qo) else len(qt))
+        n = ex.extract_grammars_ids(host, (qo[a:b] - t0_).astype(np.int32), qt[t0_:t1_], outdir or spool, qs["first"] + a if whole else 0)
         if acc["on"]:                                         # the per-batch timers and tallies of the library hold the batch that just ran
             acc["kernel_ms"].append(ex.stage_ms("sa_lookup_kernel"))
             for k in stage_names: acc["stage"][k] += max(ex.stage_ms(k), 0.0)
             for k in host_names: acc["host"][k] += max(ex.host_ms(k), 0.0)
             cc = ex.counts(); acc["look1_items"] += max(ex.stage_ms("look1_items"), 0.0); acc["look2_items"] += max(ex.stage_ms("look2_items"), 0.0)
             acc["h1"] += cc["h1"]; acc["h2"] += cc["h2"]; acc["batches"] += 1
+            acc["ubytes"] += max(ex.stage_ms("fmt_unique_bytes"), 0.0); acc["pbytes"] += max(ex.stage_ms("fmt_plain_unique_bytes"), 0.0); acc["fbytes"] += max(ex.stage_ms("fmt_file_bytes"), 0.0)
         return n
 
-    def step():
+    def step(outdir_of=None):
+        """One step = one query batch; consecutive steps take consecutive batches of the rotation.  -> (rules, queries)"""
+        qs = qsets[step_no[0] % nsets]; step_no[0] += 1
         n = 0
-        for a, b in chunks:
-            n += run_chunk(a, b)
-        return n
+        for a, b in qs["chunks"]:
+            n += run_chunk(a, b, outdir_of() if outdir_of else None, qs)
+        return n, len(qs["qoff"])
 
     # the CPU baseline has had the corpus generation and the index build to finish; wait for the rest of it now
     cpu_res = collect_cpu_baseline(cpu_proc, 240 + int(args.cpu_full_sa_seconds)) if cpu_proc else None
@@ -354,10 +409,11 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    t0 = time.perf_counter(); rules = 0
+    reruns0 = max(ex.stage_ms("append_reruns"), 0.0)
+    t0 = time.perf_counter(); rules = 0; queries_done = 0
     acc["on"] = True
     for _ in range(steps):
-        rules += step()
+        r_, q_ = step(); rules += r_; queries_done += q_
     acc["on"] = False
     kernel_ms, stage, hoststage = acc["kernel_ms"], acc["stage"], acc["host"]
     ex.flush()                                # every grammar file of every timed step is on disk before the clock stops
@@ -365,12 +421,13 @@ def main():
     if world > 1:
         dist.barrier()
     dt = shard.max_over_ranks(time.perf_counter() - t0, dist if world > 1 else None)
-    total_q = shard.sum_over_ranks(nq * steps, dist if world > 1 else None)
+    append_reruns = max(ex.stage_ms("append_reruns"), 0.0) - reruns0
+    total_q = shard.sum_over_ranks(queries_done, dist if world > 1 else None)
     total_rules = shard.sum_over_ranks(rules, dist if world > 1 else None)
 
     # ---- what every rank did in the timed steps: the GPU chain alone, and the two host stages beside it ----
     chain_s = sum(stage[k] for k in ("sa_lookup", "blocks", "gappy", "extract", "lexicon", "format")) / 1e3
-    mine = {"rank": rank, "queries": int(nq * steps), "gpu_chain_s": chain_s, "dma_wait_s": hoststage["write_wait_d2h"] / 1e3, "file_phase_s": hoststage["write_file"] / 1e3,
+    mine = {"rank": rank, "queries": int(queries_done), "gpu_chain_s": chain_s, "dma_wait_s": hoststage["write_wait_d2h"] / 1e3, "file_phase_s": hoststage["write_file"] / 1e3,
             "writer_threads": int(max(ex.host_ms("writer_threads"), 0)), "cpus_usable": usable_cpus(), "cgx_threads_env": os.environ.get("CGX_THREADS")}
     ranks = [mine]
     if world > 1:
@@ -395,14 +452,17 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize()
             tf = time.perf_counter()
+            fresh_q = 0
+
+            def fresh_dir():
+                while len(deleters) > 1:
+                    deleters.pop(0).join()
+                if len(gens) > 2:                               # the library keeps at most two batches in flight: the files of the third-last chunk are complete
+                    th = threading.Thread(target=shutil.rmtree, args=(gens.pop(0), True)); th.start(); deleters.append(th)
+                d = tempfile.mkdtemp(prefix="gen_", dir=spool); gens.append(d)
+                return d
             for _ in range(fresh_steps):
-                for a, b in chunks:
-                    while len(deleters) > 1:
-                        deleters.pop(0).join()
-                    d = tempfile.mkdtemp(prefix="gen_", dir=spool)
-                    run_chunk(a, b, d); gens.append(d)
-                    if len(gens) > 2:
-                        th = threading.Thread(target=shutil.rmtree, args=(gens.pop(0), True)); th.start(); deleters.append(th)
+                fresh_q += step(fresh_dir)[1]
             ex.flush()
             torch.cuda.synchronize()
             if world > 1:
@@ -410,9 +470,52 @@ def main():
             dtf = shard.max_over_ranks(time.perf_counter() - tf, dist if world > 1 else None)
             for th in deleters:
                 th.join()
-            tq = shard.sum_over_ranks(nq * fresh_steps, dist if world > 1 else None)
+            tq = shard.sum_over_ranks(fresh_q, dist if world > 1 else None)
             fresh.update(steps=fresh_steps, value=round(tq / dtf, 3), ms_per_step=round(dtf / fresh_steps * 1e3, 3),
                          note="every chunk written into a new directory; directories older than two chunks deleted by a helper thread inside the timed region")
+
+    # ---- the same steps with grammar.<q>.s.gz output: the gzip members are made by the GPU formatter, so PCIe and the file phase
+    # move a third of the bytes (the plain files above stay the default and the headline) ----
+    gz_steps = args.gz_steps if args.gz_steps is not None else min(steps, 5)
+    gzres = {"steps": 0, "value": None}
+    if write and gz_steps > 0:
+        shutil.rmtree(spool, ignore_errors=True); os.makedirs(spool, exist_ok=True)
+        ex.set_option("gz_level", 1)
+        main_acc = acc; acc = new_acc()
+        for _ in range(2):                                    # fill the .gz file slots twice before the clock starts, as for the plain files
+            step()
+        ex.flush()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        tg = time.perf_counter(); gz_rules = 0; gz_q = 0
+        acc["on"] = True
+        for _ in range(gz_steps):
+            r_, q_ = step(); gz_rules += r_; gz_q += q_
+        acc["on"] = False
+        ex.flush()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dtg = shard.max_over_ranks(time.perf_counter() - tg, dist if world > 1 else None)
+        tqg = shard.sum_over_ranks(gz_q, dist if world > 1 else None); trg = shard.sum_over_ranks(gz_rules, dist if world > 1 else None)
+        gacc = acc; acc = main_acc
+        ex.set_option("gz_level", 0)
+        gchain = sum(gacc["stage"][k] for k in ("sa_lookup", "blocks", "gappy", "extract", "lexicon", "format")) / 1e3
+        gchain_max = shard.max_over_ranks(gchain, dist if world > 1 else None)
+        gzres = {"steps": gz_steps, "value": round(tqg / dtg, 3), "rules_per_s": round(trg / dtg, 1), "ms_per_step": round(dtg / gz_steps * 1e3, 3),
+                 "value_gpu_chain": round(tqg / max(gchain_max, 1e-9), 3),
+                 "gpu_chain_ms_per_step": round(gchain / gz_steps * 1e3, 2), "dma_wait_ms_per_step": round(gacc["host"]["write_wait_d2h"] / gz_steps, 2), "file_phase_ms_per_step": round(gacc["host"]["write_file"] / gz_steps, 2),
+                 "format_ms_per_step": round(gacc["stage"]["format"] / gz_steps, 2), "fmt_count_ms_per_step": round(gacc["stage"]["fmt_count"] / gz_steps, 2), "fmt_write_ms_per_step": round(gacc["stage"]["fmt_write"] / gz_steps, 2),
+                 "d2h_bytes_per_step": int(gacc["ubytes"] / gz_steps), "plain_unique_text_bytes_per_step": int(gacc["pbytes"] / gz_steps), "gz_file_bytes_per_step": int(gacc["fbytes"] / gz_steps),
+                 "compressed_to": round(gacc["ubytes"] / max(gacc["pbytes"], 1.0), 4),
+                 "bound": max((("gpu_chain", gchain), ("dma", gacc["host"]["write_wait_d2h"] / 1e3), ("file_phase", gacc["host"]["write_file"] / 1e3)), key=lambda t: t[1])[0],
+                 "note": "this rank's figures; files grammar.<q>.s.gz rewritten in place in the spool directory, slots filled twice before the clock starts; one gzip member per emission group (fixed Huffman codes, back-references from the line structure), every piece of the unique text a series of whole members"}
+
+    if full_dir is not None:                                  # after every timed region: the CPUs and the memory bandwidth are free
+        full_res = run_cpu_full_corpus(ex, full_dir, args)
+        if cpu_res is not None:
+            cpu_res["full_corpus"] = full_res
 
     if rank == 0:
         line = {"metric": "query sentences/sec", "value": round(total_q / dt, 3), "unit": "query sentences/s", "rules_per_s": round(total_rules / dt, 1),
@@ -420,6 +523,9 @@ def main():
                 "scaling": cfg["scaling"], "vs_baseline": None, "dtype": "i32", "data": "synthetic",
                 # value = files rewritten in place in one spool directory per rank (page-cache friendly); the same path into new directories:
                 "value_fresh_files": fresh["value"], "fresh_files": fresh,
+                # the same steps writing grammar.<q>.s.gz, the gzip members made by the GPU formatter
+                "value_gz": gzres["value"], "gz": gzres,
+                "query_batches_rotated": nsets, "append_pass_reruns_per_step": round(append_reruns / max(steps, 1), 3),
                 # the GPU stages alone (lookup .. text layout, hipEvent-timed per stage), without DMA and file phases: what scales with the GPU count by construction
                 "value_gpu_chain": round(sum(r["queries"] for r in ranks) / max(max(r["gpu_chain_s"] for r in ranks), 1e-9), 3),
                 "per_rank": {"gpu_chain_ms_per_step": [round(min(r["gpu_chain_s"] for r in ranks) / max(steps, 1) * 1e3, 2), round(max(r["gpu_chain_s"] for r in ranks) / max(steps, 1) * 1e3, 2)],
@@ -519,6 +625,13 @@ def report(ex, args, cfg, L):
                          microbench_random_128B_runs_per_s_eight_lanes_per_run=pk["random_read_peak"].get("runs_per_s_128B_eight_lanes_per_run_8B_offsets"),   # tools/micro/gather_coop: the way the kernels read their windows now (runs at random 8-byte offsets)
                          dram_read_requests_per_s=round(kk["TCC_EA0_RDREQ_per_batch"] / (ms * 1e-3), 1))   # against 3.0e10 (64-byte) .. 5.2e10 (16-byte) random reads per second of the card: the bound that applies
             by_time.append(e)
+    by_time.sort(key=lambda e: -e["ms_per_launch"])              # roofline_dominant = the kernel that takes the most time per batch
+    gb = lambda k: round(max(ex.stage_ms(k), 0.0) / 1e9, 2)
+    hbm = {"index_as_broadcast": gb("mem_index"), "derived_tables": gb("mem_derived"), "derived_ngram_tables": gb("mem_derived_ngram_tables"), "derived_interleaved_layouts_and_target_blocks": gb("mem_derived_layouts"),
+           "derived_lexical_pair_hash": gb("mem_derived_lex_hash"), "text_slots_and_piece_lists": gb("mem_text"), "last_batch_results": gb("mem_batch"),
+           "allocator_idle_blocks_kept_for_the_next_batch": gb("mem_cached"), "other_live_blocks": gb("mem_other")}
+    hbm["hip_runtime_torch_and_unaccounted"] = round((total_b - free_b) / 1e9 - sum(hbm[k] for k in ("index_as_broadcast", "derived_tables", "text_slots_and_piece_lists", "last_batch_results", "allocator_idle_blocks_kept_for_the_next_batch", "other_live_blocks")), 2)
+    hbm["note"] = "GB, after the timed steps; idle blocks = the high-water mark of a batch's temporaries (lookup outputs, sort buffers, hit lists) held by the caching allocator for reuse"
     div = steps * 1.0
     out = {
         "config": {"workload": cfg["what"], "name": args.config, "sentence_pairs": cfg["pairs"], "source_tokens": n_src, "vocab": cfg["vocab"],
@@ -538,7 +651,7 @@ def report(ex, args, cfg, L):
         "index": {"build_sa_ms": round(ex.stage_ms("build_sa"), 1), "precompute_ms": round(ex.stage_ms("precompute"), 1), "ngram_tables_ms": round(ex.stage_ms("ngrams"), 1),
                   "ngram_table_bytes": int(max(ex.stage_ms("ngram_table_bytes"), 0)), "broadcast_s": round(L["t_bcast"], 3), "broadcast_bytes": int(L["bcast_bytes"]),
                   "total_s": round(L["t_index"], 2), "corpus_gen_s": round(L["t_gen"], 2), "frequent_pair_hits": c["nphits"]},
-        "hbm_in_use_gb": round((total_b - free_b) / 1e9, 1),
+        "hbm_in_use_gb": round((total_b - free_b) / 1e9, 1), "hbm_breakdown": hbm,
         "counts": {**{k: c[k] for k in ("d1", "d2", "h1", "h2", "g", "n0", "n1", "n2", "guard_exits")},
                    "lexicon_lines": int(max(ex.stage_ms("lex_lines"), 0)), "grammar_lines": int(max(ex.stage_ms("fmt_nlines"), 0)), "emission_items": int(max(ex.stage_ms("fmt_items"), 0)),
                    "unique_text_bytes": int(max(ex.stage_ms("fmt_unique_bytes"), 0)), "segments": int(max(ex.stage_ms("fmt_segments"), 0))},

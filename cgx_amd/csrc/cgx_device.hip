@@ -298,7 +298,7 @@ static int append_pass(cgx_ctx *ctx, uint64_t units, uint64_t chunk, uint64_t W,
         if (rc_got != CGX_OK) { dfree(total); return rc_got; }
         if (got <= out.cap) { out.n = (size_t)got; break; }
         if (attempt) { snprintf(ctx->err, sizeof ctx->err, "append pass overflowed twice"); dfree(total); return CGX_ERR_STATE; }
-        want = (size_t)got;
+        want = (size_t)got; ctx->ms["append_reruns"] += 1.0;   // the capacity guessed from the previous batch was too small: the launch runs once more with the exact size
     }
     if (W) { double r = (double)(out.n - n0) / (double)W * 1.25 + 0.05; if (r > *per_item || r < *per_item * 0.5) *per_item = r; }
     dfree(total);
@@ -545,8 +545,36 @@ extern "C" double cgx_host_ms(cgx_ctx *c, const char *name) {
     auto it = c->host_ms.find(name);
     return it == c->host_ms.end() ? -1.0 : it->second;
 }
+// Device memory by purpose, bytes ("mem_*" names of cgx_stage_ms): what the context holds right now, looked up block by block in
+// the allocator.  index = what a replica receives; derived = tables rebuilt from it on every rank (interleaved layouts, target-side
+// blocks, l-gram tables, pair hash); text = the two text slots and their piece lists; batch = results of the last batch kept for
+// cgx_fetch and the formatter; cached = idle blocks the allocator keeps for the next batch (lookup outputs, sort buffers: the
+// high-water mark of the temporaries); other = live blocks of other contexts on this device.
+static void memory_report(cgx_ctx *c) {
+    std::lock_guard<std::mutex> g(g_pool_lock);
+    DevPool &P = pool_of(c->device);
+    auto sz = [&](const void *p) -> double { if (!p) return 0.0; auto it = P.live.find((void *)p); return it == P.live.end() ? 0.0 : (double)it->second.bytes; };
+    double index = 0, derived = 0, text = 0, batch = 0;
+    for (const void *p : {(const void *)c->d_str, (const void *)c->d_sa, (const void *)c->d_rlp, (const void *)c->d_tstr, (const void *)c->d_ltar, (const void *)c->d_rtar, (const void *)c->d_ltar16, (const void *)c->d_rtar16,
+                          (const void *)c->d_lexkey, (const void *)c->d_lexv1, (const void *)c->d_lexv2, (const void *)c->d_lexn1, (const void *)c->d_lexn2, (const void *)c->d_lexrow, (const void *)c->d_lexnullt,
+                          (const void *)c->d_tokstart, (const void *)c->d_tokrank, (const void *)c->d_freq, (const void *)c->d_pidx, (const void *)c->d_miss, (const void *)c->d_phit_start, (const void *)c->d_phit_len,
+                          (const void *)c->d_spool, (const void *)c->d_soff, (const void *)c->d_tpool, (const void *)c->d_toff, (const void *)c->d_aa, (const void *)c->d_bb, (const void *)c->d_fs, (const void *)c->d_gztab}) index += sz(p);
+    double ngram = 0; for (int k = 0; k < 4; k++) ngram += sz(c->d_ng[k]);
+    const double layouts = sz(c->d_tok8) + sz(c->d_lr16) + sz(c->d_lrs) + sz(c->d_pos1), lexhash = sz(c->d_lexslot) + sz(c->d_lexnullv) + sz(c->d_lexhkey) + sz(c->d_lexhidx);
+    derived = ngram + layouts + lexhash;
+    for (int a = 0; a < 2; a++) text += sz(c->d_text[a]) + sz(c->d_qtext[a]) + sz(c->d_seg_off[a]) + sz(c->d_seg_len[a]) + sz(c->d_qseg[a]);
+    for (const void *p : {(const void *)c->d_qoff, (const void *)c->d_qtok, (const void *)c->d_tok2q, (const void *)c->d_lm, (const void *)c->d_up, (const void *)c->d_down,
+                          (const void *)c->d_g1, (const void *)c->d_p1, (const void *)c->d_pid1, (const void *)c->d_s1, (const void *)c->d_hits1, (const void *)c->d_g2, (const void *)c->d_c2, (const void *)c->d_pid2, (const void *)c->d_s2, (const void *)c->d_hits2,
+                          (const void *)c->d_p1d, (const void *)c->d_c2d, (const void *)c->d_one2, (const void *)c->d_blocks, (const void *)c->d_r0, (const void *)c->d_r1, (const void *)c->d_r2,
+                          (const void *)c->d_rng0, (const void *)c->d_rng1, (const void *)c->d_rng2, (const void *)c->d_lex0, (const void *)c->d_lex1, (const void *)c->d_lex2,
+                          (const void *)c->d_qb_off, (const void *)c->d_qb_ids, (const void *)c->d_qo_off, (const void *)c->d_qo_ids, (const void *)c->d_qt_off, (const void *)c->d_qt_ids}) batch += sz(p);
+    double live = 0; for (auto &kv : P.live) live += (double)kv.second.bytes;
+    c->ms["mem_index"] = index; c->ms["mem_derived"] = derived; c->ms["mem_derived_ngram_tables"] = ngram; c->ms["mem_derived_layouts"] = layouts; c->ms["mem_derived_lex_hash"] = lexhash;
+    c->ms["mem_text"] = text; c->ms["mem_batch"] = batch; c->ms["mem_cached"] = (double)P.cached_bytes; c->ms["mem_other"] = live - index - derived - text - batch;
+}
 extern "C" double cgx_stage_ms(cgx_ctx *c, const char *name) {
     if (!c || !name) return -1;
+    if (!strncmp(name, "mem_", 4)) memory_report(c);
     auto it = c->ms.find(name);
     return it == c->ms.end() ? -1.0 : it->second;
 }

@@ -164,10 +164,14 @@ template <class S> CGX_HD void fmt_target(S &o, const fmt_view &F, int kind, con
         else fmt_word(o, F.tpool, F.toff, F.nt, 't', F.tstr[jj]);
     }
 }
-template <class S> CGX_HD bool fmt_line(S &o, const fmt_view &F, int kind, const cgx_lexent &e) {
+CGX_HD void fmt_note(CountSink &o, uint32_t *at) { if (at) *at = o.n; }
+template <class S> CGX_HD void fmt_note(S &, uint32_t *) {}
+// tail_at (counting sink only): where the features start, " ||| EgivenFCoherent=" -- the gzip members refer to the previous line's tail by it
+template <class S> CGX_HD bool fmt_line(S &o, const fmt_view &F, int kind, const cgx_lexent &e, uint32_t *tail_at = nullptr) {
     bool ok = true;
     FMT_LIT(o, "[X] ||| "); fmt_source(o, F, kind, (uint32_t)e.id); FMT_LIT(o, " ||| ");
     fmt_target(o, F, kind, e);
+    fmt_note(o, tail_at);
     if (e.paircount >= FMT_TABN || e.fsample >= FMT_TABN || e.fsample == 0) ok = false;
     uint32_t pc = e.paircount < FMT_TABN ? e.paircount : 0, f = e.fsample < FMT_TABN ? e.fsample : 0;
     FMT_LIT(o, " ||| EgivenFCoherent="); ok &= fmt_f6(o, F.aa[pc * FMT_TABN + f]);
@@ -225,6 +229,13 @@ CGX_HD uint32_t gz_brev(uint32_t x, uint32_t nbits) {            // the low nbit
     uint32_t r = 0; for (uint32_t i = 0; i < nbits; i++) r |= ((x >> i) & 1u) << (nbits - 1u - i); return r;
 #endif
 }
+CGX_HD uint32_t gz_brev_bytes(uint32_t x) {                      // every byte of x reversed in place
+#if defined(__clang__)
+    return __builtin_bswap32(__builtin_bitreverse32(x));
+#else
+    x = ((x & 0xF0F0F0F0u) >> 4) | ((x & 0x0F0F0F0Fu) << 4); x = ((x & 0xCCCCCCCCu) >> 2) | ((x & 0x33333333u) << 2); return ((x & 0xAAAAAAAAu) >> 1) | ((x & 0x55555555u) << 1);
+#endif
+}
 CGX_HD uint32_t gz_log2(uint32_t x) { return 31u - (uint32_t)__builtin_clz(x); }   // x > 0
 
 // bit sinks: the counting pass only adds, the writing pass packs LSB-first and hands whole 32-bit words to a byte sink
@@ -238,7 +249,7 @@ struct BitCount {
 template <class S> struct BitOut {
     S &o; uint64_t acc; uint32_t nb, n;
     CGX_HD explicit BitOut(S &s) : o(s), acc(0), nb(0), n(0) {}
-    CGX_HD void bits(uint32_t code, uint32_t len) {              // len <= 16, code < 2^len
+    CGX_HD void bits(uint32_t code, uint32_t len) {              // len <= 32, code < 2^len
         acc |= (uint64_t)code << nb; nb += len; n += len;
         if (nb >= 32u) { o.wide(acc & 0xFFFFFFFFull, 4); acc >>= 32; nb -= 32u; }
     }
@@ -258,20 +269,32 @@ CGX_HD uint32_t gz_multmodp(uint32_t a, uint32_t b) {
     }
     return p;
 }
-// tables, 5 x 256 words: [0] the byte-wise CRC table; [1 + j][d] = x^(8 * d * 256^j) mod P, j = 0..3
-#define GZ_TAB_WORDS (5 * 256)
+// Tables, 12 x 256 words.  [k][x], k = 0..7: the CRC register after byte x and k zero bytes, started from 0 ("slicing": a group of
+// n <= 8 bytes is folded in with n independent look-ups instead of n dependent ones; the kernel keeps these 8 KB in LDS).
+// [8 + j][d] = x^(8 * d * 256^j) mod P, j = 0..3: the factors of x^(8 * n).
+#define GZ_CRC_WORDS (8 * 256)
+#define GZ_TAB_WORDS (12 * 256)
 CGX_HD uint32_t gz_x8n(const uint32_t *tab, uint64_t nbytes) {   // x^(8 * nbytes) mod P, nbytes < 2^32
-    uint32_t r = tab[256 + (nbytes & 255u)];
+    uint32_t r = tab[GZ_CRC_WORDS + (nbytes & 255u)];
     CGX_UNROLL
-    for (int j = 1; j < 4; j++) { const uint32_t d = (uint32_t)(nbytes >> (8 * j)) & 255u; if (d) r = gz_multmodp(tab[256 * (j + 1) + d], r); }
+    for (int j = 1; j < 4; j++) { const uint32_t d = (uint32_t)(nbytes >> (8 * j)) & 255u; if (d) r = gz_multmodp(tab[GZ_CRC_WORDS + 256 * j + d], r); }
+    return r;
+}
+// the CRC register after the low n (1..8) bytes of v
+CGX_HD uint32_t gz_crc_group(const uint32_t *tab, uint32_t crc, uint64_t v, uint32_t n) {
+    const uint64_t w = v ^ (uint64_t)crc;
+    uint32_t r = n < 4u ? crc >> (8u * n) : 0u;
+    CGX_UNROLL
+    for (uint32_t i = 0; i < 8u; i++) if (i < n) r ^= tab[((n - 1u - i) << 8) + ((uint32_t)(w >> (8u * i)) & 255u)];
     return r;
 }
 inline void gz_make_tables(uint32_t *tab) {                      // host only
     for (uint32_t i = 0; i < 256; i++) { uint32_t c = i; for (int k = 0; k < 8; k++) c = (c & 1u) ? (c >> 1) ^ GZ_POLY : c >> 1; tab[i] = c; }
+    for (int k = 1; k < 8; k++) for (uint32_t i = 0; i < 256; i++) { const uint32_t c = tab[256 * (k - 1) + i]; tab[256 * k + i] = (c >> 8) ^ tab[c & 255u]; }
     uint32_t x8 = 0x80000000u; for (int k = 0; k < 8; k++) x8 = (x8 & 1u) ? (x8 >> 1) ^ GZ_POLY : x8 >> 1;    // x^8
     uint32_t step = x8;
     for (int j = 0; j < 4; j++) {
-        uint32_t *t = tab + 256 * (j + 1); t[0] = 0x80000000u;
+        uint32_t *t = tab + GZ_CRC_WORDS + 256 * j; t[0] = 0x80000000u;
         for (uint32_t d = 1; d < 256; d++) t[d] = gz_multmodp(t[d - 1], step);
         step = gz_multmodp(t[255], step);                        // x^(8 * 256^(j+1))
     }
@@ -296,11 +319,19 @@ template <class B, bool CRC> struct GzSink {
     // the bytes that follow stood `dist` bytes earlier in this member / are new
     CGX_HD void match(uint32_t dist) { if (inm && dist == mdist) return; flush(); inm = dist >= 1u && dist <= 32768u; mdist = dist; }
     CGX_HD void lit() { flush(); inm = false; }
-    CGX_HD void feed(uint64_t v, uint32_t n) {                   // the low n <= 8 bytes of v
+    CGX_HD void feed(uint64_t v, uint32_t n) {                   // the low n (1..8) bytes of v
         pos += n;
-        if (CRC) { uint64_t w = v; for (uint32_t i = 0; i < n; i++) { crc = tab[(crc ^ (uint32_t)w) & 255u] ^ (crc >> 8); w >>= 8; } }
+        if (CRC) crc = gz_crc_group(tab, crc, v, n);
         if (inm) { mlen += n; if (mlen >= 258u) { emit_match(255u, mdist); mlen -= 255u; } }      // what stays pending is again >= 3
-        else for (uint32_t i = 0; i < n; i++) { const uint32_t c = (uint32_t)(v >> (8u * i)) & 255u; if (c < 144u) b.bits(gz_brev(0x30u + c, 8), 8); else b.bits(gz_brev(0x100u + c, 9), 9); }
+        else {
+            const uint64_t m = n < 8u ? v & ((1ull << (8u * n)) - 1ull) : v;
+            if ((m & 0x8080808080808080ull) == 0) {              // ASCII: eight-bit codes 0x30 + c, all bytes of the group at once
+                const uint64_t x = m + (0x3030303030303030ull & (n < 8u ? (1ull << (8u * n)) - 1ull : ~0ull));
+                b.bits(gz_brev_bytes((uint32_t)x), n < 4u ? 8u * n : 32u);
+                if (n > 4u) b.bits(gz_brev_bytes((uint32_t)(x >> 32)), 8u * (n - 4u));
+            }
+            else for (uint32_t i = 0; i < n; i++) { const uint32_t c = (uint32_t)(v >> (8u * i)) & 255u; if (c < 144u) b.bits(gz_brev(0x30u + c, 8), 8); else b.bits(gz_brev(0x100u + c, 9), 9); }
+        }
     }
     CGX_HD void put(char c) { feed((uint64_t)(uint8_t)c, 1); }
     CGX_HD void puts(const char *s, uint32_t len) { for (uint32_t i = 0; i < len; i++) put(s[i]); }
@@ -314,15 +345,18 @@ template <class B, bool CRC> struct GzSink {
 struct gz_place {
     bool first, last;        // first / last line of its emission group
     bool same_item;          // the line before it belongs to the same canonical item: same source side
-    uint32_t prev_len;       // characters of the line before it (first == false)
-    float pv[5]; bool pf1, pf2;   // that line's five feature values and two flags
+    uint32_t prev_len, prev_tail;   // characters of the line before it, and where its features start (first == false)
+    const cgx_lexent *pe;    // that line's lexicon entry: its feature values are fetched where they are compared, not held
 };
-CGX_HD void gz_place_prev(gz_place &P, const fmt_view &F, const cgx_lexent &pe) {
-    const uint32_t pc = pe.paircount < FMT_TABN ? pe.paircount : 0, f = pe.fsample < FMT_TABN ? pe.fsample : 0;
-    P.pv[0] = F.aa[pc * FMT_TABN + f]; P.pv[1] = F.fs[f]; P.pv[2] = F.bb[pc]; P.pv[3] = pe.fe; P.pv[4] = pe.ef;
-    P.pf1 = pe.f == 1; P.pf2 = pe.paircount == 1;
-}
 CGX_HD bool gz_same_bits(float a, float b) { union { float f; uint32_t u; } x, y; x.f = a; y.f = b; return x.u == y.u; }
+// one feature value: in the running match when it is the previous line's value, literal otherwise; the distance moves by the difference of the two lengths
+template <class Z> CGX_HD bool gz_value(Z &z, float v, float pv, uint32_t &dist) {
+    const uint32_t p0 = z.pos;
+    if (!gz_same_bits(v, pv)) z.lit();
+    const bool ok = fmt_f6(z, v);
+    dist += (z.pos - p0) - fmt_f6_len(pv);
+    return ok;
+}
 #define GZ_MIN_LINE 16u      // the byte sink of the writing kernel needs every line to reach past its first 16-byte unit
 // One line of a member.  Returns false when the line cannot be represented (the batch is then formatted on the host).
 // Bytes: [gzip header, first line only] fixed block { symbols, end of block } empty stored block(s) [8 bytes for CRC-32 and ISIZE, last line only]
@@ -343,23 +377,18 @@ template <class B, bool CRC> CGX_HD bool fmt_line_gz(B &b, GzSink<B, CRC> &z, co
     const float v0 = F.aa[pc * FMT_TABN + f], v1 = F.fs[f], v2 = F.bb[pc];
     const bool f1 = e.f == 1, f2 = e.paircount == 1;
     if (prev) {
-        // rem = characters of the previous line from the point that corresponds to this one: the distance is pos + rem
-        const uint32_t l0 = fmt_f6_len(P.pv[0]), l1 = fmt_f6_len(P.pv[1]), l2 = fmt_f6_len(P.pv[2]), l3 = fmt_f6_len(P.pv[3]), l4 = fmt_f6_len(P.pv[4]);
-        uint32_t rem = 106u + l0 + l1 + l2 + l3 + l4;
-        z.match(z.pos + rem); FMT_LIT(z, " ||| EgivenFCoherent="); rem -= 21u;
-        if (!gz_same_bits(v0, P.pv[0])) z.lit(); ok &= fmt_f6(z, v0); rem -= l0;
-        z.match(z.pos + rem); FMT_LIT(z, " SampleCountF="); rem -= 14u;
-        if (!gz_same_bits(v1, P.pv[1])) z.lit(); ok &= fmt_f6(z, v1); rem -= l1;
-        z.match(z.pos + rem); FMT_LIT(z, " CountEF="); rem -= 9u;
-        if (!gz_same_bits(v2, P.pv[2])) z.lit(); ok &= fmt_f6(z, v2); rem -= l2;
-        z.match(z.pos + rem); FMT_LIT(z, " MaxLexFgivenE="); rem -= 15u;
-        if (!gz_same_bits(e.fe, P.pv[3])) z.lit(); ok &= fmt_f6(z, e.fe); rem -= l3;
-        z.match(z.pos + rem); FMT_LIT(z, " MaxLexEgivenF="); rem -= 15u;
-        if (!gz_same_bits(e.ef, P.pv[4])) z.lit(); ok &= fmt_f6(z, e.ef); rem -= l4;
-        z.match(z.pos + rem); FMT_LIT(z, " IsSingletonF="); rem -= 14u;
-        if (f1 != P.pf1) z.lit(); z.put(f1 ? '1' : '0'); rem -= 1u;
-        z.match(z.pos + rem); FMT_LIT(z, " IsSingletonFE=");
-        if (f2 != P.pf2) z.lit(); z.put(f2 ? '1' : '0'); z.put('\n');    // the line feed alone would be a match of one character: it goes the way of the flag
+        // the distance to the same place of the previous line: what is left of that line plus what this line has so far
+        uint32_t dist = z.pos + P.prev_len - P.prev_tail;
+        const uint32_t ppc = P.pe->paircount < FMT_TABN ? P.pe->paircount : 0, pf = P.pe->fsample < FMT_TABN ? P.pe->fsample : 0;
+        z.match(dist); FMT_LIT(z, " ||| EgivenFCoherent="); ok &= gz_value(z, v0, F.aa[ppc * FMT_TABN + pf], dist);
+        z.match(dist); FMT_LIT(z, " SampleCountF="); ok &= gz_value(z, v1, F.fs[pf], dist);
+        z.match(dist); FMT_LIT(z, " CountEF="); ok &= gz_value(z, v2, F.bb[ppc], dist);
+        z.match(dist); FMT_LIT(z, " MaxLexFgivenE="); ok &= gz_value(z, e.fe, P.pe->fe, dist);
+        z.match(dist); FMT_LIT(z, " MaxLexEgivenF="); ok &= gz_value(z, e.ef, P.pe->ef, dist);
+        z.match(dist); FMT_LIT(z, " IsSingletonF=");
+        if (f1 != (P.pe->f == 1)) z.lit(); z.put(f1 ? '1' : '0');
+        z.match(dist); FMT_LIT(z, " IsSingletonFE=");
+        if (f2 != (P.pe->paircount == 1)) z.lit(); z.put(f2 ? '1' : '0'); z.put('\n');    // the line feed alone would be a match of one character: it goes the way of the flag
     } else {
         z.match(z.pos - 3u); FMT_LIT(z, " ||| "); z.lit(); FMT_LIT(z, "EgivenFCoherent="); ok &= fmt_f6(z, v0);
         FMT_LIT(z, " SampleCountF="); ok &= fmt_f6(z, v1);

@@ -159,7 +159,10 @@ int64_t cgx_fetch(cgx_ctx *ctx, const char *name, void *dst, int64_t cap);
 int cgx_fetch_pinned(cgx_ctx *ctx, const char *name, void **out, int64_t *nbytes);
 int cgx_pinned_next_batch(cgx_ctx *ctx);
 /* last-stage timings in milliseconds (hipEvent): "sa_lookup" "gappy" "extract" "lex" "build_sa" "precompute";
- * "sa_lookup_kernel" is the batched interval-search kernel alone */
+ * "sa_lookup_kernel" is the batched interval-search kernel alone.  Other tallies come through the same call: "append_reruns" (lookup launches repeated
+ * because the output capacity remembered from the previous batch was too small, cumulative), "fmt_unique_bytes" / "fmt_plain_unique_bytes" (the
+ * unique text of the last batch as laid out / before compression), and the device memory the context holds, in bytes: "mem_index" "mem_derived"
+ * ("mem_derived_ngram_tables" "mem_derived_layouts" "mem_derived_lex_hash") "mem_text" "mem_batch" "mem_cached" "mem_other" */
 double cgx_stage_ms(cgx_ctx *ctx, const char *name);
 
 /* ---- whole-path host driver (what the CLI calls): text files in, grammar files out ---- */

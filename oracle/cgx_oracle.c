@@ -413,6 +413,7 @@ orc_index *orc_index_load(const char *src, const char *tgt, const char *align, c
     return ix;
 }
 
+static int g_tables_follow;      /* orc_index_from_arrays_pre: the caller fills the frequent-pair tables */
 orc_index *orc_index_from_arrays(const int32_t *str, uint32_t n, const int32_t *sentind, int32_t nsent,
                                  const int32_t *tstr, uint32_t nt, const int32_t *tsentind,
                                  const uint8_t *lsrc, const uint8_t *rsrc, const uint8_t *ltar, const uint8_t *rtar,
@@ -441,7 +442,26 @@ orc_index *orc_index_from_arrays(const int32_t *str, uint32_t n, const int32_t *
     char buf[32];
     for (int32_t i = 2; i <= maxs; i++) { snprintf(buf, sizeof buf, "s%d", i); ix->svocab[i] = xstrdup(buf); }
     for (int32_t i = 2; i <= maxt; i++) { snprintf(buf, sizeof buf, "t%d", i); ix->tvocab[i] = xstrdup(buf); }
-    if (orc_precompute(ix)) DIE("fewer than %d distinct source tokens", ORC_TOP);
+    if (!g_tables_follow && orc_precompute(ix)) DIE("fewer than %d distinct source tokens", ORC_TOP);
+    return ix;
+}
+/* The same with the suffix array AND the frequent-pair tables handed in: nothing is built here.  bench.py's CPU leg on the whole
+ * benchmark corpus uses it with the tables the product built on the GPU (tests/test_gpu_parity.py compares exactly these arrays with
+ * orc_build_sa / orc_precompute stage by stage), so that the leg times the per-query path (SuffixArray.cu:1342-2269,
+ * ExtractPair.cu:3215-4001 restated) and not ten minutes of single-thread index construction. */
+orc_index *orc_index_from_arrays_pre(const int32_t *str, uint32_t n, const int32_t *sentind, int32_t nsent,
+                                     const int32_t *tstr, uint32_t nt, const int32_t *tsentind,
+                                     const uint8_t *lsrc, const uint8_t *rsrc, const uint8_t *ltar, const uint8_t *rtar,
+                                     const orc_lexkey *lexk, const orc_lexval *lexv, uint32_t nlex, const int32_t *sa,
+                                     const int32_t *freq, const uint32_t *pidx, const int32_t *miss, const uint32_t *phit_start, const uint8_t *phit_len, uint32_t nphits) {
+    if (!sa || !freq || !pidx || !miss || (nphits && (!phit_start || !phit_len))) return NULL;
+    g_tables_follow = 1;
+    orc_index *ix = orc_index_from_arrays(str, n, sentind, nsent, tstr, nt, tsentind, lsrc, rsrc, ltar, rtar, lexk, lexv, nlex, sa);
+    g_tables_follow = 0;
+    memcpy(ix->freq, freq, sizeof ix->freq); memcpy(ix->miss, miss, sizeof ix->miss);
+    for (int i = 0; i < ORC_TOP * ORC_TOP; i++) { ix->pidx[i].start = pidx[2 * i]; ix->pidx[i].end = pidx[2 * i + 1]; }
+    ix->nphits = nphits; ix->phits = xmalloc(((size_t)nphits + 1) * sizeof *ix->phits);
+    for (uint32_t i = 0; i < nphits; i++) { ix->phits[i].start = phit_start[i]; ix->phits[i].length = phit_len[i]; }
     return ix;
 }
 

@@ -155,6 +155,12 @@ orc_index *orc_index_from_arrays(const int32_t *str, uint32_t n, const int32_t *
                                  const uint8_t *ltar, const uint8_t *rtar,
                                  const orc_lexkey *lexk, const orc_lexval *lexv, uint32_t nlex,
                                  const int32_t *sa);
+/* the same with the suffix array and the frequent-pair tables handed in (the layouts of cgx_fetch "sa" "freq" "pidx" "miss" "phit_start" "phit_len"); nothing is built */
+orc_index *orc_index_from_arrays_pre(const int32_t *str, uint32_t n, const int32_t *sentind, int32_t nsent,
+                                     const int32_t *tstr, uint32_t nt, const int32_t *tsentind,
+                                     const uint8_t *lsrc, const uint8_t *rsrc, const uint8_t *ltar, const uint8_t *rtar,
+                                     const orc_lexkey *lexk, const orc_lexval *lexv, uint32_t nlex, const int32_t *sa,
+                                     const int32_t *freq, const uint32_t *pidx, const int32_t *miss, const uint32_t *phit_start, const uint8_t *phit_len, uint32_t nphits);
 void orc_index_free(orc_index *ix);
 void orc_set_long_sentences(int on);   /* before orc_index_load: accept sentences of 255+ tokens (source < 1024, target < 2040); default off = the reference's byte positions */
 void orc_build_sa(const int32_t *str, uint32_t n, int32_t *sa);

@@ -100,11 +100,16 @@ static int run_case(uint32_t G, uint32_t D1, uint32_t D2, uint32_t ns, uint32_t 
     }
     const uint32_t NU = (uint32_t)line_ent.size(); cstart[NC] = NU;
     uint32_t tab[GZ_TAB_WORDS]; gz_make_tables(tab);
+    for (int t = 0; t < 200; t++) {                             // the group-wise CRC against zlib, every group length
+        unsigned char buf[64]; uint32_t crc = 0xFFFFFFFFu; size_t at = 0; for (auto &c : buf) c = (unsigned char)rr(256);
+        while (at < 56) { const uint32_t n = 1 + rr(8); uint64_t v; memcpy(&v, buf + at, 8); crc = gz_crc_group(tab, crc, v, n); at += n; }
+        if ((crc ^ 0xFFFFFFFFu) != (uint32_t)crc32(0, buf, (uInt)at)) { fprintf(stderr, "gz_crc_group disagrees with zlib\n"); return 1; }
+    }
     // pass 1: plain lengths; the plain text itself is the expectation
-    std::vector<uint32_t> len_u(NU); std::vector<uint64_t> U(NU + 1, 0); std::vector<std::string> plain(NU);
+    std::vector<uint32_t> len_u(NU), tail_u(NU); std::vector<uint64_t> U(NU + 1, 0); std::vector<std::string> plain(NU);
     for (uint32_t l = 0; l < NU; l++) {
         const int kind = (int)(line_ent[l] >> 30); const cgx_lexent &e = F.lex[kind][line_ent[l] & 0x3FFFFFFFu];
-        CountSink cs{0}; fmt_line(cs, F, kind, e); len_u[l] = cs.n;
+        CountSink cs{0}; fmt_line(cs, F, kind, e, &tail_u[l]); len_u[l] = cs.n;
         std::vector<char> buf(cs.n + 16); MemSink ms{buf.data()}; if (!fmt_line(ms, F, kind, e)) { fprintf(stderr, "plain line not representable\n"); return 1; }
         if ((uint32_t)(ms.p - buf.data()) != cs.n) { fprintf(stderr, "plain count != plain write\n"); return 1; }
         plain[l].assign(buf.data(), cs.n); U[l + 1] = U[l] + cs.n;
@@ -113,7 +118,7 @@ static int run_case(uint32_t G, uint32_t D1, uint32_t D2, uint32_t ns, uint32_t 
         const uint32_t ci = line_c[l], g = canon_group(ci, G, D1), l0 = cstart[canon_group_first(g, G, D1)], l1 = cstart[canon_group_first(g + 1, G, D1)];
         memset(&P, 0, sizeof P);
         P.first = l == l0; P.last = l + 1 == l1; P.same_item = l > cstart[ci];
-        if (!P.first) { const int pk = (int)(line_ent[l - 1] >> 30); gz_place_prev(P, F, F.lex[pk][line_ent[l - 1] & 0x3FFFFFFFu]); P.prev_len = len_u[l - 1]; }
+        if (!P.first) { const int pk = (int)(line_ent[l - 1] >> 30); P.pe = &F.lex[pk][line_ent[l - 1] & 0x3FFFFFFFu]; P.prev_len = len_u[l - 1]; P.prev_tail = tail_u[l - 1]; }
         return l1;
     };
     // pass 2: compressed lengths

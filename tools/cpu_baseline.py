@@ -81,8 +81,71 @@ def _forked(job):
     return run_queries(_G["lib"], _G["ix"], _G["qoff"], _G["qtok"], a, b, _G["scratch"])
 
 
+def full_corpus_leg(args, lib, cores, usable, ncpu_online, scratch):
+    """--full-dir: the benchmark's OWN corpus (the arrays bench.py generated, the suffix array and the frequent-pair tables the product
+    built on the GPU, saved by bench.py after its timed region) and the first queries of its first batch: the per-query path on
+    one core and on all cores against the whole corpus -- occurrence lists grow with the corpus, so the rate on a 2 % sample is
+    not the rate on the benchmark's inputs."""
+    d = args.full_dir
+    ld = lambda k: np.load(os.path.join(d, k + ".npy"), mmap_mode="r")
+    keys = ("str", "sentind", "tstr", "tsentind", "lsrc", "rsrc", "ltar", "rtar", "lexk", "lexv", "sa", "freq", "pidx", "miss", "phit_start", "phit_len", "qoff", "qtok")
+    t0 = time.perf_counter()
+    A = {k: np.ascontiguousarray(ld(k)) for k in keys}
+    lib.orc_index_from_arrays_pre.restype = VP
+    lib.orc_index_from_arrays_pre.argtypes = [VP, C.c_uint32, VP, C.c_int32, VP, C.c_uint32, VP, VP, VP, VP, VP, VP, VP, C.c_uint32, VP, VP, VP, VP, VP, VP, C.c_uint32]
+    ix = lib.orc_index_from_arrays_pre(ptr(A["str"]), len(A["str"]), ptr(A["sentind"]), len(A["sentind"]) - 1, ptr(A["tstr"]), len(A["tstr"]), ptr(A["tsentind"]), ptr(A["lsrc"]), ptr(A["rsrc"]),
+                                       ptr(A["ltar"]), ptr(A["rtar"]), ptr(A["lexk"]), ptr(A["lexv"]), len(A["lexk"]), ptr(A["sa"]),
+                                       ptr(A["freq"]), ptr(A["pidx"]), ptr(A["miss"]), ptr(A["phit_start"]), ptr(A["phit_len"]), len(A["phit_start"]))
+    if not ix:
+        return {"error": "orc_index_from_arrays_pre refused the tables"}
+    n_src = int(len(A["str"])); qoff = np.asarray(A["qoff"], np.int64); qtok = A["qtok"]
+    for k in keys[:-2]:
+        A.pop(k)                                               # the oracle holds its own copies
+    t_load = time.perf_counter() - t0
+    nq_have = len(qoff); want = min(args.full_queries, nq_have)
+    # one core: batches of 8 queries until `want` are done or the time cap is reached (at least 8)
+    done = 0; dt1 = 0.0; lines1 = 0; st1 = {}
+    while done < want and (done < 8 or dt1 < args.full_seconds):
+        b = min(done + 8, want)
+        dt, ln, st = run_queries(lib, ix, qoff, qtok, done, b, scratch)
+        dt1 += dt; lines1 += ln; done = b
+        for k, v in st.items():
+            st1[k] = round(st1.get(k, 0.0) + v, 4)
+    res = {"source_tokens": n_src, "load_s": round(t_load, 2),
+           "one_core": {"value": round(done / dt1, 4), "rules_per_s": round(lines1 / dt1, 1), "cores": 1, "queries": done, "seconds": round(dt1, 3), "stages_s": st1, "batch_queries": 8}}
+    # all cores: every forked worker runs its own 8-query batches of the following queries, for about the same time
+    per_q = dt1 / max(done, 1)
+    each = int(max(8, min((nq_have - want) // max(cores, 1), 8 * round(min(args.full_seconds, dt1) / per_q / 8 + 0.5)))) if nq_have - want >= 8 * cores else 0
+    if each:
+        _G.update(lib=lib, ix=ix, qoff=qoff, qtok=qtok, scratch=scratch)
+        jobs = [(want + k * each, want + (k + 1) * each) for k in range(cores)]
+        w0 = time.perf_counter()
+        with mp.get_context("fork").Pool(cores) as pool:
+            outs = pool.map(_forked8, jobs, chunksize=1)
+        wall = time.perf_counter() - w0
+        slow = max(o[0] for o in outs)
+        res["all_cores"] = {"value": round(cores * each / slow, 3), "rules_per_s": round(sum(o[1] for o in outs) / slow, 1), "cores": cores, "queries": cores * each, "seconds": round(slow, 3),
+                            "wall_seconds_with_fork": round(wall, 3), "batch_queries": 8}
+        res["value"] = res["all_cores"]["value"]; res["cores"] = cores
+    res["sample"] = ("the benchmark's own corpus (N=%d source tokens) with the suffix array and frequent-pair tables the product built on the GPU; queries %d.. of the first timed batch in "
+                     "batches of 8: %d on one core%s; C restatement of the whole per-query path incl. file writing" % (n_src, 0, done, (", %d x %d on %d forked workers" % (cores, each, cores)) if each else ""))
+    lib.orc_index_free(ix)
+    return res
+
+
+def _forked8(job):
+    a, b = job; tot = 0.0; lines = 0
+    for x in range(a, b, 8):
+        dt, ln, _ = run_queries(_G["lib"], _G["ix"], _G["qoff"], _G["qtok"], x, min(x + 8, b), _G["scratch"])
+        tot += dt; lines += ln
+    return tot, lines
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--full-dir", default=None, help="directory with the benchmark's own corpus arrays, GPU-built suffix array and frequent-pair tables and queries (.npy, written by bench.py): run ONLY the full-corpus leg")
+    ap.add_argument("--full-queries", type=int, default=64, help="queries of the one-core leg on the full corpus")
+    ap.add_argument("--full-seconds", type=float, default=60.0, help="time cap of each full-corpus leg (at least 8 queries run whatever it says)")
     ap.add_argument("--pairs", type=int, default=200000, help="sentence pairs of the sample corpus")
     ap.add_argument("--vocab", type=int, default=200000)
     ap.add_argument("--seed", type=int, default=1234)
@@ -104,6 +167,9 @@ def main():
     cores = args.cores if args.cores > 0 else usable
     lib = load_oracle()
     scratch = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+    if args.full_dir:
+        print(json.dumps(full_corpus_leg(args, lib, cores, usable, ncpu_online, scratch))); sys.stdout.flush()
+        return
 
     t0 = time.perf_counter()
     corpus = synth.make_corpus(args.pairs, args.vocab, args.seed)        # same model, vocabulary and seed as the benchmark corpus, fewer sentence pairs
