@@ -182,6 +182,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; nccl (= RCCL over xGMI) for real runs, gloo only to rehearse N>1 on a one-GPU box")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--bcast", choices=("torch", "c"), default="torch", help="index broadcast: torch = torch.distributed.broadcast (RCCL) on a staging tensor per buffer; c = the library's own cgx_broadcast_index on an RCCL communicator made here (what a C host would call)")
+    ap.add_argument("--force-dist", action="store_true", help="with one rank: still create the torch.distributed process group (backend as given) and take the N > 1 code path -- index broadcast through RCCL on a one-rank communicator, barriers, gathers -- so that path runs on a one-GPU box")
     ap.add_argument("--sub-batch", type=int, default=0, help="at most this many queries per batch (submitted as chunks of a step; 0 = automatic: as many as fit the spool, at most one step)")
     ap.add_argument("--no-numa-pin", action="store_true", help="do not bind the writer threads to the GPU's NUMA node")
     ap.add_argument("--sync-write", action="store_true", help="write each chunk's files before starting the next chunk")
@@ -202,6 +203,7 @@ def main():
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     if args.single_device:
         local = 0
+    multi = world > 1 or args.force_dist                  # the torch.distributed path (a one-rank group with --force-dist)
     if local_world > 1 and "CGX_THREADS" not in os.environ:
         # the ranks of one host share its CPUs (and its cgroup quota): each writer gets its share, two CPUs of it left to
         # the thread that feeds the GPU (what the library does by itself for a single process)
@@ -219,8 +221,13 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the extractor has no CPU fallback")
     torch.cuda.set_device(local)
-    if world > 1:
-        dist.init_process_group(args.backend)
+    if multi:
+        if "MASTER_ADDR" in os.environ and "RANK" in os.environ:
+            dist.init_process_group(args.backend)
+        else:                                             # --force-dist outside a launcher: a one-rank group on the loopback interface
+            import socket
+            sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+            dist.init_process_group(args.backend, init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
     ex = cgx_amd.Extractor(local)
     if args.sub_batch:
         ex.set_option("sub_batch", args.sub_batch)
@@ -245,7 +252,7 @@ def main():
             os.makedirs(share, exist_ok=True)
             for k in keys:
                 np.save(os.path.join(share, k + ".npy"), corpus[k])
-    if world > 1:
+    if multi:
         dist.barrier()
         if not leader:
             corpus = {k: np.load(os.path.join(share, k + ".npy"), mmap_mode="r") for k in keys}
@@ -259,7 +266,7 @@ def main():
     t0 = time.perf_counter(); t_bcast = 0.0; bcast_bytes = 0
     if rank == 0:
         ex.upload_corpus(host)
-    if world > 1:
+    if multi:
         meta = [None]
         if rank == 0:
             meta = [ex.index_shape()]
@@ -324,7 +331,7 @@ def main():
     else:
         full_dir = None
     del corpus, gq_off, gq_tok
-    if world > 1:
+    if multi:
         dist.barrier()
         if share and leader:
             shutil.rmtree(share, ignore_errors=True)            # every rank holds its own copy now
@@ -370,6 +377,11 @@ def main():
     acc = new_acc()
     step_no = [0]
 
+    def writer_totals():
+        """The writer's running totals (ms) over every batch it has finished: read after ex.flush() on both sides of a region, the
+        differences are the region's own DMA waits and file phases (the per-batch figures lag two batches behind the submissions)."""
+        return {k: max(ex.host_ms(k + "_sum"), 0.0) for k in ("write", "write_wait_d2h", "write_file")}
+
     def run_chunk(a, b, outdir=None, qs=None):
         # With several chunks per step the chunks reuse the file slots grammar.0.s ..: first_query_index is 0 for each of them, so the
         # library's write_period / write_count sampling (an index into the whole query list) would be chunk-local here; the bench does not use it.
@@ -406,10 +418,11 @@ def main():
     ex.flush()
     if write:
         spool_bytes[0] = sum(e.stat().st_size for e in os.scandir(spool) if e.is_file())
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     reruns0 = max(ex.stage_ms("append_reruns"), 0.0)
+    wt0 = writer_totals()
     t0 = time.perf_counter(); rules = 0; queries_done = 0
     acc["on"] = True
     for _ in range(steps):
@@ -417,20 +430,22 @@ def main():
     acc["on"] = False
     kernel_ms, stage, hoststage = acc["kernel_ms"], acc["stage"], acc["host"]
     ex.flush()                                # every grammar file of every timed step is on disk before the clock stops
+    wt1 = writer_totals()
+    for k in wt0: hoststage[k] = wt1[k] - wt0[k]          # the timed steps' own batches
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
-    dt = shard.max_over_ranks(time.perf_counter() - t0, dist if world > 1 else None)
+    dt = shard.max_over_ranks(time.perf_counter() - t0, dist if multi else None)
     append_reruns = max(ex.stage_ms("append_reruns"), 0.0) - reruns0
-    total_q = shard.sum_over_ranks(queries_done, dist if world > 1 else None)
-    total_rules = shard.sum_over_ranks(rules, dist if world > 1 else None)
+    total_q = shard.sum_over_ranks(queries_done, dist if multi else None)
+    total_rules = shard.sum_over_ranks(rules, dist if multi else None)
 
     # ---- what every rank did in the timed steps: the GPU chain alone, and the two host stages beside it ----
     chain_s = sum(stage[k] for k in ("sa_lookup", "blocks", "gappy", "extract", "lexicon", "format")) / 1e3
     mine = {"rank": rank, "queries": int(queries_done), "gpu_chain_s": chain_s, "dma_wait_s": hoststage["write_wait_d2h"] / 1e3, "file_phase_s": hoststage["write_file"] / 1e3,
             "writer_threads": int(max(ex.host_ms("writer_threads"), 0)), "cpus_usable": usable_cpus(), "cgx_threads_env": os.environ.get("CGX_THREADS")}
     ranks = [mine]
-    if world > 1:
+    if multi:
         ranks = [None] * world; dist.all_gather_object(ranks, mine)
 
     # ---- the same steps into FRESH directories (what a user who writes every batch into a new directory sees): every chunk
@@ -443,12 +458,12 @@ def main():
         gen_bytes = max(spool_bytes[0], 1)
         shutil.rmtree(spool, ignore_errors=True); os.makedirs(spool, exist_ok=True)     # the in-place spool has done its work: its memory goes to the generations
         fits = gen_bytes * 5.6 <= per_rank * 2.6                                         # three live generations + one being deleted + the writer's page-locked buffers (1.6)
-        fits = bool(shard.min_over_ranks(1.0 if fits else 0.0, dist if world > 1 else None))      # all ranks or none (the region has barriers)
+        fits = bool(shard.min_over_ranks(1.0 if fits else 0.0, dist if multi else None))      # all ranks or none (the region has barriers)
         if not fits:
             fresh["note"] = "skipped: four generations of %.1f GB of files do not fit this rank's memory budget" % (gen_bytes / 1e9)
         else:
             gens, deleters = [], []
-            if world > 1:
+            if multi:
                 dist.barrier()
             torch.cuda.synchronize()
             tf = time.perf_counter()
@@ -465,12 +480,12 @@ def main():
                 fresh_q += step(fresh_dir)[1]
             ex.flush()
             torch.cuda.synchronize()
-            if world > 1:
+            if multi:
                 dist.barrier()
-            dtf = shard.max_over_ranks(time.perf_counter() - tf, dist if world > 1 else None)
+            dtf = shard.max_over_ranks(time.perf_counter() - tf, dist if multi else None)
             for th in deleters:
                 th.join()
-            tq = shard.sum_over_ranks(fresh_q, dist if world > 1 else None)
+            tq = shard.sum_over_ranks(fresh_q, dist if multi else None)
             fresh.update(steps=fresh_steps, value=round(tq / dtf, 3), ms_per_step=round(dtf / fresh_steps * 1e3, 3),
                          note="every chunk written into a new directory; directories older than two chunks deleted by a helper thread inside the timed region")
 
@@ -485,30 +500,34 @@ def main():
         for _ in range(2):                                    # fill the .gz file slots twice before the clock starts, as for the plain files
             step()
         ex.flush()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
+        wg0 = writer_totals()
         tg = time.perf_counter(); gz_rules = 0; gz_q = 0
         acc["on"] = True
         for _ in range(gz_steps):
             r_, q_ = step(); gz_rules += r_; gz_q += q_
         acc["on"] = False
         ex.flush()
+        wg1 = writer_totals()
+        for k in wg0: acc["host"][k] = wg1[k] - wg0[k]
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
-        dtg = shard.max_over_ranks(time.perf_counter() - tg, dist if world > 1 else None)
-        tqg = shard.sum_over_ranks(gz_q, dist if world > 1 else None); trg = shard.sum_over_ranks(gz_rules, dist if world > 1 else None)
+        dtg = shard.max_over_ranks(time.perf_counter() - tg, dist if multi else None)
+        tqg = shard.sum_over_ranks(gz_q, dist if multi else None); trg = shard.sum_over_ranks(gz_rules, dist if multi else None)
         gacc = acc; acc = main_acc
         ex.set_option("gz_level", 0)
         gchain = sum(gacc["stage"][k] for k in ("sa_lookup", "blocks", "gappy", "extract", "lexicon", "format")) / 1e3
-        gchain_max = shard.max_over_ranks(gchain, dist if world > 1 else None)
+        gchain_max = shard.max_over_ranks(gchain, dist if multi else None)
         gzres = {"steps": gz_steps, "value": round(tqg / dtg, 3), "rules_per_s": round(trg / dtg, 1), "ms_per_step": round(dtg / gz_steps * 1e3, 3),
                  "value_gpu_chain": round(tqg / max(gchain_max, 1e-9), 3),
                  "gpu_chain_ms_per_step": round(gchain / gz_steps * 1e3, 2), "dma_wait_ms_per_step": round(gacc["host"]["write_wait_d2h"] / gz_steps, 2), "file_phase_ms_per_step": round(gacc["host"]["write_file"] / gz_steps, 2),
                  "format_ms_per_step": round(gacc["stage"]["format"] / gz_steps, 2), "fmt_count_ms_per_step": round(gacc["stage"]["fmt_count"] / gz_steps, 2), "fmt_write_ms_per_step": round(gacc["stage"]["fmt_write"] / gz_steps, 2),
                  "d2h_bytes_per_step": int(gacc["ubytes"] / gz_steps), "plain_unique_text_bytes_per_step": int(gacc["pbytes"] / gz_steps), "gz_file_bytes_per_step": int(gacc["fbytes"] / gz_steps),
                  "compressed_to": round(gacc["ubytes"] / max(gacc["pbytes"], 1.0), 4),
+                 "stages_ms_per_step": {k: round(v / gz_steps, 2) for k, v in list(gacc["stage"].items()) + [("host_" + k, v) for k, v in gacc["host"].items()]},
                  "bound": max((("gpu_chain", gchain), ("dma", gacc["host"]["write_wait_d2h"] / 1e3), ("file_phase", gacc["host"]["write_file"] / 1e3)), key=lambda t: t[1])[0],
                  "note": "this rank's figures; files grammar.<q>.s.gz rewritten in place in the spool directory, slots filled twice before the clock starts; one gzip member per emission group (fixed Huffman codes, back-references from the line structure), every piece of the unique text a series of whole members"}
 
@@ -542,7 +561,7 @@ def main():
     if spool:
         shutil.rmtree(spool, ignore_errors=True)
     ex.close()
-    if world > 1:
+    if multi:
         dist.barrier(); dist.destroy_process_group()
 
 

@@ -47,6 +47,7 @@ struct cgx_ctx {
     int gz_level = 0;                   // 1..9: grammar.<q>.s.gz instead of plain files
     bool gz_device = true;              // with gz_level and the device formatter: the formatter emits the gzip members itself (cgx_fmt.h); 0 = the host's zlib at gz_level compresses the plain text
     uint32_t *d_gztab = nullptr;        // CRC tables of the member trailers (GZ_TAB_WORDS words)
+    unsigned int *d_rs_long = nullptr;  // run_sort: runs longer than the fix pass's LDS buffer met so far (slow path taken; cgx_stage_ms "run_sort_long_runs")
     bool text_gz[2] = {false, false};   // what the text slot holds: gzip members / plain text
     bool occ_order = true;              // one-token driving phrases take their occurrences in corpus order (d_pos1) instead of suffix order (test / A-B hook)
     bool src_blocks = true;             // the lookups find a sentence's target-side bytes from its source start (d_lrs); 0 = through the delimiter's alignment word (test / A-B hook)

@@ -371,17 +371,19 @@ __global__ __launch_bounds__(RS_BLOCK) void k_runsort_block(const uint32_t *__re
     kout[base + (uint32_t)lo + rank] = k; if (VAL) vout[base + (uint32_t)lo + rank] = v;
 }
 template <bool VAL>
-__global__ __launch_bounds__(64) void k_runsort_fix(const uint32_t *__restrict__ major, uint64_t *__restrict__ key, uint32_t *__restrict__ val, uint32_t n) {
+__global__ __launch_bounds__(64) void k_runsort_fix(const uint32_t *__restrict__ major, const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin,
+                                                     uint64_t *__restrict__ key, uint32_t *__restrict__ val, uint32_t n, unsigned int *__restrict__ nlong) {
     __shared__ uint64_t sk[RS_MAXRUN]; __shared__ uint32_t sv[RS_MAXRUN];
     const uint32_t p = (blockIdx.x + 1) * RS_BLOCK;            // the boundary between record p-1 and record p
     if (p >= n) return;
     const uint32_t m = major[p];
     if (major[p - 1] != m) return;                               // no run is cut here
     const int lane = (int)threadIdx.x;
-    // run start: the first record of the id, at most RS_MAXRUN back (wave-parallel: every lane looks at one record per round)
+    // run start: the first record of the id (wave-parallel: every lane looks at one record per round; a short run ends the walk
+    // in the first rounds, a long one is followed to its end -- no length is assumed)
     uint32_t rs = p;
-    for (uint32_t back = 0; back < RS_MAXRUN; back += 64) {
-        const uint32_t q = p - 1 - back - (uint32_t)lane; const bool same = p >= 1 + back + (uint32_t)lane && major[q] == m;
+    for (uint32_t back = 0; ; back += 64) {
+        const bool same = p >= 1 + back + (uint32_t)lane && major[p - 1 - back - (uint32_t)lane] == m;
         const unsigned long long b = __ballot(same);
         const int run = b == ~0ull ? 64 : __ffsll((long long)~b) - 1;   // lanes 0..run-1 still belong to the id
         rs = p - back - (uint32_t)run;
@@ -389,7 +391,7 @@ __global__ __launch_bounds__(64) void k_runsort_fix(const uint32_t *__restrict__
     }
     if ((rs / RS_BLOCK + 1) * RS_BLOCK != p) return;             // a run cut by several boundaries is handled at the first of them
     uint32_t re = p;                                             // one past the last record of the id
-    for (uint32_t fwd = 0; fwd < RS_MAXRUN; fwd += 64) {
+    for (uint32_t fwd = 0; ; fwd += 64) {
         const uint32_t q = p + fwd + (uint32_t)lane; const bool same = q < n && major[q] == m;
         const unsigned long long b = __ballot(same);
         const int run = b == ~0ull ? 64 : __ffsll((long long)~b) - 1;
@@ -397,7 +399,18 @@ __global__ __launch_bounds__(64) void k_runsort_fix(const uint32_t *__restrict__
         if (run < 64) break;
     }
     const uint32_t len = re - rs;
-    if (len > RS_MAXRUN) return;                                 // not a short run: the callers' contract excludes it (checked on the host)
+    if (len > RS_MAXRUN) {
+        // Not a short run (no caller produces one today: static_assert below).  Still sorted, only slowly: the block pass permuted
+        // the records of the run inside each block, so the INPUT arrays hold the same records between rs and re and nobody writes
+        // them; every record is ranked against the whole run there (ties by input position: stable) and written to its place.
+        if (lane == 0) atomicAdd(nlong, 1u);
+        for (uint32_t j = rs + (uint32_t)lane; j < re; j += 64) {
+            const uint64_t k = kin[j]; uint32_t rank = 0;
+            for (uint32_t x = rs; x < re; x++) { const uint64_t o = kin[x]; rank += (o < k || (o == k && x < j)) ? 1u : 0u; }
+            key[rs + rank] = k; if (VAL) val[rs + rank] = vin[j];
+        }
+        return;
+    }
     for (uint32_t j = (uint32_t)lane; j < len; j += 64) { sk[j] = key[rs + j]; if (VAL) sv[j] = val[rs + j]; }
     __syncthreads();
     for (uint32_t j = (uint32_t)lane; j < len; j += 64) {
@@ -406,19 +419,43 @@ __global__ __launch_bounds__(64) void k_runsort_fix(const uint32_t *__restrict__
         key[rs + rank] = k; if (VAL) val[rs + rank] = sv[j];
     }
 }
-// keys (and an optional payload) sorted inside every run of equal `major`; kout/vout must not alias the inputs
+// The fast path of the fix pass holds a run in LDS: every caller's runs fit (an id has at most as many records as a unit has samples)
+static_assert(CGX_SAMPLER <= RS_MAXRUN && CGX_SAMPLER_ONEGAP <= RS_MAXRUN && CGX_SAMPLER_TWOGAP <= RS_MAXRUN, "run_sort: a unit's samples must fit the fix pass's LDS run");
+// keys (and an optional payload) sorted inside every run of equal `major`, whatever the run lengths (runs of more than RS_MAXRUN
+// records that cross a block boundary take the slow path of the fix pass and are counted in ctx->d_rs_long, "run_sort_long_runs");
+// kout/vout must not alias the inputs
 static int run_sort(cgx_ctx *ctx, const uint32_t *major, const uint64_t *kin, const uint32_t *vin, uint64_t *kout, uint32_t *vout, size_t n) {
     if (n == 0) return CGX_OK;
     if (n > 0xFFFFFF00ull) return fail(ctx, CGX_ERR_NOMEM, "run_sort: too many records", hipSuccess);
+    if ((const void *)kin == (const void *)kout || (vin && vin == vout)) return fail(ctx, CGX_ERR_ARG, "run_sort: output aliases input", hipSuccess);
+    if (!ctx->d_rs_long) { TRY(dalloc(ctx, &ctx->d_rs_long, 1)); HIPCHK(hipMemsetAsync(ctx->d_rs_long, 0, 4, ctx->stream)); }
     const unsigned nb = nblocks(n, RS_BLOCK);
     if (vin) k_runsort_block<true><<<nb, RS_BLOCK, 0, ctx->stream>>>(major, kin, vin, kout, vout, (uint32_t)n);
     else k_runsort_block<false><<<nb, RS_BLOCK, 0, ctx->stream>>>(major, kin, nullptr, kout, nullptr, (uint32_t)n);
     if (nb > 1) {
-        if (vin) k_runsort_fix<true><<<nb - 1, 64, 0, ctx->stream>>>(major, kout, vout, (uint32_t)n);
-        else k_runsort_fix<false><<<nb - 1, 64, 0, ctx->stream>>>(major, kout, nullptr, (uint32_t)n);
+        if (vin) k_runsort_fix<true><<<nb - 1, 64, 0, ctx->stream>>>(major, kin, vin, kout, vout, (uint32_t)n, ctx->d_rs_long);
+        else k_runsort_fix<false><<<nb - 1, 64, 0, ctx->stream>>>(major, kin, nullptr, kout, nullptr, (uint32_t)n, ctx->d_rs_long);
     }
     HIPCHK(hipGetLastError());
     return CGX_OK;
+}
+// test hook (tests/test_gpu_parity.py): host arrays through run_sort; returns the number of long runs the fix pass met
+extern "C" int64_t cgx__test_run_sort(cgx_ctx *ctx, const uint32_t *major, const uint64_t *key, const uint32_t *val, uint64_t *key_out, uint32_t *val_out, int64_t n) {
+    if (!ctx || n < 0 || (n && (!major || !key || !key_out)) || (val && !val_out)) return CGX_ERR_ARG;
+    HIPCHK(hipSetDevice(ctx->device)); stage_enter(ctx);
+    uint32_t *dm = nullptr, *dv = nullptr, *dvo = nullptr; uint64_t *dk = nullptr, *dko = nullptr;
+    TRY(dalloc(ctx, &dm, (size_t)n)); TRY(dalloc(ctx, &dk, (size_t)n)); TRY(dalloc(ctx, &dko, (size_t)n));
+    if (val) { TRY(dalloc(ctx, &dv, (size_t)n)); TRY(dalloc(ctx, &dvo, (size_t)n)); }
+    unsigned int before = 0, after = 0;
+    if (n) {
+        TRY(h2d(ctx, dm, major, (size_t)n)); TRY(h2d(ctx, dk, key, (size_t)n)); if (val) TRY(h2d(ctx, dv, val, (size_t)n));
+        if (ctx->d_rs_long) TRY(d2h(ctx, &before, ctx->d_rs_long, 1));
+        TRY(run_sort(ctx, dm, dk, dv, dko, dvo, (size_t)n));
+        TRY(d2h(ctx, key_out, dko, (size_t)n)); if (val) TRY(d2h(ctx, val_out, dvo, (size_t)n));
+        TRY(d2h(ctx, &after, ctx->d_rs_long, 1));
+    }
+    dfree(dm); dfree(dk); dfree(dko); dfree(dv); dfree(dvo);
+    return (int64_t)(after - before);
 }
 
 // ------------------------------------------------------------------------------------
@@ -463,7 +500,7 @@ extern "C" void cgx_destroy(cgx_ctx *c) {
     free_batch(c); free_index(c);
     for (int a = 0; a < 2; a++) if (c->arena[a]) { (void)hipHostFree(c->arena[a]); c->arena[a] = nullptr; }
     for (int a = 0; a < 2; a++) { dfree(c->d_text[a]); dfree(c->d_qtext[a]); dfree(c->d_seg_off[a]); dfree(c->d_seg_len[a]); dfree(c->d_qseg[a]); }
-    dfree(c->d_spool); dfree(c->d_soff); dfree(c->d_tpool); dfree(c->d_toff); dfree(c->d_aa); dfree(c->d_bb); dfree(c->d_fs); dfree(c->d_gztab);
+    dfree(c->d_spool); dfree(c->d_soff); dfree(c->d_tpool); dfree(c->d_toff); dfree(c->d_aa); dfree(c->d_bb); dfree(c->d_fs); dfree(c->d_gztab); dfree(c->d_rs_long);
     if (c->sync_ev) (void)hipEventDestroy(c->sync_ev);
     for (int r = 0; r < CGX_COPY_STREAMS; r++) if (c->copy_streams[r]) (void)hipStreamDestroy(c->copy_streams[r]);
     for (int r = 0; r < CGX_MAX_READERS; r++) if (c->copy_done[r]) (void)hipEventDestroy(c->copy_done[r]);
@@ -575,6 +612,11 @@ static void memory_report(cgx_ctx *c) {
 extern "C" double cgx_stage_ms(cgx_ctx *c, const char *name) {
     if (!c || !name) return -1;
     if (!strncmp(name, "mem_", 4)) memory_report(c);
+    if (!strcmp(name, "run_sort_long_runs")) {                  // runs the fix pass of run_sort had to take the slow way (none with today's callers)
+        unsigned int v = 0;
+        if (c->d_rs_long && (hipSetDevice(c->device) != hipSuccess || hipMemcpyAsync(&v, c->d_rs_long, 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess || stream_wait(c) != hipSuccess)) return -1.0;
+        return (double)v;
+    }
     auto it = c->ms.find(name);
     return it == c->ms.end() ? -1.0 : it->second;
 }

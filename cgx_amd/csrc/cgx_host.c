@@ -1384,6 +1384,11 @@ static int join_oldest(cgx_ctx *ctx, wstate *ws) {
     int rc = pw->rc;
     cgx__set_host_ms(ctx, "write", pw->ms);
     if (pw->dev) { cgx__set_host_ms(ctx, "write_wait_d2h", pw->wait_ms); cgx__set_host_ms(ctx, "write_file", pw->file_ms); }
+    /* running totals over every batch joined so far: a caller that brackets a region with cgx_flush reads the region's own batches from
+     * the differences (the figures above are those of the batch joined LAST, which with two batches in flight is not the one just submitted) */
+    { double a = cgx_host_ms(ctx, "write_sum"), b = cgx_host_ms(ctx, "write_wait_d2h_sum"), c = cgx_host_ms(ctx, "write_file_sum"), d = cgx_host_ms(ctx, "batches_joined");
+      cgx__set_host_ms(ctx, "write_sum", (a > 0 ? a : 0) + pw->ms); cgx__set_host_ms(ctx, "batches_joined", (d > 0 ? d : 0) + 1);
+      if (pw->dev) { cgx__set_host_ms(ctx, "write_wait_d2h_sum", (b > 0 ? b : 0) + pw->wait_ms); cgx__set_host_ms(ctx, "write_file_sum", (c > 0 ? c : 0) + pw->file_ms); } }
     ws->inflight[0] = ws->inflight[1]; ws->inflight[1] = NULL; ws->n--;
     if (pw->b) { batch_free(pw->b); free(pw->b); }
     free(pw->outdir); free(pw);

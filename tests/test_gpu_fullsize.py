@@ -344,3 +344,81 @@ def test_two_ranks_on_one_gpu_run_the_product(tmp_path):
     assert pr["writer_threads"][0] >= 2 and pr["gpu_chain_ms_per_step"][0] > 0 and pr["gpu_chain_ms_per_step"][1] >= pr["gpu_chain_ms_per_step"][0]
     a, b = two["rules_per_s"] * two["ms_per_step"], one["rules_per_s"] * one["ms_per_step"]                     # rules per step x 1000, from rounded fields
     assert abs(a - b) <= 1e-4 * b and two["counts"]["grammar_lines"] > 0
+
+
+def _rccl():
+    import ctypes as C
+    try:
+        lib = C.CDLL("librccl.so", mode=C.RTLD_GLOBAL)
+    except OSError:
+        lib = C.CDLL("librccl.so.1", mode=C.RTLD_GLOBAL)
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+    lib.ncclGetUniqueId.argtypes = [C.POINTER(UniqueId)]
+    lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    lib.ncclCommDestroy.argtypes = [C.c_void_p]
+    lib.ncclGetErrorString.restype = C.c_char_p; lib.ncclGetErrorString.argtypes = [C.c_int]
+    return lib, UniqueId
+
+
+def test_rccl_broadcast_on_a_one_rank_communicator(tmp_path):
+    """cgx_broadcast_index on REAL RCCL with the one card a test box has: `ncclCommInitRank` with nranks = 1 gives a communicator
+    on which the library's own call runs end to end -- dlopen of librccl, the symbol look-ups, the datatype constant, the grouped
+    ncclBroadcast of every index buffer on the context's stream -- first as the root (the buffers come back as they were: the same
+    golden files afterwards), then on a second context that holds a replica and is told it is NOT the root, so that the call ends
+    in cgx_index_finalize as on ranks 1..N-1 of a real job.  (Two ranks need two cards: test_two_gpu_bench_broadcast_paths.)"""
+    import ctypes as C
+    import torch
+    torch.zeros(1, device="cuda:0")
+    import cgx_amd as cgx
+    import oracle_py as op
+    from test_oracle import META, make_fixture
+    fx = make_fixture("toy", str(tmp_path / "fx")); files = op.fixture_args(fx)
+    rccl, UniqueId = _rccl()
+    uid = UniqueId(); rc = rccl.ncclGetUniqueId(C.byref(uid)); assert rc == 0, rccl.ncclGetErrorString(rc)
+    comm = C.c_void_p(); rc = rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0); assert rc == 0, rccl.ncclGetErrorString(rc)
+    root = cgx.Extractor(0); corpus = cgx.Corpus.load(files[0], files[2], files[3], files[4]); root.upload_corpus(corpus)
+    root._chk(root.lib.cgx_broadcast_index(root.h, comm, 0, 0), "cgx_broadcast_index (root)")
+    nbytes = sum(nb for _, nb in root.index_buffers())
+    assert nbytes > 0 and root.stage_ms("broadcast_bytes") == nbytes
+    os.makedirs(str(tmp_path / "a")); root.extract_grammars(corpus, files[1], str(tmp_path / "a"))
+    assert op.sha_dir(str(tmp_path / "a"), 7) == META["toy"]["grammar"]
+    # a replica, filled buffer by buffer, then the same call as a non-root rank: broadcast (from itself: one rank) + finalize
+    rep = cgx.Extractor(0); rep.index_alloc(root.index_shape())
+    for i, (name, nb) in enumerate(root.index_buffers()):
+        if nb == 0:
+            continue
+        stage = torch.empty(nb, dtype=torch.uint8, device="cuda:0")
+        root.index_d2d(i, stage.data_ptr(), 0); torch.cuda.synchronize()
+        rep.index_d2d(i, stage.data_ptr(), 1); torch.cuda.synchronize()
+    rep._chk(rep.lib.cgx_broadcast_index(rep.h, comm, 0, 1), "cgx_broadcast_index (replica)")
+    os.makedirs(str(tmp_path / "b")); rep.extract_grammars(corpus, files[1], str(tmp_path / "b"))
+    assert op.sha_dir(str(tmp_path / "b"), 7) == META["toy"]["grammar"]
+    # a context without buffers is refused, not crashed
+    empty = cgx.Extractor(0)
+    assert empty.lib.cgx_broadcast_index(empty.h, comm, 0, 1) != 0 and b"not allocated" in empty.lib.cgx_last_error(empty.h)
+    empty.close(); rep.close(); root.close(); corpus.close()
+    assert rccl.ncclCommDestroy(comm) == 0
+
+
+@pytest.mark.parametrize("bcast", ["torch", "c"])
+def test_bench_under_torch_distributed_nccl_with_one_rank(bcast):
+    """bench.py's N > 1 code path on one card, in a fresh process: `--force-dist` creates the torch.distributed process group with
+    backend nccl (= RCCL) for a world of one and takes every branch a multi-GPU run takes -- index shape broadcast, the index
+    buffers through torch.distributed.broadcast / through cgx_broadcast_index on a communicator of our own, barriers, gathers,
+    max over ranks.  The rule count must equal the plain single-process run's."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--config", "cfg4", "--pairs", "60000", "--queries", "2000", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--fresh-steps", "0", "--gz-steps", "0"]
+    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    one = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][0])
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--backend", "nccl", "--bcast", bcast] + common, capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    two = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][0])
+    assert two["n_gpus"] == 1 and two["index"]["broadcast_bytes"] > 0 and two["index"]["broadcast_s"] >= 0
+    a, b = two["rules_per_s"] * two["ms_per_step"], one["rules_per_s"] * one["ms_per_step"]
+    assert abs(a - b) <= 1e-4 * b and two["counts"]["grammar_lines"] > 0

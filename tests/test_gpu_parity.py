@@ -575,3 +575,35 @@ def test_id_level_batch_on_synthetic_corpus(pairs, vocab, nq, cgx, tmp_path):
     assert op.sha_dir(str(out), nq) == op.sha_dir(str(oout), nq)
     assert nrules == sum(sum(1 for _ in open(oout / f, "rb")) for f in os.listdir(oout))
     ex.close(); host.close()
+
+
+def test_run_sort_orders_runs_of_any_length(cgx):
+    """run_sort (the order inside id runs of the rule and lexicon keys): short runs through the LDS passes, and runs longer than
+    the fix pass's LDS buffer (RS_MAXRUN = 320) that straddle a 1024-record block boundary through its slow path -- sorted all the
+    same, stable, payload carried, and counted.  No caller produces such a run today (the sampling caps are 300 / 65 / 70)."""
+    rng = np.random.default_rng(5)
+    ex = cgx.Extractor(0)
+
+    def check(lengths, keybits, want_long):
+        major = np.repeat(np.arange(len(lengths), dtype=np.uint32) * 3 + 7, lengths)
+        n = len(major)
+        key = rng.integers(0, 1 << keybits, n, dtype=np.uint64)
+        val = np.arange(n, dtype=np.uint32)
+        ko, vo, nlong = ex.run_sort(major, key, val)
+        order = np.lexsort((val, key, major))                  # (major, key, input position): what a stable sort inside the runs gives
+        assert np.array_equal(ko, key[order]) and np.array_equal(vo, val[order])
+        ko2, vo2, _ = ex.run_sort(major, key)
+        assert vo2 is None and np.array_equal(ko2, key[order])
+        assert nlong == want_long, (nlong, want_long)
+
+    # short runs only (1..300), many of them cut by block boundaries: the fast path
+    check(rng.integers(1, 301, 4000), 40, 0)
+    # few distinct keys: ties keep input order
+    check(rng.integers(1, 301, 500), 2, 0)
+    # a 400-record run across the first boundary (records 900..1299), a 5000-record run across four boundaries, a 330-record run
+    # inside one block (no fix needed), short runs around them
+    lengths = [900, 400, 60, 5000, 20, 330, 300, 1]
+    check(lengths, 30, 2)
+    check([1024, 321 + 1024, 3], 3, 1)                         # a long run that starts exactly at a boundary; ties
+    assert ex.stage_ms("run_sort_long_runs") == 2 * (2 + 1)    # each check sorts twice (with and without payload)
+    ex.close()

@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU chain only (rules counted on the device, nothing leaves the card): stage times of a short run.  usage: tools/gpu_bench_nowrite.sh <tag>
+# GPU chain only (rules counted on the device, nothing leaves the card): stage times of a short run.  usage: tools/jobs/gpu_bench_nowrite.sh <tag>
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; TAG=${1:-nw}
 timeout -k 10 300 python3 bench.py --steps 4 --warmup 2 --no-write --no-cpu-baseline > gpurun_out/${TAG}_nowrite.log 2> gpurun_out/${TAG}_nowrite.err; echo "rc=$?"
 python3 - <<Q

@@ -1,5 +1,5 @@
 #!/bin/bash
-# the whole cfg5 step (10^6 queries, files written) with two builds of the library, one after the other.  usage: tools/gpu_cfg5_ab.sh <tag> <lib> <lib>
+# the whole cfg5 step (10^6 queries, files written) with two builds of the library, one after the other.  usage: tools/jobs/gpu_cfg5_ab.sh <tag> <lib> <lib>
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; TAG=$1; shift
 for lib in "$@"; do
   name=$(basename $lib .so)

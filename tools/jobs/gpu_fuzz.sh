@@ -1,5 +1,5 @@
 #!/bin/bash
-# randomized oracle-vs-GPU parity sweep.  usage: tools/gpu_fuzz.sh <tag> <seed> [cases] [big-seed] [big-cases]
+# randomized oracle-vs-GPU parity sweep.  usage: tools/jobs/gpu_fuzz.sh <tag> <seed> [cases] [big-seed] [big-cases]
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; TAG=${1:-fuzz}; SEED=${2:-51}; N=${3:-60}
 make -C oracle strmatch_oracle liboracle.so > /dev/null 2>&1
 timeout -k 10 800 python3 tools/stress_parity.py --fuzz $N --seed $SEED > gpurun_out/${TAG}_fuzz${SEED}.log 2>&1; rc=$?; echo "fuzz rc=$rc"; tail -3 gpurun_out/${TAG}_fuzz${SEED}.log | cut -c1-250; grep -c OK gpurun_out/${TAG}_fuzz${SEED}.log; grep -c MISMATCH gpurun_out/${TAG}_fuzz${SEED}.log

@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of several builds of the library on one box: bench.py --no-write with CGX_LIB = each build in turn; prints the lookup
-# kernels' and the stages' times.  usage: tools/gpu_lib_variants.sh <tag> <lib> [<lib> ...]   (paths relative to the repo root)
+# kernels' and the stages' times.  usage: tools/jobs/gpu_lib_variants.sh <tag> <lib> [<lib> ...]   (paths relative to the repo root)
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; TAG=$1; shift
 for lib in "$@"; do
   name=$(basename $lib .so)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# as gpu_lib_variants.sh, with the bench arguments given: tools/gpu_lib_variants_cfg.sh <tag> "<bench args>" <lib> [<lib> ...]
+# as gpu_lib_variants.sh, with the bench arguments given: tools/jobs/gpu_lib_variants_cfg.sh <tag> "<bench args>" <lib> [<lib> ...]
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; TAG=$1; ARGS=$2; shift; shift
 for lib in "$@"; do
   name=$(basename $lib .so)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# the other presets' bench lines at the head: toy, cfg4, cfg5 (the driver's cfg3 command is tools/gpu_tests_bench.sh).  usage: tools/gpu_round3_h.sh <tag>
+# the other presets' bench lines at the head: toy, cfg4, cfg5 (the driver's cfg3 command is tools/jobs/gpu_tests_bench.sh).  usage: tools/jobs/gpu_round3_h.sh <tag>
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 T=${1:-r3h}
 timeout -k 10 200 python3 bench.py --config toy --no-cpu-baseline > gpurun_out/${T}_bench_toy.json 2> gpurun_out/${T}_bench_toy.err; echo "toy rc=$?"; head -c 300 gpurun_out/${T}_bench_toy.json; echo

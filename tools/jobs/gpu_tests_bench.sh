@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU parity suite, then bench.py with the driver's arguments.  usage: tools/gpu_tests_bench.sh <tag> [extra bench args]
+# GPU parity suite, then bench.py with the driver's arguments.  usage: tools/jobs/gpu_tests_bench.sh <tag> [extra bench args]
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; TAG=${1:-x}; shift
 timeout -k 10 1100 python -m pytest tests -m gpu -x -q > gpurun_out/${TAG}_pytest.log 2>&1; rc=$?
 tail -6 gpurun_out/${TAG}_pytest.log; echo "pytest rc=$rc"

@@ -1,5 +1,5 @@
 #!/bin/bash
-# kernel timeline of one batch (launch order, merged runs, idle gaps).  usage: tools/gpu_timeline.sh <tag>
+# kernel timeline of one batch (launch order, merged runs, idle gaps).  usage: tools/jobs/gpu_timeline.sh <tag>
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; TAG=${1:-tl}
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/tl_tmp -- python3 $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-write > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_run.log 2>&1; echo "rc=$?"

@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B runs of bench.py --no-write with cgx_set_option overrides; prints the lookup stage times of each variant.
-# usage: tools/gpu_variants.sh <tag> "<opts of variant 1>" "<opts of variant 2>" ...   (opts = space separated name=value, "-" = defaults)
+# usage: tools/jobs/gpu_variants.sh <tag> "<opts of variant 1>" "<opts of variant 2>" ...   (opts = space separated name=value, "-" = defaults)
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; TAG=$1; shift
 i=0
 for v in "$@"; do
