@@ -188,7 +188,7 @@ def main():
     ap.add_argument("--sync-write", action="store_true", help="write each chunk's files before starting the next chunk")
     ap.add_argument("--fresh-steps", type=int, default=None, help="extra timed steps AFTER the contract's K steps that write every chunk into a NEW directory (value_fresh_files); default 3 (1 when a step is several chunks), 0 = skip")
     ap.add_argument("--query-sets", type=int, default=3, help="distinct query batches (different seeds) the steps rotate through: step i runs set i %% N, so capacity guesses, tables and file sizes change from step to step as in a serving run")
-    ap.add_argument("--gz-steps", type=int, default=None, help="extra timed steps AFTER the contract's K steps with grammar.<q>.s.gz output, the gzip members made by the GPU formatter (value_gz); default min(K, 5), 0 = skip")
+    ap.add_argument("--gz-steps", type=int, default=None, help="extra timed steps AFTER the contract's K steps with grammar.<q>.s.gz output, the gzip members made by the GPU formatter (value_gz); default K (as many as the plain leg, so that the drain of the writer pipeline after the last step weighs the same in both figures), 0 = skip")
     ap.add_argument("--no-write", action="store_true", help="count the rules on the GPU, lay out no text, write no files (kernel-side study; not the headline)")
     ap.add_argument("--option", action="append", default=[], help="name=value passed to cgx_set_option (repeatable)")
     args = ap.parse_args()
@@ -284,10 +284,12 @@ def main():
             class UniqueId(C.Structure):
                 _fields_ = [("internal", C.c_char * 128)]
             uid = UniqueId()
+            rccl.ncclGetUniqueId.argtypes = [C.POINTER(UniqueId)]
             if rank == 0 and rccl.ncclGetUniqueId(C.byref(uid)) != 0:
                 raise SystemExit("ncclGetUniqueId failed")
-            box = [bytes(uid.internal)] if rank == 0 else [None]
+            box = [C.string_at(C.byref(uid), 128)] if rank == 0 else [None]      # all 128 bytes (a c_char array read as a field stops at the first NUL: found by the one-rank test)
             dist.broadcast_object_list(box, src=0)
+            assert len(box[0]) == 128
             C.memmove(C.byref(uid), box[0], 128)
             comm = C.c_void_p()
             rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
@@ -491,7 +493,7 @@ def main():
 
     # ---- the same steps with grammar.<q>.s.gz output: the gzip members are made by the GPU formatter, so PCIe and the file phase
     # move a third of the bytes (the plain files above stay the default and the headline) ----
-    gz_steps = args.gz_steps if args.gz_steps is not None else min(steps, 5)
+    gz_steps = args.gz_steps if args.gz_steps is not None else steps
     gzres = {"steps": 0, "value": None}
     if write and gz_steps > 0:
         shutil.rmtree(spool, ignore_errors=True); os.makedirs(spool, exist_ok=True)

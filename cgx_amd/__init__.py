@@ -53,6 +53,7 @@ ABI = [
     "cgx_stage_ms", "cgx_corpus_load", "cgx_corpus_free", "cgx_corpus_checksum", "cgx_corpus_save", "cgx_corpus_load_cache", "cgx_corpus_matches_sources", "cgx_corpus_upload", "cgx_extract_grammars", "cgx_extract_grammars_shard", "cgx_shard_bounds", "cgx_extract_grammars_ids",
     "cgx_corpus_from_ids", "cgx_host_ms", "cgx_flush", "cgx_fetch_pinned", "cgx_pinned_next_batch", "cgx_upload_vocab", "cgx_upload_score_tables", "cgx_set_query_blocks",
     "cgx_format", "cgx_text_info", "cgx_text_encoding", "cgx_assemble_files_enc", "cgx_text_segments", "cgx_text_segments_begin", "cgx_text_offsets", "cgx_text_read", "cgx_text_read_begin", "cgx_text_read_wait", "cgx_pinned_alloc", "cgx_pinned_free", "cgx_assemble_files", "cgx_corpus_load_opt",
+    "cgx_corpus_flags", "cgx_corpus_from_ids16",
 ]
 
 
@@ -144,6 +145,24 @@ class Corpus:
         if not h:
             raise CgxError("cgx_corpus_from_ids failed")
         return cls(h)
+
+    @classmethod
+    def from_ids16(cls, str_, sentind, tstr, tsentind, lsrc, rsrc, ltar, rtar, lexk, lexv):
+        """from_ids with 16-bit alignment positions (0xFFFF = not aligned): long-sentence mode (cgx_corpus_from_ids16)."""
+        lib = load_library()
+        a = [_c(str_, np.int32), _c(sentind, np.int32), _c(tstr, np.int32), _c(tsentind, np.int32), _c(lsrc, np.uint16), _c(rsrc, np.uint16),
+             _c(ltar, np.uint16), _c(rtar, np.uint16), _c(lexk, LEXKEY), _c(lexv, LEXVAL)]
+        lib.cgx_corpus_from_ids16.restype = C.c_void_p
+        lib.cgx_corpus_from_ids16.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_int32, C.c_void_p, C.c_uint32, C.c_void_p] + [C.c_void_p] * 4 + [C.c_void_p, C.c_void_p, C.c_uint32]
+        h = lib.cgx_corpus_from_ids16(_ptr(a[0]), len(a[0]), _ptr(a[1]), len(a[1]) - 1, _ptr(a[2]), len(a[2]), _ptr(a[3]),
+                                      _ptr(a[4]), _ptr(a[5]), _ptr(a[6]), _ptr(a[7]), _ptr(a[8]), _ptr(a[9]), len(a[8]))
+        if not h:
+            raise CgxError("cgx_corpus_from_ids16 failed (a position or a sentence beyond the long-sentence limits)")
+        return cls(h)
+
+    def flags(self):
+        lib = load_library(); lib.cgx_corpus_flags.argtypes = [C.c_void_p]
+        return int(lib.cgx_corpus_flags(self.h))
 
     def save(self, path):
         rc = load_library().cgx_corpus_save(self.h, path.encode())

@@ -514,7 +514,7 @@ extern "C" void cgx_destroy(cgx_ctx *c) {
 extern "C" const char *cgx_last_error(cgx_ctx *c) { return c ? c->err : "null context"; }
 extern "C" int cgx_set_option(cgx_ctx *c, const char *name, int64_t value) {
     if (!c || !name) return CGX_ERR_ARG;
-    if (!strcmp(name, "k1_limit")) { c->k1_limit = (int)value; return CGX_OK; }
+    if (!strcmp(name, "k1_limit")) { c->k1_limit = value <= 0 || value > 0x7FFFFFFF ? 0x7FFFFFFF : (int)value; return CGX_OK; }   /* 0 = no limit; the reference's K1 stops at 128 tokens per query */
     if (!strcmp(name, "device_format")) { c->device_format = value != 0; return CGX_OK; }
     if (!strcmp(name, "use_bigrams")) { c->ngram_max = value != 0 ? 5 : 1; return CGX_OK; }       /* round-1 name: 0 = every l >= 2 by binary search */
     if (!strcmp(name, "ngram_tables")) { if (value < 1 || value > 5) return CGX_ERR_ARG; c->ngram_max = (int)value; return CGX_OK; }

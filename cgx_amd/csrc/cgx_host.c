@@ -547,6 +547,41 @@ cgx_corpus *cgx_corpus_from_ids(const int32_t *str, uint32_t n, const int32_t *s
     return c;
 }
 
+/* The same for sentence pairs of 255 tokens and more (long-sentence mode): alignment positions as 16-bit words,
+ * 0xFFFF = not aligned; source sentences < 1024 tokens, target sentences < 2040.  The corpus then behaves like one loaded with
+ * CGX_CORPUS_LONG_SENTENCES (on a corpus the reference accepts it yields the same files as cgx_corpus_from_ids). */
+cgx_corpus *cgx_corpus_from_ids16(const int32_t *str, uint32_t n, const int32_t *sentind, int32_t nsent, const int32_t *tstr, uint32_t nt,
+                                  const int32_t *tsentind, const uint16_t *lsrc, const uint16_t *rsrc, const uint16_t *ltar, const uint16_t *rtar,
+                                  const cgx_lexkey *lexk, const cgx_lexval *lexv, uint32_t nlex) {
+    if (!str || !sentind || !tstr || !tsentind || !lsrc || !rsrc || !ltar || !rtar || (nlex && (!lexk || !lexv)) || nsent < 0) return NULL;
+    for (int32_t q = 0; q < nsent; q++) if (sentind[q + 1] - sentind[q] - 1 >= LONG_MAX_SRC || tsentind[q + 1] - tsentind[q] - 1 >= LONG_MAX_TGT) return NULL;
+    for (uint32_t i = 0; i < n; i++) if ((lsrc[i] != 0xFFFF && lsrc[i] >= LONG_MAX_TGT) || (rsrc[i] != 0xFFFF && rsrc[i] >= LONG_MAX_TGT)) return NULL;
+    for (uint32_t i = 0; i < nt; i++) if ((ltar[i] != 0xFFFF && ltar[i] >= LONG_MAX_SRC) || (rtar[i] != 0xFFFF && rtar[i] >= LONG_MAX_SRC)) return NULL;
+    /* byte views for the common constructor (not-aligned stays not-aligned, positions beyond a byte saturate: only the 16-bit tables are read in this mode) */
+    uint8_t *b = malloc(2 * (size_t)n + 2 * (size_t)nt + 4);
+    if (!b) return NULL;
+    uint8_t *ls8 = b, *rs8 = b + n, *lt8 = b + 2 * (size_t)n, *rt8 = lt8 + nt;
+    for (uint32_t i = 0; i < n; i++) { ls8[i] = (uint8_t)(lsrc[i] > 254 ? 255 : lsrc[i]); rs8[i] = (uint8_t)(rsrc[i] > 254 ? 255 : rsrc[i]); }
+    for (uint32_t i = 0; i < nt; i++) { lt8[i] = (uint8_t)(ltar[i] > 254 ? 255 : ltar[i]); rt8[i] = (uint8_t)(rtar[i] > 254 ? 255 : rtar[i]); }
+    cgx_corpus *c = cgx_corpus_from_ids(str, n, sentind, nsent, tstr, nt, tsentind, ls8, rs8, lt8, rt8, lexk, lexv, nlex);
+    free(b);
+    if (!c) return NULL;
+    c->long_pos = 1;
+    c->ltar16 = malloc(((size_t)nt + 1) * 2); c->rtar16 = malloc(((size_t)nt + 1) * 2);
+    int32_t *l = malloc(((size_t)n + 1) * 4), *r = malloc(((size_t)n + 1) * 4);
+    int rc = -1;
+    if (c->ltar16 && c->rtar16 && l && r) {
+        memcpy(c->ltar16, ltar, (size_t)nt * 2); memcpy(c->rtar16, rtar, (size_t)nt * 2);
+        for (uint32_t i = 0; i < n; i++) { l[i] = lsrc[i] == 0xFFFF ? -1 : (int32_t)lsrc[i]; r[i] = rsrc[i] == 0xFFFF ? -1 : (int32_t)rsrc[i]; }
+        free(c->rlp); c->rlp = NULL;
+        rc = pack_alignment_i(c, l, r);                       /* the alignment words again, with position codes (cgx_rules.h) */
+    }
+    free(l); free(r);
+    if (rc) { cgx_corpus_free(c); return NULL; }
+    return c;
+}
+int cgx_corpus_flags(const cgx_corpus *c) { return c && c->long_pos ? CGX_CORPUS_LONG_SENTENCES : 0; }
+
 /* ------------------------------------------------------------------ */
 /* on-disk corpus cache: the parsed corpus as one binary file, so that later runs skip the text loaders
  * (the reference re-reads and re-tokenises its four text files on every start; its own index cache is
@@ -554,10 +589,10 @@ cgx_corpus *cgx_corpus_from_ids(const int32_t *str, uint32_t n, const int32_t *s
  * loader checks the file size against them. */
 /* ------------------------------------------------------------------ */
 typedef struct { char magic[8]; uint64_t checksum; uint32_t n, nt, nsent, nlex, nsvocab, ntvocab, maxword, reserved; uint64_t sbytes, tbytes; uint64_t src_size[4], src_mtime[4]; } cachehdr;
-static const char CACHE_MAGIC[8] = {'C', 'G', 'X', 'C', 'O', 'R', 'P', '3'};   /* 3: source fingerprint = size + 1 and nanosecond mtime */
+static const char CACHE_MAGIC[8] = {'C', 'G', 'X', 'C', 'O', 'R', 'P', '4'};   /* 3: source fingerprint = size + 1 and nanosecond mtime; 4: header field `reserved` = flags (bit 0: long-sentence mode, the 16-bit target tables follow the byte tables) */
+#define CACHE_LONG 1u
 int cgx_corpus_save(const cgx_corpus *c, const char *path) {
-    if (c && c->long_pos) return CGX_ERR_STATE;              /* the cache format holds the reference's byte tables only: a long-sentence corpus is parsed each time */
-    if (!c || !path || !c->rlp || !c->svocab || !c->tvocab) return CGX_ERR_ARG;
+    if (!c || !path || !c->rlp || !c->svocab || !c->tvocab || (c->long_pos && (!c->ltar16 || !c->rtar16))) return CGX_ERR_ARG;
     /* written under a private name and renamed into place: a reader (another --shard process started at the same time)
      * sees either no cache or a complete one, never a file with holes */
     size_t pl = strlen(path); char *tmp = malloc(pl + 40);
@@ -567,7 +602,7 @@ int cgx_corpus_save(const cgx_corpus *c, const char *path) {
     if (!f) { free(tmp); return CGX_ERR_IO; }
     cachehdr h; memset(&h, 0, sizeof h); memcpy(h.magic, CACHE_MAGIC, 8);
     h.checksum = cgx_corpus_checksum(c); h.n = c->n; h.nt = c->nt; h.nsent = (uint32_t)c->nsent; h.nlex = c->nlex;
-    h.nsvocab = (uint32_t)c->nsvocab; h.ntvocab = (uint32_t)c->ntvocab; h.maxword = c->maxword;
+    h.nsvocab = (uint32_t)c->nsvocab; h.ntvocab = (uint32_t)c->ntvocab; h.maxword = c->maxword; h.reserved = c->long_pos ? CACHE_LONG : 0u;
     memcpy(h.src_size, c->src_size, sizeof h.src_size); memcpy(h.src_mtime, c->src_mtime, sizeof h.src_mtime);
     for (int32_t i = 0; i < c->nsvocab; i++) h.sbytes += c->svocab[i] ? c->svlen[i] : 0;
     for (int32_t i = 0; i < c->ntvocab; i++) h.tbytes += c->tvocab[i] ? c->tvlen[i] : 0;
@@ -575,6 +610,7 @@ int cgx_corpus_save(const cgx_corpus *c, const char *path) {
 #define PUT(ptr, count, size) do { if (ok && (count) && fwrite((ptr), (size), (count), f) != (size_t)(count)) ok = 0; } while (0)
     PUT(c->str, c->n, 4); PUT(c->tstr, c->nt, 4); PUT(c->sentind, (size_t)c->nsent + 1, 4); PUT(c->tsentind, (size_t)c->nsent + 1, 4);
     PUT(c->P, c->n, 1); PUT(c->rlp, c->n, 4); PUT(c->ltar, c->nt, 1); PUT(c->rtar, c->nt, 1);
+    if (c->long_pos) { PUT(c->ltar16, c->nt, 2); PUT(c->rtar16, c->nt, 2); }
     PUT(c->lexk, c->nlex, sizeof *c->lexk); PUT(c->lexv, c->nlex, sizeof *c->lexv);
     /* spelling lengths (0 for the unused ids 0 and 1), then the spellings back to back */
     for (int32_t i = 0; ok && i < c->nsvocab; i++) { uint32_t L = c->svocab[i] ? c->svlen[i] : 0; PUT(&L, 1, 4); }
@@ -604,16 +640,18 @@ cgx_corpus *cgx_corpus_load_cache(const char *path, char *err, size_t errcap) {
     cachehdr h; cgx_corpus *c = NULL;
     if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, CACHE_MAGIC, 8)) { snprintf(err, errcap, "\"%s\" is not a corpus cache of this version", path); fclose(f); return NULL; }
     uint64_t want = sizeof h + (uint64_t)h.n * 9 + (uint64_t)h.nt * 6 + ((uint64_t)h.nsent + 1) * 8 + (uint64_t)h.nlex * (sizeof(cgx_lexkey) + sizeof(cgx_lexval))
-                  + ((uint64_t)h.nsvocab + h.ntvocab) * 4 + h.sbytes + h.tbytes;
+                  + ((uint64_t)h.nsvocab + h.ntvocab) * 4 + h.sbytes + h.tbytes + ((h.reserved & CACHE_LONG) ? (uint64_t)h.nt * 4 : 0);
     fseek(f, 0, SEEK_END); uint64_t have = (uint64_t)ftell(f); fseek(f, (long)sizeof h, SEEK_SET);
-    if (have != want || h.n < 4 || h.nt < 2) { snprintf(err, errcap, "corpus cache \"%s\" is truncated or corrupt (%llu bytes, header says %llu)", path, (unsigned long long)have, (unsigned long long)want); fclose(f); return NULL; }
+    if (have != want || h.n < 4 || h.nt < 2 || (h.reserved & ~CACHE_LONG)) { snprintf(err, errcap, "corpus cache \"%s\" is truncated or corrupt (%llu bytes, header says %llu)", path, (unsigned long long)have, (unsigned long long)want); fclose(f); return NULL; }
     c = calloc(1, sizeof *c);
     if (!c) { fclose(f); return NULL; }
     c->n = h.n; c->nt = h.nt; c->nsent = (int32_t)h.nsent; c->nlex = h.nlex; c->nsvocab = (int32_t)h.nsvocab; c->ntvocab = (int32_t)h.ntvocab; c->maxword = h.maxword;
+    c->long_pos = (h.reserved & CACHE_LONG) != 0;
     int ok = 1;
 #define GET(field, count, size) do { if (ok) { (field) = malloc((size_t)(count) * (size) + 16); if (!(field) || ((count) && fread((field), (size), (count), f) != (size_t)(count))) ok = 0; } } while (0)
     GET(c->str, c->n, 4); GET(c->tstr, c->nt, 4); GET(c->sentind, (size_t)c->nsent + 1, 4); GET(c->tsentind, (size_t)c->nsent + 1, 4);
     GET(c->P, c->n, 1); GET(c->rlp, c->n, 4); GET(c->ltar, c->nt, 1); GET(c->rtar, c->nt, 1);
+    if (c->long_pos) { GET(c->ltar16, c->nt, 2); GET(c->rtar16, c->nt, 2); }
     GET(c->lexk, c->nlex, sizeof *c->lexk); GET(c->lexv, c->nlex, sizeof *c->lexv);
 #undef GET
     if (ok && (cache_words(f, c->nsvocab, &c->svocab, &c->svlen) || cache_words(f, c->ntvocab, &c->tvocab, &c->tvlen))) ok = 0;
@@ -641,6 +679,7 @@ cgx_corpus *cgx_corpus_load_cache(const char *path, char *err, size_t errcap) {
         if (!what && (c->sentind[0] != 0 || c->tsentind[0] != 0)) what = "sentence table";
         for (int32_t q = 0; !what && q < c->nsent; q++) if (c->sentind[q + 1] <= c->sentind[q] || (uint32_t)c->sentind[q + 1] > c->n || c->tsentind[q + 1] <= c->tsentind[q] || (uint32_t)c->tsentind[q + 1] > c->nt) what = "sentence table";
         for (uint32_t i = 0; !what && i < c->nlex; i++) if (c->lexk[i].src < -1 || c->lexk[i].src >= c->nsvocab || c->lexk[i].tgt < -1 || c->lexk[i].tgt >= c->ntvocab) what = "lexical table id";
+        for (uint32_t i = 0; !what && c->long_pos && i < c->nt; i++) if ((c->ltar16[i] != 0xFFFF && c->ltar16[i] >= LONG_MAX_SRC) || (c->rtar16[i] != 0xFFFF && c->rtar16[i] >= LONG_MAX_SRC)) what = "alignment position";
         if (!what && cgx_corpus_checksum(c) != h.checksum) what = "checksum";
         if (what) { snprintf(err, errcap, "corpus cache \"%s\" is corrupt (%s)", path, what); ok = 0; }
     }

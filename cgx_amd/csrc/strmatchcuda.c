@@ -9,7 +9,9 @@
  * grammar.<q>.s.gz through zlib instead of plain files), --sub-batch N (queries per internal batch; default: as many as
  * hold 300 000 query tokens.  Any split writes the same files), --long-sentences (accept sentence pairs of 255 tokens and more,
  * which the reference rejects: source < 1024, target < 2040 tokens; shorter sentences give the same files with or without it;
- * turns --index-cache off).
+ * the caches remember the mode they were written in), --query-limit N (query tokens per sentence that are looked up: the reference's first kernel launches
+ * 128 threads per query sentence, SuffixArray.cu:1374-1378, so tokens from the 129th on never match -- the default here too;
+ * N = 0 lifts the limit, any other N sets it).
  */
 #include "../../include/cgx.h"
 #include <stdio.h>
@@ -24,7 +26,7 @@ static void print_help(void) {
 }
 
 int main(int argc, char **argv) {
-    int minmatchlen = 1, fingerlen = 10, device = 0, shard = 0, nshard = 1, gz = 0, sub_batch = 0, long_sentences = 0; const char *timefile = NULL, *cache = NULL;
+    int minmatchlen = 1, fingerlen = 10, device = 0, shard = 0, nshard = 1, gz = 0, sub_batch = 0, long_sentences = 0, query_limit = -1; const char *timefile = NULL, *cache = NULL;
     /* pull the long options out first so getopt sees the reference's grammar only */
     char **av = malloc(sizeof(char *) * (size_t)(argc + 1)); int ac = 0;
     for (int i = 0; i < argc; i++) {
@@ -32,6 +34,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--index-cache") && i + 1 < argc) cache = argv[++i];
         else if (!strcmp(argv[i], "--gz") && i + 1 < argc) { gz = atoi(argv[++i]); if (gz < 1 || gz > 9) print_help(); }
         else if (!strcmp(argv[i], "--long-sentences")) long_sentences = 1;
+        else if (!strcmp(argv[i], "--query-limit") && i + 1 < argc) { query_limit = atoi(argv[++i]); if (query_limit < 0) print_help(); }
         else if (!strcmp(argv[i], "--sub-batch") && i + 1 < argc) { sub_batch = atoi(argv[++i]); if (sub_batch < 1) print_help(); }
         else if (!strcmp(argv[i], "--shard") && i + 1 < argc) { if (sscanf(argv[++i], "%d/%d", &shard, &nshard) != 2 || nshard < 1 || shard < 0 || shard >= nshard) print_help(); }
         else av[ac++] = argv[i];
@@ -59,10 +62,13 @@ int main(int argc, char **argv) {
     fclose(qf);
 
     char err[512];
-    if (long_sentences) cache = NULL;                      /* the caches hold the reference's byte positions only */
     cgx_corpus *corpus = cache ? cgx_corpus_load_cache(cache, err, sizeof err) : NULL;
     if (cache && corpus && cgx_corpus_matches_sources(corpus, src, tgt, ali, lex) == 0) {   /* a text file changed since the cache was written: parse again */
         fprintf(stderr, "strmatchcuda: corpus cache %s is older than the text files, rebuilding it\n", cache);
+        cgx_corpus_free(corpus); corpus = NULL;
+    }
+    if (cache && corpus && (cgx_corpus_flags(corpus) & CGX_CORPUS_LONG_SENTENCES) != (long_sentences ? CGX_CORPUS_LONG_SENTENCES : 0)) {   /* parsed under the other position width */
+        fprintf(stderr, "strmatchcuda: corpus cache %s was written %s --long-sentences, rebuilding it\n", cache, long_sentences ? "without" : "with");
         cgx_corpus_free(corpus); corpus = NULL;
     }
     if (cache && corpus) fprintf(stderr, "strmatchcuda: corpus read from cache %s\n", cache);
@@ -97,6 +103,7 @@ int main(int argc, char **argv) {
     uint64_t nrules = 0;
     if (gz) (void)cgx_set_option(ctx, "gz_level", gz);       /* grammar.<q>.s.gz instead of grammar.<q>.s */
     if (sub_batch) (void)cgx_set_option(ctx, "sub_batch", sub_batch);
+    if (query_limit >= 0) (void)cgx_set_option(ctx, "k1_limit", query_limit);   /* 0: no limit */
     (void)cgx_set_option(ctx, "async_write", 1);             /* large query files run as several internal batches: write batch k while batch k+1 is on the GPU */
     rc = nshard == 1 ? cgx_extract_grammars(ctx, corpus, qry, out, 0, -1, &nrules)
                      : cgx_extract_grammars_shard(ctx, corpus, qry, out, shard, nshard, &nrules);   /* contiguous shards balanced by token count */

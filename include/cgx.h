@@ -78,7 +78,7 @@ typedef struct {
 cgx_ctx *cgx_create(int device);                       /* replaces suffixArraySearchInit (SuffixArray.cu:769) */
 void cgx_destroy(cgx_ctx *ctx);                        /* replaces suffixArraySearchFinalize*, extractPairFinalize */
 const char *cgx_last_error(cgx_ctx *ctx);
-int cgx_set_option(cgx_ctx *ctx, const char *name, int64_t value); /* "k1_limit" (default 128), "chunk_items", "force_host_lexicon", "async_write", "prealloc_text" (default 0; 1 = a caller that will submit several batches with async_write asks for both text buffers to be allocated at the first one), "use_bigrams" (default 1), "use_lex_hash" (default 1), "device_format" (default 1), "gz_level" (0 = plain grammar.<q>.s; 1..9 = grammar.<q>.s.gz) and "gz_device" (default 1: with the device formatter the gzip members are produced on the GPU and gz_level only switches them on; 0 = the host's zlib compresses the plain text at gz_level), "sub_batch" (queries per internal batch of cgx_extract_grammars*; 0 = automatic: at most "auto_batch_tokens" (default 300000) query tokens per internal batch; with async_write the writer of one sub-batch overlaps the GPU work of the next), "write_period" / "write_count" (with a period P > 0 only the files of queries g with g % P < count are written, g = index in the whole query list; rules are counted for all, and an internal batch without such a query lays out no text: full-count runs that sample their output), "src_blocks" (default 1; 0 = the lookups locate a sentence's target-side alignment bytes through the delimiter's alignment word instead of the source-addressed copy of the blocks: A/B and test hook), "wide_hits2", "look_rec_cap", "pool_cap", "fault_inject", "append_slack", "append_guess_milli" (test hooks for the lookup output sizing) */
+int cgx_set_option(cgx_ctx *ctx, const char *name, int64_t value); /* "k1_limit" (default 128: query tokens per sentence that are looked up, the reference's K1 launch width; 0 = no limit), "chunk_items", "force_host_lexicon", "async_write", "prealloc_text" (default 0; 1 = a caller that will submit several batches with async_write asks for both text buffers to be allocated at the first one), "use_bigrams" (default 1), "use_lex_hash" (default 1), "device_format" (default 1), "gz_level" (0 = plain grammar.<q>.s; 1..9 = grammar.<q>.s.gz) and "gz_device" (default 1: with the device formatter the gzip members are produced on the GPU and gz_level only switches them on; 0 = the host's zlib compresses the plain text at gz_level), "sub_batch" (queries per internal batch of cgx_extract_grammars*; 0 = automatic: at most "auto_batch_tokens" (default 300000) query tokens per internal batch; with async_write the writer of one sub-batch overlaps the GPU work of the next), "write_period" / "write_count" (with a period P > 0 only the files of queries g with g % P < count are written, g = index in the whole query list; rules are counted for all, and an internal batch without such a query lays out no text: full-count runs that sample their output), "src_blocks" (default 1; 0 = the lookups locate a sentence's target-side alignment bytes through the delimiter's alignment word instead of the source-addressed copy of the blocks: A/B and test hook), "wide_hits2", "look_rec_cap", "pool_cap", "fault_inject", "append_slack", "append_guess_milli" (test hooks for the lookup output sizing) */
 
 /* ---- index: upload, device suffix-array construction, frequent-pair precomputation ---- */
 int cgx_upload_index(cgx_ctx *ctx, const cgx_index_host *ix);   /* H2D of the index (SuffixArray.cu:1396-1412, ExtractPair.cu:3279-3282) */
@@ -169,7 +169,13 @@ double cgx_stage_ms(cgx_ctx *ctx, const char *name);
 typedef struct cgx_corpus cgx_corpus;
 cgx_corpus *cgx_corpus_load(const char *src, const char *tgt, const char *align, const char *lex, char *err, size_t errcap);
 #define CGX_CORPUS_LONG_SENTENCES 1   /* accept sentence pairs of 255 tokens and more (source < 1024, target < 2040 tokens): positions wider than the reference's bytes; results for shorter sentences are unchanged */
-cgx_corpus *cgx_corpus_load_opt(const char *src, const char *tgt, const char *align, const char *lex, int flags, char *err, size_t errcap);   /* cgx_corpus_load with options (strmatchcuda --long-sentences); such a corpus is not written to the corpus / index caches */
+cgx_corpus *cgx_corpus_load_opt(const char *src, const char *tgt, const char *align, const char *lex, int flags, char *err, size_t errcap);   /* cgx_corpus_load with options (strmatchcuda --long-sentences); the corpus and index caches record the mode */
+int cgx_corpus_flags(const cgx_corpus *c);                  /* CGX_CORPUS_LONG_SENTENCES when the corpus carries wide positions (loaded with that flag, from a cache written in that mode, or built by cgx_corpus_from_ids16) */
+/* cgx_corpus_from_ids for sentence pairs of 255 tokens and more (long-sentence mode; the reference refuses them, ExtractPair.cu:2683): the four alignment
+ * tables as 16-bit words, 0xFFFF = not aligned; source sentences < 1024 tokens, target sentences < 2040.  NULL on a position or sentence out of that range. */
+cgx_corpus *cgx_corpus_from_ids16(const int32_t *str, uint32_t n, const int32_t *sentind, int32_t nsent, const int32_t *tstr, uint32_t nt,
+                                  const int32_t *tsentind, const uint16_t *lsrc, const uint16_t *rsrc, const uint16_t *ltar, const uint16_t *rtar,
+                                  const cgx_lexkey *lexk, const cgx_lexval *lexv, uint32_t nlex);
 void cgx_corpus_free(cgx_corpus *c);
 uint64_t cgx_corpus_checksum(const cgx_corpus *c);               /* FNV-1a over every array and spelling of the loaded corpus */
 int cgx_corpus_save(const cgx_corpus *c, const char *path);      /* the parsed corpus as one binary file (the reference's own index cache is commented out, SuffixArray.c:208-230) */

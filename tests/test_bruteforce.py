@@ -176,3 +176,46 @@ def test_long_sentence_mode_of_the_oracle_agrees_with_the_definitions(oracle_bin
     assert done > 100
     hits_of = bf.hit_lists(d["s1"], d["hits1"], d["pidx"], d["phits"]["start"], d["phits"]["length"])
     assert bf.check_extension_rules(c, d["sa"], d["blocks"], d["s1"], hits_of, d["r1"], h["sep1"], d["r2"], h["sep2a"], h["sep2b"]) > 1000
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("limit", [128, 1000, 0])
+def test_query_token_limit_against_the_definitions(limit, oracle_bin, fixtures_dir, tmp_path):
+    """the reference's first kernel launches 128 threads per query sentence (SuffixArray.cu:1374-1378), so a query's
+    tokens from the 129th on never match.  Option "k1_limit" (strmatchcuda --query-limit): the default keeps that, 1000 moves the
+    limit, 0 lifts it.  Queries of 150..260 tokens cut from the corpus (so that they match far beyond position 128), the HIP path
+    against the definitions: longest matches under the limit, enumeration, pattern ids, per-query lists, hit sets and rules."""
+    import torch
+    torch.zeros(1, device="cuda:0")
+    import cgx_amd as cgx
+    fx = make_fixture("mid", fixtures_dir); dump = str(tmp_path / "d.bin")
+    op.run_oracle(oracle_bin, fx, str(tmp_path / "o"), dump)               # only for the id-level input arrays of the fixture
+    d = op.read_dump(dump); h = d["hdr"]; n, nt = h["n"], h["nt"]
+    s = np.asarray(d["str"][:n], np.int64); rng = np.random.default_rng(40 + limit)
+    words = s[s >= 2]
+    qtok, qoff = [], []
+    for ln in (150, 260, 129, 7, 200, 128):                              # long and short queries mixed; pieces of corpus text glued together
+        qoff.append(len(qtok)); got = 0
+        while got < ln:
+            a = int(rng.integers(0, len(words) - 20)); m = min(int(rng.integers(3, 12)), ln - got)
+            qtok += [int(x) for x in words[a:a + m]]; got += m
+    qoff = np.asarray(qoff, np.int32); qtok = np.asarray(qtok, np.int32)
+    ex = cgx.Extractor(0)
+    if limit != 128:
+        ex.set_option("k1_limit", limit)
+    ex.upload_index(d["str"][:n], d["rlp"], d["tstr"][:nt], d["ltar"], d["rtar"], d["lexk"], d["lexv"])
+    ex.build_sa(); ex.precompute(); ex.upload_queries(qoff, qtok); ex.sa_lookup(); ex.make_blocks(); ex.gappy_search(); ex.extract(); ex.lexicon(); ex.count_rules()
+    c = bf.Corpus(d["str"][:n], d["rlp"], d["ltar"], d["rtar"]); k = ex.counts()
+    lm = ex.fetch("lm"); eff = limit if limit > 0 else 1 << 30
+    in_pos = np.concatenate([np.arange(b - a) for a, b in zip(qoff, list(qoff[1:]) + [len(qtok)])])
+    assert (lm[in_pos >= eff] == 0).all()
+    assert (lm[in_pos >= 128] > 0).any() == (eff > 128)                    # the limit is what keeps the late tokens from matching
+    s1, s2, p1d, c2d = ex.fetch("s1"), ex.fetch("s2"), ex.fetch("p1d"), ex.fetch("c2d")
+    a, b = bf.check_query_side(c, qoff, qtok, lm, k["e1"], s1, p1d, _csr(ex.fetch("qo_off"), ex.fetch("qo_ids")),
+                               k["e2"], s2, c2d, _csr(ex.fetch("qt_off"), ex.fetch("qt_ids")), k1_limit=eff)
+    assert (a, b) == (k["d1"], k["d2"]) and a > 100
+    pick = sorted(set(range(100)) | set(int(x) for x in np.random.default_rng(12).integers(0, max(int(k["d1"]), 1), 800)))
+    done = bf.check_batch(c, ex.fetch("sa"), ex.fetch("freq"), _phits(ex.fetch("pidx"), ex.fetch("phit_start"), ex.fetch("phit_len")), s1, p1d,
+                          ex.fetch("hits1"), s2, c2d, ex.fetch("hits2"), ex.fetch("blocks"), ex.fetch("r0"), ex.fetch("r1"), k["sep1"], ex.fetch("r2"), k["sep2a"], k["sep2b"], max_patterns=100, pick=pick)
+    assert done > 100 and k["guard_exits"] == 0
+    ex.close()

@@ -98,6 +98,26 @@ def test_cli_is_a_drop_in(cgx, oracle_bin, fixtures_dir, tmp_path):
     assert r.returncode == 0 and "It is not valid" in r.stderr          # PrintResults.c:443-446
 
 
+def test_cli_query_limit_switch(cgx, fixtures_dir, tmp_path):
+    """strmatchcuda --query-limit N: the default and 128 keep the reference's 128 looked-up tokens per query sentence
+    (SuffixArray.cu:1374-1378), 0 lifts the limit: a 300-token query then yields rules for its late tokens too."""
+    fx = make_fixture("toy", fixtures_dir); files = op.fixture_args(fx)
+    words = open(files[0]).read().split()
+    q = tmp_path / "long.f"; q.write_text(" ".join(words[:300]) + "\n" + " ".join(words[300:320]) + "\n")
+    args = [files[0], str(q), files[2], files[3], files[4]]
+    sizes = {}
+    for tag, extra in (("default", []), ("l128", ["--query-limit", "128"]), ("l0", ["--query-limit", "0"]), ("l200", ["--query-limit", "200"])):
+        out = tmp_path / tag; out.mkdir()
+        r = subprocess.run([os.path.join(ROOT, "bin", "strmatchcuda")] + extra + args + [str(out)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        sizes[tag] = [open(str(out / ("grammar.%d.s" % i)), "rb").read() for i in range(2)]
+    assert sizes["default"] == sizes["l128"]
+    assert sizes["l0"][1] == sizes["default"][1]                              # the short query does not notice
+    assert len(sizes["default"][0]) < len(sizes["l200"][0]) < len(sizes["l0"][0])
+    r = subprocess.run([os.path.join(ROOT, "bin", "strmatchcuda"), "--query-limit", "-3"] + args + [str(tmp_path / "l0")], capture_output=True, text=True, timeout=60)
+    assert "Please check your input arguments" in r.stdout
+
+
 def _gunzip_three_ways(path):
     """The bytes of a .gz file as Python's gzip, the zcat program and zlib's gzread give them; all three must agree."""
     import ctypes as C

@@ -3,6 +3,7 @@ same first-appearance word ids, same arrays, same alignment bytes -- and report 
 import os
 import shutil
 
+import numpy as np
 import pytest
 
 import oracle_py as op
@@ -125,3 +126,31 @@ def test_mutated_inputs_never_fault(cgx):
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_loaders.py"), "--cases", "80", "--seed", "5"], capture_output=True, timeout=600)
     assert r.returncode == 0, r.stderr.decode(errors="replace")[-2000:]
     assert b"fuzz_loaders: 80 cases" in r.stdout
+
+
+def test_corpus_cache_keeps_long_sentence_mode(cgx, fixtures_dir, tmp_path):
+    """Cache format 4: a corpus parsed with CGX_CORPUS_LONG_SENTENCES -- sentence pairs of 240..330 tokens, which the
+    reference refuses -- is written with its 16-bit target tables and comes back as the same corpus in the same mode; a corpus
+    within the reference's limits comes back in the mode it was parsed in; a flipped 16-bit position fails the checks."""
+    from test_oracle import make_long_fixture
+    lf = make_long_fixture(fixtures_dir); files = op.fixture_args(lf)
+    with pytest.raises(cgx.CgxError, match="too long sentence"):
+        cgx.Corpus.load(files[0], files[2], files[3], files[4])
+    c = cgx.Corpus.load(files[0], files[2], files[3], files[4], long_sentences=True)
+    assert c.flags() == 1
+    path = str(tmp_path / "long.cgx"); c.save(path); want = c.checksum(); c.close()
+    c2 = cgx.Corpus.load_cache(path); assert c2.checksum() == want and c2.flags() == 1; c2.close()
+    fx = make_fixture("tiny", fixtures_dir); f = op.fixture_args(fx)
+    for mode in (False, True):
+        c = cgx.Corpus.load(f[0], f[2], f[3], f[4], long_sentences=mode); p2 = str(tmp_path / ("tiny%d.cgx" % mode)); c.save(p2); w = c.checksum(); c.close()
+        c2 = cgx.Corpus.load_cache(p2); assert c2.checksum() == w and c2.flags() == int(mode); c2.close()
+    assert os.path.getsize(str(tmp_path / "tiny1.cgx")) > os.path.getsize(str(tmp_path / "tiny0.cgx"))
+    # the 16-bit tables sit behind the byte tables: a position pushed out of range there is caught (range check or checksum)
+    raw = bytearray(open(path, "rb").read()); hdr = np.frombuffer(bytes(raw[:48]), np.uint32)
+    n, nt, nsent = int(hdr[4]), int(hdr[5]), int(hdr[6])
+    hdr_bytes = 8 + 8 + 8 * 4 + 16 + 64
+    off16 = hdr_bytes + n * 4 + nt * 4 + (nsent + 1) * 8 + n + n * 4 + nt + nt
+    raw[off16 + 1] = 0x7F                                     # high byte of the first 16-bit position: 0x7Fxx is beyond 1024 and not the "not aligned" mark
+    bad = str(tmp_path / "bad.cgx"); open(bad, "wb").write(bytes(raw))
+    with pytest.raises(cgx.CgxError, match="corrupt"):
+        cgx.Corpus.load_cache(bad)
