@@ -371,7 +371,7 @@ def main():
     whole = all(len(q["chunks"]) == 1 for q in qsets)
     spool_bytes = [0]
 
-    stage_names = ("sa_lookup", "blocks", "gappy", "extract", "lexicon", "format", "fmt_count", "fmt_write", "look1_kernel", "look2_kernel")
+    stage_names = ("sa_lookup", "blocks", "gappy", "extract", "lexicon", "format", "fmt_count", "fmt_write", "look1_kernel", "look2_kernel", "select_hits", "select_long1", "select_long2", "sort_lists1", "sort_lists2")
     host_names = ("write", "write_wait_d2h", "write_file", "total", "t_upload_sa", "t_blocks", "t_gappy", "t_extract", "t_lexicon", "t_format", "t_flush_wait")
     def new_acc():
         return {"on": False, "kernel_ms": [], "stage": {k: 0.0 for k in stage_names}, "host": {k: 0.0 for k in host_names},

@@ -53,7 +53,7 @@ ABI = [
     "cgx_stage_ms", "cgx_corpus_load", "cgx_corpus_free", "cgx_corpus_checksum", "cgx_corpus_save", "cgx_corpus_load_cache", "cgx_corpus_matches_sources", "cgx_corpus_upload", "cgx_extract_grammars", "cgx_extract_grammars_shard", "cgx_shard_bounds", "cgx_extract_grammars_ids",
     "cgx_corpus_from_ids", "cgx_host_ms", "cgx_flush", "cgx_fetch_pinned", "cgx_pinned_next_batch", "cgx_upload_vocab", "cgx_upload_score_tables", "cgx_set_query_blocks",
     "cgx_format", "cgx_text_info", "cgx_text_encoding", "cgx_assemble_files_enc", "cgx_text_segments", "cgx_text_segments_begin", "cgx_text_offsets", "cgx_text_read", "cgx_text_read_begin", "cgx_text_read_wait", "cgx_pinned_alloc", "cgx_pinned_free", "cgx_assemble_files", "cgx_corpus_load_opt",
-    "cgx_corpus_flags", "cgx_corpus_from_ids16",
+    "cgx_corpus_flags", "cgx_corpus_from_ids16", "cgx_text_trailers", "cgx_text_trailers_begin",
 ]
 
 
@@ -349,8 +349,16 @@ class Extractor:
             self.lib.cgx_pinned_free(buf)
         return text, qseg, so[:int(ns.value)], sl[:int(ns.value)], qtext
 
+    def text_trailers(self, slot, nq):
+        """CRC-32 and ISIZE of every file of a slot of deflate pieces: u32[nq, 2]."""
+        trl = np.zeros((max(nq, 1), 2), np.uint32)
+        self.lib.cgx_text_trailers.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        self._chk(self.lib.cgx_text_trailers(self.h, slot, _ptr(trl)), "cgx_text_trailers")
+        return trl[:nq]
+
     def text_encoding(self, slot):
-        """0: the slot holds plain text; 1: gzip members, one per emission group (option gz_level with gz_device)."""
+        """0: the slot holds plain text; 1: deflate blocks, one per emission group, every piece a byte-aligned stretch of a deflate
+        stream (option gz_level with gz_device): a file is the gzip header, its pieces, 03 00, CRC-32, ISIZE (text_trailers)."""
         self.lib.cgx_text_encoding.argtypes = [C.c_void_p, C.c_int]
         rc = self.lib.cgx_text_encoding(self.h, slot)
         if rc < 0:

@@ -48,7 +48,8 @@ struct cgx_ctx {
     bool gz_device = true;              // with gz_level and the device formatter: the formatter emits the gzip members itself (cgx_fmt.h); 0 = the host's zlib at gz_level compresses the plain text
     uint32_t *d_gztab = nullptr;        // CRC tables of the member trailers (GZ_TAB_WORDS words)
     unsigned int *d_rs_long = nullptr;  // run_sort: runs longer than the fix pass's LDS buffer met so far (slow path taken; cgx_stage_ms "run_sort_long_runs")
-    bool text_gz[2] = {false, false};   // what the text slot holds: gzip members / plain text
+    bool text_gz[2] = {false, false};   // what the text slot holds: deflate pieces / plain text
+    uint32_t *d_trl[2] = {nullptr, nullptr};   // deflate pieces: CRC-32 and ISIZE of every query's file (k_gz_files)
     bool occ_order = true;              // one-token driving phrases take their occurrences in corpus order (d_pos1) instead of suffix order (test / A-B hook)
     bool src_blocks = true;             // the lookups find a sentence's target-side bytes from its source start (d_lrs); 0 = through the delimiter's alignment word (test / A-B hook)
     bool use_layouts = true;            // test hook: 0 = window kernels read the plain str / rlp / ltar / rtar arrays (round-1 access pattern)
@@ -63,7 +64,8 @@ struct cgx_ctx {
     int64_t fault_inject = 0;           // test hook: the n-th device allocation from now fails
     uint32_t pool_cap = 1u << 30;       // test hook: entries of the per-block append pool in use (clamped to POOL_N)
     uint32_t look_rec_cap = 65535;      // test hook: groups with more records than this read them from global memory
-    bool wide_hits2 = false;            // test hook: take the >2^24-distinct-two-gap-patterns path
+    bool wide_hits2 = false;            // test hook: take the path of two-gap pattern ids that do not fit beside the occurrence
+    bool hit_order = false;             // 1: the hit lists are sorted completely (what cgx_fetch "hits1" / "hits2" callers may want); 0: as far as extraction needs
     int32_t freq[100] = {0};
 
     // ---- batch ----
@@ -74,6 +76,9 @@ struct cgx_ctx {
     uint32_t e1 = 0, d1 = 0, h1 = 0, e2 = 0, d2 = 0, h2 = 0;
     cgx_gappy *d_g1 = nullptr; cgx_gappat *d_p1 = nullptr; uint32_t *d_pid1 = nullptr; cgx_gapsearch *d_s1 = nullptr; cgx_hit1 *d_hits1 = nullptr;
     cgx_twogappy *d_g2 = nullptr; int32_t *d_c2 = nullptr; uint32_t *d_pid2 = nullptr; cgx_twogapsearch *d_s2 = nullptr; cgx_hit2 *d_hits2 = nullptr;
+    // the hit lists as the stages use them (cgx_search.inc "hitview"): 64-bit keys grouped by pattern, ordered inside a pattern by the top bits of the
+    // start position (okey >> hb) or completely (hit_order); d_hits1 / d_hits2 above are made from them on request (cgx_fetch)
+    uint64_t *d_hk1 = nullptr, *d_hk2 = nullptr; uint32_t *d_hid2 = nullptr; unsigned hs1 = 4, hs2 = 4, hb1 = 0, hb2 = 0;
     cgx_gappat *d_p1d = nullptr; int32_t *d_c2d = nullptr; uint32_t *d_one2 = nullptr;   // per distinct pattern
     uint32_t g = 0; cgx_block *d_blocks = nullptr;
     uint32_t n0 = 0, n1 = 0, n2 = 0, sep1 = 0, sep2a = 0, sep2b = 0, guard_exits = 0;

@@ -479,8 +479,8 @@ extern "C" cgx_ctx *cgx_create(int device) {
 }
 static void free_batch(cgx_ctx *c) {
     dfree(c->d_qoff); dfree(c->d_qtok); dfree(c->d_tok2q); dfree(c->d_lm); dfree(c->d_up); dfree(c->d_down);
-    dfree(c->d_g1); dfree(c->d_p1); dfree(c->d_pid1); dfree(c->d_s1); dfree(c->d_hits1);
-    dfree(c->d_g2); dfree(c->d_c2); dfree(c->d_pid2); dfree(c->d_s2); dfree(c->d_hits2); dfree(c->d_p1d); dfree(c->d_c2d); dfree(c->d_one2);
+    dfree(c->d_g1); dfree(c->d_p1); dfree(c->d_pid1); dfree(c->d_s1); dfree(c->d_hits1); dfree(c->d_hk1);
+    dfree(c->d_g2); dfree(c->d_c2); dfree(c->d_pid2); dfree(c->d_s2); dfree(c->d_hits2); dfree(c->d_hk2); dfree(c->d_hid2); dfree(c->d_p1d); dfree(c->d_c2d); dfree(c->d_one2);
     dfree(c->d_qb_off); dfree(c->d_qb_ids); dfree(c->d_qo_off); dfree(c->d_qo_ids); dfree(c->d_qt_off); dfree(c->d_qt_ids); c->nqo = c->nqt = 0;
     dfree(c->d_blocks); dfree(c->d_r0); dfree(c->d_r1); dfree(c->d_r2); dfree(c->d_lex0); dfree(c->d_lex1); dfree(c->d_lex2); dfree(c->d_rng0); dfree(c->d_rng1); dfree(c->d_rng2); c->nl0 = c->nl1 = c->nl2 = 0;
     c->e1 = c->d1 = c->h1 = c->e2 = c->d2 = c->h2 = c->g = c->n0 = c->n1 = c->n2 = c->sep1 = c->sep2a = c->sep2b = 0;
@@ -499,7 +499,7 @@ extern "C" void cgx_destroy(cgx_ctx *c) {
     (void)hipSetDevice(c->device);
     free_batch(c); free_index(c);
     for (int a = 0; a < 2; a++) if (c->arena[a]) { (void)hipHostFree(c->arena[a]); c->arena[a] = nullptr; }
-    for (int a = 0; a < 2; a++) { dfree(c->d_text[a]); dfree(c->d_qtext[a]); dfree(c->d_seg_off[a]); dfree(c->d_seg_len[a]); dfree(c->d_qseg[a]); }
+    for (int a = 0; a < 2; a++) { dfree(c->d_text[a]); dfree(c->d_qtext[a]); dfree(c->d_seg_off[a]); dfree(c->d_seg_len[a]); dfree(c->d_qseg[a]); dfree(c->d_trl[a]); }
     dfree(c->d_spool); dfree(c->d_soff); dfree(c->d_tpool); dfree(c->d_toff); dfree(c->d_aa); dfree(c->d_bb); dfree(c->d_fs); dfree(c->d_gztab); dfree(c->d_rs_long);
     if (c->sync_ev) (void)hipEventDestroy(c->sync_ev);
     for (int r = 0; r < CGX_COPY_STREAMS; r++) if (c->copy_streams[r]) (void)hipStreamDestroy(c->copy_streams[r]);
@@ -528,6 +528,7 @@ extern "C" int cgx_set_option(cgx_ctx *c, const char *name, int64_t value) {
     if (!strcmp(name, "prealloc_text")) { c->prealloc_text = value != 0; return CGX_OK; }
     if (!strcmp(name, "use_lex_hash")) { c->use_lex_hash = value != 0; return CGX_OK; }
     if (!strcmp(name, "wide_hits2")) { c->wide_hits2 = value != 0; return CGX_OK; }
+    if (!strcmp(name, "hit_order")) { c->hit_order = value != 0; return CGX_OK; }
     if (!strcmp(name, "write_period")) { if (value < 0) return CGX_ERR_ARG; c->write_period = value; return CGX_OK; }
     if (!strcmp(name, "write_count")) { if (value < 0) return CGX_ERR_ARG; c->write_count = value; return CGX_OK; }
     if (!strcmp(name, "fault_inject")) { c->fault_inject = value; return CGX_OK; }
@@ -599,9 +600,10 @@ static void memory_report(cgx_ctx *c) {
     double ngram = 0; for (int k = 0; k < 4; k++) ngram += sz(c->d_ng[k]);
     const double layouts = sz(c->d_tok8) + sz(c->d_lr16) + sz(c->d_lrs) + sz(c->d_pos1), lexhash = sz(c->d_lexslot) + sz(c->d_lexnullv) + sz(c->d_lexhkey) + sz(c->d_lexhidx);
     derived = ngram + layouts + lexhash;
-    for (int a = 0; a < 2; a++) text += sz(c->d_text[a]) + sz(c->d_qtext[a]) + sz(c->d_seg_off[a]) + sz(c->d_seg_len[a]) + sz(c->d_qseg[a]);
+    for (int a = 0; a < 2; a++) text += sz(c->d_text[a]) + sz(c->d_qtext[a]) + sz(c->d_seg_off[a]) + sz(c->d_seg_len[a]) + sz(c->d_qseg[a]) + sz(c->d_trl[a]);
     for (const void *p : {(const void *)c->d_qoff, (const void *)c->d_qtok, (const void *)c->d_tok2q, (const void *)c->d_lm, (const void *)c->d_up, (const void *)c->d_down,
                           (const void *)c->d_g1, (const void *)c->d_p1, (const void *)c->d_pid1, (const void *)c->d_s1, (const void *)c->d_hits1, (const void *)c->d_g2, (const void *)c->d_c2, (const void *)c->d_pid2, (const void *)c->d_s2, (const void *)c->d_hits2,
+                          (const void *)c->d_hk1, (const void *)c->d_hk2, (const void *)c->d_hid2,
                           (const void *)c->d_p1d, (const void *)c->d_c2d, (const void *)c->d_one2, (const void *)c->d_blocks, (const void *)c->d_r0, (const void *)c->d_r1, (const void *)c->d_r2,
                           (const void *)c->d_rng0, (const void *)c->d_rng1, (const void *)c->d_rng2, (const void *)c->d_lex0, (const void *)c->d_lex1, (const void *)c->d_lex2,
                           (const void *)c->d_qb_off, (const void *)c->d_qb_ids, (const void *)c->d_qo_off, (const void *)c->d_qo_ids, (const void *)c->d_qt_off, (const void *)c->d_qt_ids}) batch += sz(p);
@@ -637,6 +639,15 @@ extern "C" int64_t cgx_fetch(cgx_ctx *ctx, const char *name, void *dst, int64_t 
     uint32_t counts[16] = { ctx->e1, ctx->d1, ctx->h1, ctx->e2, ctx->d2, ctx->h2, ctx->g, ctx->n0, ctx->n1, ctx->n2, ctx->sep1, ctx->sep2a, ctx->sep2b,
                             ctx->nphits, ctx->guard_exits, (uint32_t)ctx->last };
     std::string s(name);
+    // the reference's hit records are made from the device's keys when somebody asks for them
+    if (s == "hits1" && dst && !ctx->d_hits1 && ctx->h1 && ctx->d_hk1) {
+        if (dalloc(ctx, &ctx->d_hits1, ctx->h1) != CGX_OK) return CGX_ERR_NOMEM;
+        k_unpack_hits1<<<nblocks(ctx->h1, 256), 256, 0, ctx->stream>>>(hits1_view(ctx), ctx->h1, ctx->d_hits1);
+    }
+    if (s == "hits2" && dst && !ctx->d_hits2 && ctx->h2 && ctx->d_hk2) {
+        if (dalloc(ctx, &ctx->d_hits2, ctx->h2) != CGX_OK) return CGX_ERR_NOMEM;
+        k_unpack_hits2<<<nblocks(ctx->h2, 256), 256, 0, ctx->stream>>>(hits2_view(ctx), ctx->h2, ctx->d_hits2);
+    }
 #define ENT(nm, ptr, cnt, T) if (s == nm) { src = (ptr); bytes = (int64_t)(cnt) * (int64_t)sizeof(T); }
     ENT("sa", ctx->d_sa, ctx->n, int32_t) ENT("tokstart", ctx->d_tokstart, (size_t)ctx->last + 3, int32_t)
     ENT("freq", ctx->d_freq, CGX_TOP, int32_t) ENT("pidx", ctx->d_pidx, 2 * CGX_TOP * CGX_TOP, uint32_t) ENT("miss", ctx->d_miss, CGX_TOP * CGX_TOP, int32_t)

@@ -207,17 +207,20 @@ CGX_HD uint32_t canon_group_first(uint32_t g, uint32_t G, uint32_t D1) { if (g <
 // itself -- back-references (length, distance) where it knows the bytes stood one line earlier, literals elsewhere, the fixed
 // Huffman code of RFC 1951 3.2.6 -- and no hash chains, no window, no second look at the text are needed.
 //
-//  * One gzip MEMBER (RFC 1952) per emission group (the four items of a contiguous phrase, the three of a one-gap pattern,
-//    the one of a two-gap pattern): a grammar file is a series of whole groups, RFC 1952 2.2 allows a file to be a series of
-//    members, so a file stays a concatenation of pieces of the batch's unique text and phrases shared by thousands of
-//    queries are still formatted, compressed and sent once.  Members do not see each other: a back-reference never leaves
-//    its group.
-//  * Every line is one fixed-Huffman block followed by an empty stored block (the "sync flush" of zlib): the stored block's
-//    header pads to a byte boundary, so lines begin on bytes and the byte-offset machinery of the plain text (count -> scan ->
-//    write, one lane per line) serves unchanged.  It costs 5-6 bytes per line; a bit-granular layout would save them.
-//  * CRC-32 of a member: every line computes the CRC of its own text (byte-wise, 1 KB table in LDS) and multiplies it by
-//    x^(8 * bytes that follow it in the member) mod P (zlib's crc32_combine as a product of table entries); the member's CRC
-//    is the XOR of its lines' contributions, folded and written with ISIZE by k_gz_trailers.
+//  * One DEFLATE BLOCK per emission group (the four items of a contiguous phrase, the three of a one-gap pattern, the one of a
+//    two-gap pattern), followed by an empty stored block (zlib's "sync flush": its header pads to a byte boundary): a group's
+//    bytes are a self-contained, byte-aligned stretch of a deflate stream -- a back-reference never leaves its group -- so a
+//    grammar file is still a concatenation of pieces of the batch's unique text, and phrases shared by thousands of queries are
+//    formatted, compressed and sent once.  The file is ONE gzip member (RFC 1952): ten header bytes, the groups, an empty final
+//    block (03 00), CRC-32 and ISIZE -- header and trailer are put around the pieces by the host writer, the trailer's values
+//    come from the device (k_gz_files).
+//    (Round 4's first version made every group a gzip member of its own and every line a block of its own, ending on a byte:
+//    18 bytes per group and 5-6 per line, a quarter of the output, were framing.)
+//  * Inside a group the lines follow each other at BIT granularity: count pass (bits per line) -> scan -> bit offset of every
+//    line; the writing sink of k_fmt_lines_gz shares a line's first and last 32-bit word with its neighbours.
+//  * CRC-32: every line computes the CRC of its own text (group-wise, tables in LDS) and multiplies it by x^(8 * bytes that
+//    follow it in the group) mod P (zlib's crc32_combine as a product of table entries); a group's CRC is the XOR of its lines'
+//    contributions (k_gz_groups) and a file's the fold of its groups' (k_gz_files).
 // What a line may refer to: its predecessor in the same group (prefix through the source side when both lines belong to the
 // same item, "[X] ||| " otherwise; the tail from " ||| EgivenFCoherent=" on, name by name, a value only when it equals the
 // predecessor's), and itself (" ||| " and, in a group's first line, " IsSingletonF" / " MaxLex").  Target words are literals.
@@ -238,24 +241,11 @@ CGX_HD uint32_t gz_brev_bytes(uint32_t x) {                      // every byte o
 }
 CGX_HD uint32_t gz_log2(uint32_t x) { return 31u - (uint32_t)__builtin_clz(x); }   // x > 0
 
-// bit sinks: the counting pass only adds, the writing pass packs LSB-first and hands whole 32-bit words to a byte sink
+// bit sinks: the counting pass only adds; the writing sinks (BitWordSink in cgx_format.inc, a plain bit buffer in tests/cpu_sim)
+// pack LSB-first from the line's bit offset on
 struct BitCount {
     uint32_t n;
     CGX_HD void bits(uint32_t, uint32_t len) { n += len; }
-    CGX_HD void align() { n = (n + 7u) & ~7u; }
-    CGX_HD uint32_t bytes() const { return n >> 3; }             // after align()
-    CGX_HD void finish() {}
-};
-template <class S> struct BitOut {
-    S &o; uint64_t acc; uint32_t nb, n;
-    CGX_HD explicit BitOut(S &s) : o(s), acc(0), nb(0), n(0) {}
-    CGX_HD void bits(uint32_t code, uint32_t len) {              // len <= 32, code < 2^len
-        acc |= (uint64_t)code << nb; nb += len; n += len;
-        if (nb >= 32u) { o.wide(acc & 0xFFFFFFFFull, 4); acc >>= 32; nb -= 32u; }
-    }
-    CGX_HD void align() { const uint32_t pad = (8u - (nb & 7u)) & 7u; bits(0, pad); }
-    CGX_HD uint32_t bytes() const { return n >> 3; }
-    CGX_HD void finish() { if (nb) { o.wide(acc, nb >> 3); acc = 0; nb = 0; } }   // after align(): whole bytes only (at most 3)
 };
 
 #define GZ_POLY 0xEDB88320u
@@ -357,13 +347,20 @@ template <class Z> CGX_HD bool gz_value(Z &z, float v, float pv, uint32_t &dist)
     dist += (z.pos - p0) - fmt_f6_len(pv);
     return ok;
 }
-#define GZ_MIN_LINE 16u      // the byte sink of the writing kernel needs every line to reach past its first 16-byte unit
-// One line of a member.  Returns false when the line cannot be represented (the batch is then formatted on the host).
-// Bytes: [gzip header, first line only] fixed block { symbols, end of block } empty stored block(s) [8 bytes for CRC-32 and ISIZE, last line only]
+// The bits that follow a group's last line: the empty stored block that ends the group on a byte (BTYPE = 00 after at most seven
+// bits of padding, LEN = 0, NLEN = ~0).  bytes = whole bytes a group of `raw` symbol bits (block header .. end of block) takes.
+#define GZ_STORED_BITS 3u
+CGX_HD uint64_t gz_group_bytes(uint64_t raw_bits) { return (raw_bits + GZ_STORED_BITS + 7u) / 8u + 4u; }
+// What the host puts around a file's pieces (RFC 1952 2.3): ID1 ID2 CM FLG MTIME(4) XFL OS; and behind them an empty final block
+// (BFINAL = 1, BTYPE = 01, end of block: 03 00), CRC-32 and ISIZE of the file's text.
+#define GZ_FILE_HEADER_BYTES 10
+#define GZ_FILE_TRAILER_BYTES 10
+// One line of a group's block.  Bits: [block header, first line only] symbols [end of block, last line only] -- the caller
+// appends the stored block (gz_stored) behind a last line, where the bit position is known.
+// Returns false when the line cannot be represented (the batch is then formatted on the host).
 template <class B, bool CRC> CGX_HD bool fmt_line_gz(B &b, GzSink<B, CRC> &z, const fmt_view &F, int kind, const cgx_lexent &e, const gz_place &P) {
     bool ok = true;
-    if (P.first) { b.bits(0x8B1Fu, 16); b.bits(8u, 8); b.bits(0, 8); b.bits(0, 16); b.bits(0, 16); b.bits(0, 8); b.bits(3u, 8); }   // ID1 ID2 CM FLG MTIME XFL OS (RFC 1952 2.3)
-    b.bits(2u, 3);                                               // BFINAL = 0, BTYPE = 01 (fixed Huffman codes)
+    if (P.first) b.bits(2u, 3);                                  // BFINAL = 0, BTYPE = 01 (fixed Huffman codes)
     const bool prev = !P.first;
     if (prev && P.same_item) { z.match(P.prev_len); FMT_LIT(z, "[X] ||| "); fmt_source(z, F, kind, (uint32_t)e.id); FMT_LIT(z, " ||| "); }
     else {
@@ -400,19 +397,9 @@ template <class B, bool CRC> CGX_HD bool fmt_line_gz(B &b, GzSink<B, CRC> &z, co
     }
     z.lit();
     if (z.bad) ok = false;
-    b.bits(0, 7);                                                // end of block (symbol 256)
-    // An empty stored block (BTYPE = 00, LEN = 0, NLEN = ~0) pads to a byte boundary; the last line's closes the deflate stream
-    // (BFINAL = 1).  A line that would stay below GZ_MIN_LINE bytes (one that repeats its predecessor almost entirely) takes
-    // more of them: an open one to reach the boundary, 5-byte ones to fill, and the closing one.
-    const uint32_t trailer = P.last ? 8u : 0u, fin = P.last ? 1u : 0u;
-    if (((b.n + 3u + 7u) >> 3) + 4u + trailer >= GZ_MIN_LINE) { b.bits(fin, 3); b.align(); b.bits(0, 16); b.bits(0xFFFFu, 16); }
-    else {
-        b.bits(0, 3); b.align(); b.bits(0, 16); b.bits(0xFFFFu, 16);
-        while (b.bytes() + 5u + trailer < GZ_MIN_LINE) { b.bits(0, 8); b.bits(0, 16); b.bits(0xFFFFu, 16); }
-        b.bits(fin, 8); b.bits(0, 16); b.bits(0xFFFFu, 16);
-    }
-    if (P.last) { b.bits(0, 16); b.bits(0, 16); b.bits(0, 16); b.bits(0, 16); }   // CRC-32 and ISIZE: filled in by k_gz_trailers
-    b.finish();
+    if (P.last) b.bits(0, 7);                                    // end of block (symbol 256)
     return ok;
 }
+// behind a group's last line, in a sink that knows its bit position (align): the empty stored block
+template <class B> CGX_HD void gz_stored(B &b) { b.bits(0, GZ_STORED_BITS); b.align(); b.bits(0, 16); b.bits(0xFFFFu, 16); }
 #endif

@@ -1216,7 +1216,7 @@ static int ensure_vocab(cgx_ctx *ctx, const cgx_corpus *c) {
 #define MAX_WRITERS 64
 #define COPY_PIECE ((uint64_t)64 << 20)                   /* unique text is copied in pieces of this size, round robin over the copy streams */
 #define READERS_PER_SLOT 4                                /* reader ids of text slot s: s*4 .. s*4+2 text pieces, s*4+3 the piece lists */
-typedef struct { char *utext; uint64_t utext_cap; uint64_t *segoff, *qseg; uint32_t *seglen; uint64_t segoff_cap, seglen_cap, qseg_cap; } hostbuf;
+typedef struct { char *utext; uint64_t utext_cap; uint64_t *segoff, *qseg; uint32_t *seglen, *trl; uint64_t segoff_cap, seglen_cap, qseg_cap, trl_cap; } hostbuf;
 struct pending;
 typedef struct {
     pthread_mutex_t m; pthread_cond_t cv;
@@ -1267,8 +1267,8 @@ static void pin_to_device_node(cgx_ctx *ctx) {
 }
 typedef struct {
     cgx_ctx *ctx; int tid, rc; int32_t nq, first; const char *outdir; int32_t *next_q;
-    const char *utext; const uint64_t *qseg, *seg_off; const uint32_t *seg_len;
-    double file_ms; uint64_t calls; int gz, members; int64_t period, count;     /* gz: host zlib level for plain text; members: the text already is gzip members */
+    const char *utext; const uint64_t *qseg, *seg_off; const uint32_t *seg_len, *trl;
+    double file_ms; uint64_t calls; int gz, members; int64_t period, count;     /* gz: host zlib level for plain text; members: the text already is deflate data (CGX_TEXT_GZIP_PIECES), trl its files' CRC-32 / ISIZE */
 } devjob;
 /* optional gzip output (option "gz_level" 1..9): grammar.<q>.s.gz, the same bytes through zlib's deflate */
 static int write_one_file_gz(devjob *w, int32_t q) {
@@ -1282,21 +1282,26 @@ static int write_one_file_gz(devjob *w, int32_t q) {
     if (gzclose(f) != Z_OK) bad = 1;
     return bad ? CGX_ERR_IO : CGX_OK;
 }
-/* a gzip member that holds nothing (what gzclose writes for a file without rules): header, an empty final block, CRC-32 0, ISIZE 0 */
-static const unsigned char GZ_EMPTY_MEMBER[20] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 3, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+/* Around the pieces of a text of deflate blocks (CGX_TEXT_GZIP_PIECES): the gzip header (RFC 1952 2.3: ID1 ID2 CM FLG MTIME XFL OS), and behind them
+ * an empty final block (03 00), CRC-32 and ISIZE.  A file without rules is header + trailer: what gzclose writes for an empty file. */
+static const unsigned char GZ_FILE_HEADER[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 3};
 static int write_one_file(devjob *w, int32_t q, struct iovec *iov) {
     if (w->gz && !w->members) return write_one_file_gz(w, q);
     char fn[4096];
     snprintf(fn, sizeof fn, w->members ? "%s/grammar.%d.s.gz" : "%s/grammar.%d.s", w->outdir, w->first + q);
     const uint64_t s0 = w->qseg[q], s1 = w->qseg[q + 1];
     /* overwrite in place and cut to length: same bytes as fopen(fn,"w"), but an existing file keeps its pages */
-    int fd = open(fn, s0 == s1 ? O_WRONLY | O_CREAT | O_TRUNC : O_WRONLY | O_CREAT, 0644);
+    int fd = open(fn, s0 == s1 && !w->members ? O_WRONLY | O_CREAT | O_TRUNC : O_WRONLY | O_CREAT, 0644);
     if (fd < 0) return CGX_ERR_IO;
     int bad = 0; uint64_t pos = 0;
-    if (w->members && s0 == s1 && write(fd, GZ_EMPTY_MEMBER, sizeof GZ_EMPTY_MEMBER) != (ssize_t)sizeof GZ_EMPTY_MEMBER) bad = 1;
-    for (uint64_t s = s0; s < s1 && !bad;) {
+    unsigned char trailer[10] = {3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (w->members) { const uint32_t crc = w->trl[2 * (size_t)q], isz = w->trl[2 * (size_t)q + 1]; for (int k = 0; k < 4; k++) { trailer[2 + k] = (unsigned char)(crc >> (8 * k)); trailer[6 + k] = (unsigned char)(isz >> (8 * k)); } }
+    int head = w->members, tail = w->members;                 /* still to be written */
+    for (uint64_t s = s0; (s < s1 || head || tail) && !bad;) {
         int n = 0; uint64_t want = 0;
+        if (head) { iov[n].iov_base = (void *)GZ_FILE_HEADER; iov[n].iov_len = sizeof GZ_FILE_HEADER; want += sizeof GZ_FILE_HEADER; n++; head = 0; }
         for (; s < s1 && n < IOV_MAX; s++, n++) { iov[n].iov_base = (void *)(w->utext + w->seg_off[s]); iov[n].iov_len = w->seg_len[s]; want += w->seg_len[s]; }
+        if (tail && s == s1 && n < IOV_MAX) { iov[n].iov_base = trailer; iov[n].iov_len = sizeof trailer; want += sizeof trailer; n++; tail = 0; }
         uint64_t done = 0; int k = 0;
         while (done < want && !bad) {                       /* a short write resumes in the middle of a piece */
             ssize_t r = pwritev(fd, iov + k, n - k, (off_t)(pos + done)); w->calls++;
@@ -1307,7 +1312,7 @@ static int write_one_file(devjob *w, int32_t q, struct iovec *iov) {
         }
         pos += want;
     }
-    if (!bad && s0 != s1 && ftruncate(fd, (off_t)pos)) bad = 1;   /* an older, longer file of the same name is cut to the new length */
+    if (!bad && pos && ftruncate(fd, (off_t)pos)) bad = 1;   /* an older, longer file of the same name is cut to the new length */
     close(fd);
     return bad ? CGX_ERR_IO : CGX_OK;
 }
@@ -1341,6 +1346,10 @@ static int dev_copy_begin(pending *pw) {
         const uint64_t lo = (uint64_t)pc * COPY_PIECE, n = pw->ubytes - lo < COPY_PIECE ? pw->ubytes - lo : COPY_PIECE;
         if ((rc = cgx_text_read_begin(ctx, pw->slot, lo, n, hb->utext + lo, r0 + (int)(pc % 3))) != CGX_OK) return rc;
     }
+    if (pw->members) {                                       /* the files' CRC-32 / ISIZE travel with the piece lists (same reader: one wait covers both) */
+        if (pinned_reserve((void **)&hb->trl, &hb->trl_cap, 2 * (uint64_t)pw->nq + 2, 4)) return CGX_ERR_NOMEM;
+        if ((rc = cgx_text_trailers_begin(ctx, pw->slot, hb->trl, r0 + 3)) != CGX_OK) return rc;
+    }
     return cgx_text_segments_begin(ctx, pw->slot, hb->qseg, hb->segoff, hb->seglen, r0 + 3);
 }
 /* phase 2 (after the copies have landed and the previous batch's files are complete) */
@@ -1350,7 +1359,7 @@ static int dev_write_files(pending *pw) {
     cgx__set_host_ms(ctx, "writer_threads", nt);             /* reported beside the timings (bench.py) */
     devjob jobs[MAX_WRITERS]; pthread_t th[MAX_WRITERS]; int started[MAX_WRITERS]; int32_t next = 0; int rc = CGX_OK;
     for (int t = 0; t < nt; t++) { memset(&jobs[t], 0, sizeof jobs[t]); jobs[t].ctx = ctx; jobs[t].tid = t; jobs[t].nq = nq; jobs[t].first = pw->first; jobs[t].outdir = pw->outdir; jobs[t].next_q = &next;
-                                   jobs[t].utext = hb->utext; jobs[t].qseg = hb->qseg; jobs[t].seg_off = hb->segoff; jobs[t].seg_len = hb->seglen; jobs[t].rc = CGX_OK; jobs[t].gz = pw->gz; jobs[t].members = pw->members; jobs[t].period = pw->period; jobs[t].count = pw->count; }
+                                   jobs[t].utext = hb->utext; jobs[t].qseg = hb->qseg; jobs[t].seg_off = hb->segoff; jobs[t].seg_len = hb->seglen; jobs[t].trl = hb->trl; jobs[t].rc = CGX_OK; jobs[t].gz = pw->gz; jobs[t].members = pw->members; jobs[t].period = pw->period; jobs[t].count = pw->count; }
     started[0] = 1;
     for (int t = 1; t < nt; t++) started[t] = !pthread_create(&th[t], NULL, dev_write_worker, &jobs[t]);   /* a thread that cannot start: the others take its share */
     dev_write_worker(&jobs[0]);
@@ -1370,15 +1379,15 @@ static int dev_write_files(pending *pw) {
  * replays one recorded batch from several processes at once to measure what one host can write. */
 int cgx_assemble_files(const char *utext, const uint64_t *qseg, const uint64_t *seg_off, const uint32_t *seg_len, int32_t nq, int32_t first,
                        const char *outdir, int nthreads, double *file_ms) {
-    return cgx_assemble_files_enc(utext, qseg, seg_off, seg_len, nq, first, outdir, nthreads, file_ms, CGX_TEXT_PLAIN);
+    return cgx_assemble_files_enc(utext, qseg, seg_off, seg_len, nq, first, outdir, nthreads, file_ms, CGX_TEXT_PLAIN, NULL);
 }
 int cgx_assemble_files_enc(const char *utext, const uint64_t *qseg, const uint64_t *seg_off, const uint32_t *seg_len, int32_t nq, int32_t first,
-                           const char *outdir, int nthreads, double *file_ms, int encoding) {
-    if (!utext || !qseg || !seg_off || !seg_len || nq < 0 || !outdir || (encoding != CGX_TEXT_PLAIN && encoding != CGX_TEXT_GZIP_MEMBERS)) return CGX_ERR_ARG;
+                           const char *outdir, int nthreads, double *file_ms, int encoding, const uint32_t *trl) {
+    if (!utext || !qseg || !seg_off || !seg_len || nq < 0 || !outdir || (encoding != CGX_TEXT_PLAIN && encoding != CGX_TEXT_GZIP_PIECES) || (encoding == CGX_TEXT_GZIP_PIECES && !trl)) return CGX_ERR_ARG;
     int nt = nthreads < 1 ? 1 : nthreads > MAX_WRITERS ? MAX_WRITERS : nthreads; if (nt > nq) nt = nq > 0 ? nq : 1;
     devjob jobs[MAX_WRITERS]; pthread_t th[MAX_WRITERS]; int started[MAX_WRITERS]; int32_t next = 0; int rc = CGX_OK;
     for (int t = 0; t < nt; t++) { memset(&jobs[t], 0, sizeof jobs[t]); jobs[t].tid = t; jobs[t].nq = nq; jobs[t].first = first; jobs[t].outdir = outdir; jobs[t].next_q = &next;
-                                   jobs[t].utext = utext; jobs[t].qseg = qseg; jobs[t].seg_off = seg_off; jobs[t].seg_len = seg_len; jobs[t].rc = CGX_OK; jobs[t].members = encoding == CGX_TEXT_GZIP_MEMBERS; }
+                                   jobs[t].utext = utext; jobs[t].qseg = qseg; jobs[t].seg_off = seg_off; jobs[t].seg_len = seg_len; jobs[t].trl = trl; jobs[t].rc = CGX_OK; jobs[t].members = encoding == CGX_TEXT_GZIP_PIECES; }
     started[0] = 1;
     for (int t = 1; t < nt; t++) started[t] = !pthread_create(&th[t], NULL, dev_write_worker, &jobs[t]);
     dev_write_worker(&jobs[0]);
@@ -1444,7 +1453,7 @@ static int submit_output(cgx_ctx *ctx, batch *b, int dev, int slot, int32_t nq, 
     pw->ws = ws; pw->ctx = ctx; pw->b = b; pw->dev = dev; pw->slot = slot; pw->nq = nq; pw->first = first; pw->outdir = strdup(outdir);
     pw->hb = ws->n && ws->inflight[0]->hb == 0 ? 1 : 0;      /* the buffer set the batch still in flight does not use */
     pw->gz = b ? b->gz_level : (int)cgx__option(ctx, "gz_level"); pw->period = b ? b->write_period : cgx__option(ctx, "write_period"); pw->count = b ? b->write_count : cgx__option(ctx, "write_count");
-    pw->members = dev && cgx_text_encoding(ctx, slot) == CGX_TEXT_GZIP_MEMBERS;
+    pw->members = dev && cgx_text_encoding(ctx, slot) == CGX_TEXT_GZIP_PIECES;
     if (!pw->outdir) { free(pw); return CGX_ERR_NOMEM; }
     if (dev && (rc = dev_copy_begin(pw)) != CGX_OK) {         /* copies already enqueued target buffers that stay allocated: drain them */
         for (int r = 0; r < READERS_PER_SLOT; r++) (void)cgx_text_read_wait(ctx, slot * READERS_PER_SLOT + r);
@@ -1630,7 +1639,7 @@ void cgx__host_release(cgx_ctx *ctx) {
     wstate *ws = cgx__get_host_state(ctx);
     if (!ws) return;
     cgx__bind_thread(ctx);
-    for (int k = 0; k < 2; k++) { cgx_pinned_free(ws->hb[k].utext); cgx_pinned_free(ws->hb[k].segoff); cgx_pinned_free(ws->hb[k].seglen); cgx_pinned_free(ws->hb[k].qseg); }
+    for (int k = 0; k < 2; k++) { cgx_pinned_free(ws->hb[k].utext); cgx_pinned_free(ws->hb[k].segoff); cgx_pinned_free(ws->hb[k].seglen); cgx_pinned_free(ws->hb[k].qseg); cgx_pinned_free(ws->hb[k].trl); }
     pthread_mutex_destroy(&ws->m); pthread_cond_destroy(&ws->cv);
     free(ws); cgx__set_host_state(ctx, NULL);
 }

@@ -123,13 +123,17 @@ int cgx_format(cgx_ctx *ctx, uint64_t *total_bytes, uint64_t *total_lines, int *
  * pieces of it: piece s = bytes [seg_off[s], seg_off[s] + seg_len[s]) of the unique text; the file of query q is the concatenation of
  * pieces qseg[q] .. qseg[q+1]-1 in that order (PrintResults.c:451-570 emission order) and is qtext[q+1] - qtext[q] bytes long. */
 int cgx_text_info(cgx_ctx *ctx, int slot, uint64_t *unique_bytes, uint64_t *nseg, uint64_t *file_bytes);
-/* With option "gz_level" > 0 (and "gz_device", default 1) the slot holds the same text as GZIP MEMBERS (RFC 1952) made by the formatter itself,
- * one member per emission group, so a file is still the concatenation of its pieces: grammar.<q>.s.gz is a series of members that
- * zcat / gzread / Python's gzip read as the plain file (the reference writes one fprintf per rule, PrintResults.c:407-577).
- * Offsets, lengths and sizes above are then compressed bytes.  Returns CGX_TEXT_PLAIN or CGX_TEXT_GZIP_MEMBERS, or < 0. */
+/* With option "gz_level" > 0 (and "gz_device", default 1) the slot holds the same text as DEFLATE data made by the formatter itself (RFC 1951, fixed
+ * Huffman codes, back-references taken from the line structure): every emission group is a block that ends on a byte, so a file is still the
+ * concatenation of its pieces -- put between a gzip header (RFC 1952: 1f 8b 08 00 00 00 00 00 00 03) and the trailer 03 00 <CRC-32> <ISIZE>, whose
+ * two values come from cgx_text_trailers.  grammar.<q>.s.gz is then one gzip member that zcat / gzread / Python's gzip read as the plain file
+ * (the reference writes one fprintf per rule, PrintResults.c:407-577).  Offsets, lengths and sizes above are then compressed bytes
+ * (file sizes include the 20 bytes of header and trailer).  Returns CGX_TEXT_PLAIN or CGX_TEXT_GZIP_PIECES, or < 0. */
 #define CGX_TEXT_PLAIN 0
-#define CGX_TEXT_GZIP_MEMBERS 1
+#define CGX_TEXT_GZIP_PIECES 1
 int cgx_text_encoding(cgx_ctx *ctx, int slot);
+int cgx_text_trailers(cgx_ctx *ctx, int slot, uint32_t *trl /* 2 * nq: CRC-32 and ISIZE of every file; CGX_TEXT_GZIP_PIECES slots only */);
+int cgx_text_trailers_begin(cgx_ctx *ctx, int slot, uint32_t *trl, int reader);       /* the same copy, only enqueued on side stream `reader` */
 int cgx_text_segments(cgx_ctx *ctx, int slot, uint64_t *qseg /* nq+1 */, uint64_t *seg_off /* nseg */, uint32_t *seg_len /* nseg */);
 int cgx_text_segments_begin(cgx_ctx *ctx, int slot, uint64_t *qseg, uint64_t *seg_off, uint32_t *seg_len, int reader); /* the same copies, only enqueued on side stream `reader`; cgx_text_read_wait(reader) waits for them */
 int cgx_text_offsets(cgx_ctx *ctx, int slot, uint64_t *qtext);                       /* nq+1 cumulative file sizes: file q has qtext[q+1] - qtext[q] bytes */
@@ -141,9 +145,10 @@ int cgx_text_read_wait(cgx_ctx *ctx, int reader);                               
  * (no GPU, no context needed; what the writer of cgx_extract_grammars* runs after the DMA).  *file_ms = mean busy time per thread */
 int cgx_assemble_files(const char *utext, const uint64_t *qseg, const uint64_t *seg_off, const uint32_t *seg_len, int32_t nq, int32_t first,
                        const char *outdir, int nthreads, double *file_ms);
-/* the same with the encoding of the text (cgx_text_encoding): gzip members are written as grammar.<first+q>.s.gz, a query without rules as one empty member */
+/* the same for a text of deflate pieces (CGX_TEXT_GZIP_PIECES): grammar.<first+q>.s.gz = gzip header, the pieces, 03 00, trl[2q] (CRC-32), trl[2q+1] (ISIZE);
+ * encoding CGX_TEXT_PLAIN (trl ignored) is cgx_assemble_files */
 int cgx_assemble_files_enc(const char *utext, const uint64_t *qseg, const uint64_t *seg_off, const uint32_t *seg_len, int32_t nq, int32_t first,
-                           const char *outdir, int nthreads, double *file_ms, int encoding);
+                           const char *outdir, int nthreads, double *file_ms, int encoding, const uint32_t *trl);
 void *cgx_pinned_alloc(size_t bytes);
 void cgx_pinned_free(void *p);
 

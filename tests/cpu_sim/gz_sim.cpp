@@ -1,7 +1,8 @@
-// TEST ONLY: the formatter's gzip members (cgx_amd/csrc/cgx_fmt.h) built for the host.
-// Random lexicons over a random vocabulary are laid out group by group exactly as k_fmt_lines_gz / k_gz_trailers do it
-// (plain count -> gz count -> gz write -> CRC fold), every member is inflated by zlib and compared with the plain text
-// of its group, and the whole buffer is read back as one multi-member gzip stream.  Never calls the device ABI.
+// TEST ONLY: the formatter's DEFLATE output (cgx_amd/csrc/cgx_fmt.h) built for the host.
+// Random lexicons over a random vocabulary are laid out group by group exactly as k_fmt_lines_gz / k_gz_groups / k_gz_files do it
+// (plain count -> bit count -> scans -> bit-granular write -> CRC fold): every group's bytes, closed by an empty final block, are
+// inflated by zlib as a raw deflate stream and compared with the plain text of the group; files made of random runs of groups
+// between the gzip header and the trailer (03 00, CRC-32, ISIZE) are read back as gzip members.  Never calls the device ABI.
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -74,9 +75,9 @@ static void make_case(Case &c, uint32_t G, uint32_t D1, uint32_t D2, uint32_t ns
     F.aa = c.aa.data(); F.bb = c.bb.data(); F.fs = c.fs.data(); F.G = G; F.D1 = D1; F.D2 = D2;
 }
 
-static int inflate_member(const unsigned char *src, size_t n, std::string &out, size_t *used) {
+static int inflate_member(const unsigned char *src, size_t n, std::string &out, size_t *used, int wbits = 16 + MAX_WBITS) {
     z_stream s; memset(&s, 0, sizeof s);
-    if (inflateInit2(&s, 16 + MAX_WBITS) != Z_OK) return -1;
+    if (inflateInit2(&s, wbits) != Z_OK) return -1;
     s.next_in = (Bytef *)src; s.avail_in = (uInt)n;
     unsigned char buf[65536]; int rc;
     do { s.next_out = buf; s.avail_out = sizeof buf; rc = inflate(&s, Z_NO_FLUSH); if (rc != Z_OK && rc != Z_STREAM_END) { fprintf(stderr, "inflate: %d %s\n", rc, s.msg ? s.msg : ""); inflateEnd(&s); return -1; } out.append((char *)buf, sizeof buf - s.avail_out); } while (rc != Z_STREAM_END);
@@ -84,7 +85,12 @@ static int inflate_member(const unsigned char *src, size_t n, std::string &out, 
     return 0;
 }
 
-static uint64_t g_short_lines;
+// the writing sink of the simulation: bits OR-ed into a zeroed buffer from a bit position on (what BitWordSink does with words and lanes)
+struct BitBuf {
+    unsigned char *p; uint64_t at; uint32_t n;
+    void bits(uint32_t code, uint32_t len) { for (uint32_t i = 0; i < len; i++, at++) if ((code >> i) & 1u) p[at >> 3] |= (unsigned char)(1u << (at & 7)); n += len; }
+    void align() { while (at & 7) { at++; n++; } }
+};
 static int run_case(uint32_t G, uint32_t D1, uint32_t D2, uint32_t ns, uint32_t nt, bool utf8, uint32_t maxlines, uint64_t *nlines_out, uint64_t *plain_out, uint64_t *gz_out) {
     Case c; make_case(c, G, D1, D2, ns, nt, utf8, maxlines);
     const fmt_view &F = c.F;
@@ -114,60 +120,74 @@ static int run_case(uint32_t G, uint32_t D1, uint32_t D2, uint32_t ns, uint32_t 
         if ((uint32_t)(ms.p - buf.data()) != cs.n) { fprintf(stderr, "plain count != plain write\n"); return 1; }
         plain[l].assign(buf.data(), cs.n); U[l + 1] = U[l] + cs.n;
     }
+    auto group_of = [&](uint32_t l, uint32_t *l0, uint32_t *l1) { const uint32_t g = canon_group(line_c[l], G, D1); *l0 = cstart[canon_group_first(g, G, D1)]; *l1 = cstart[canon_group_first(g + 1, G, D1)]; return g; };
     auto place = [&](uint32_t l, gz_place &P) {
-        const uint32_t ci = line_c[l], g = canon_group(ci, G, D1), l0 = cstart[canon_group_first(g, G, D1)], l1 = cstart[canon_group_first(g + 1, G, D1)];
+        uint32_t l0, l1; group_of(l, &l0, &l1);
         memset(&P, 0, sizeof P);
-        P.first = l == l0; P.last = l + 1 == l1; P.same_item = l > cstart[ci];
+        P.first = l == l0; P.last = l + 1 == l1; P.same_item = l > cstart[line_c[l]];
         if (!P.first) { const int pk = (int)(line_ent[l - 1] >> 30); P.pe = &F.lex[pk][line_ent[l - 1] & 0x3FFFFFFFu]; P.prev_len = len_u[l - 1]; P.prev_tail = tail_u[l - 1]; }
-        return l1;
     };
-    // pass 2: compressed lengths
-    std::vector<uint32_t> len_c(NU); std::vector<uint64_t> off(NU + 1, 0);
+    // pass 2: bits per line, their running sum, bytes and byte offsets of the groups (k_gz_group_bytes)
+    std::vector<uint32_t> bits(NU); std::vector<uint64_t> P(NU + 1, 0), GO(NG + 1, 0);
     for (uint32_t l = 0; l < NU; l++) {
         const int kind = (int)(line_ent[l] >> 30); const cgx_lexent &e = F.lex[kind][line_ent[l] & 0x3FFFFFFFu];
-        gz_place P; place(l, P);
+        gz_place pl; place(l, pl);
         BitCount bc{0}; GzSink<BitCount, false> z(bc, nullptr);
-        if (!fmt_line_gz(bc, z, F, kind, e, P)) { fprintf(stderr, "gz count: line %u not representable\n", l); return 1; }
+        if (!fmt_line_gz(bc, z, F, kind, e, pl)) { fprintf(stderr, "gz count: line %u not representable\n", l); return 1; }
         if (z.pos != len_u[l]) { fprintf(stderr, "gz sink saw %u characters, the plain line has %u\n", z.pos, len_u[l]); return 1; }
-        if (bc.n & 7u) { fprintf(stderr, "line %u does not end on a byte\n", l); return 1; }
-        len_c[l] = bc.bytes(); off[l + 1] = off[l] + len_c[l];
-        if (len_c[l] == GZ_MIN_LINE || len_c[l] == GZ_MIN_LINE + 1) g_short_lines++;   // most of these took the padding blocks
-        if (len_c[l] < GZ_MIN_LINE) { fprintf(stderr, "line %u has %u bytes\n", l, len_c[l]); return 1; }
+        if (bc.n < 32u) { fprintf(stderr, "line %u has %u bits: the writing sink wants more than a word\n", l, bc.n); return 1; }
+        bits[l] = bc.n; P[l + 1] = P[l] + bc.n;
     }
-    // pass 3: write, CRC contributions
-    std::vector<unsigned char> text(off[NU] + 64, 0xAA); std::vector<uint32_t> contrib(NU);
+    for (uint32_t g = 0; g < NG; g++) { const uint32_t l0 = cstart[canon_group_first(g, G, D1)], l1 = cstart[canon_group_first(g + 1, G, D1)]; GO[g + 1] = GO[g] + (l1 > l0 ? gz_group_bytes(P[l1] - P[l0]) : 0); }
+    // pass 3: write at bit granularity, CRC contributions
+    std::vector<unsigned char> text(GO[NG] + 64, 0); std::vector<uint32_t> contrib(NU);
     for (uint32_t l = 0; l < NU; l++) {
         const int kind = (int)(line_ent[l] >> 30); const cgx_lexent &e = F.lex[kind][line_ent[l] & 0x3FFFFFFFu];
-        gz_place P; const uint32_t l1 = place(l, P);
-        MemSink ms{(char *)text.data() + off[l]}; BitOut<MemSink> bo(ms); GzSink<BitOut<MemSink>, true> z(bo, tab);
-        if (!fmt_line_gz(bo, z, F, kind, e, P)) { fprintf(stderr, "gz write: line %u not representable\n", l); return 1; }
-        if ((uint64_t)(ms.p - (char *)text.data()) != off[l + 1]) { fprintf(stderr, "gz count %u != gz write %ld at line %u\n", len_c[l], (long)(ms.p - (char *)text.data() - (long)off[l]), l); return 1; }
+        gz_place pl; place(l, pl); uint32_t l0, l1; const uint32_t g = group_of(l, &l0, &l1);
+        BitBuf bo{text.data(), 8 * GO[g] + (P[l] - P[l0]), 0}; GzSink<BitBuf, true> z(bo, tab);
+        if (!fmt_line_gz(bo, z, F, kind, e, pl)) { fprintf(stderr, "gz write: line %u not representable\n", l); return 1; }
+        if (bo.n != bits[l]) { fprintf(stderr, "gz count %u != gz write %u at line %u\n", bits[l], bo.n, l); return 1; }
+        if (pl.last) { gz_stored(bo); if (bo.at != 8 * GO[g + 1]) { fprintf(stderr, "group %u ends at bit %llu, laid out to end at %llu\n", g, (unsigned long long)bo.at, (unsigned long long)(8 * GO[g + 1])); return 1; } }
         contrib[l] = gz_multmodp(gz_x8n(tab, U[l1] - U[l + 1]), z.crc ^ 0xFFFFFFFFu);
     }
-    // trailers (k_gz_trailers) and the check: every member by itself
-    uint64_t members = 0;
+    // groups (k_gz_groups): CRC fold, and every group by itself as a raw deflate stream closed by an empty final block
+    std::vector<uint32_t> gcrc(NG, 0), glen(NG, 0), gpow(NG, 0);
+    static const unsigned char FINAL[2] = {3, 0};
     for (uint32_t g = 0; g < NG; g++) {
         const uint32_t l0 = cstart[canon_group_first(g, G, D1)], l1 = cstart[canon_group_first(g + 1, G, D1)];
-        if (l0 == l1) continue;
+        if (l0 == l1) { if (GO[g + 1] != GO[g]) return 1; continue; }
         uint32_t crc = 0; for (uint32_t l = l0; l < l1; l++) crc ^= contrib[l];
-        const uint32_t isize = (uint32_t)(U[l1] - U[l0]);
-        unsigned char *t = text.data() + off[l1] - 8;
-        for (int k = 0; k < 8; k++) if (t[k] != 0) { fprintf(stderr, "trailer bytes of group %u not zero\n", g); return 1; }
-        for (int k = 0; k < 4; k++) { t[k] = (unsigned char)(crc >> (8 * k)); t[4 + k] = (unsigned char)(isize >> (8 * k)); }
+        gcrc[g] = crc; glen[g] = (uint32_t)(U[l1] - U[l0]); gpow[g] = gz_x8n(tab, glen[g]);
         std::string want; for (uint32_t l = l0; l < l1; l++) want += plain[l];
         if ((uint32_t)crc32(0, (const Bytef *)want.data(), (uInt)want.size()) != crc) { fprintf(stderr, "CRC fold of group %u is wrong\n", g); return 1; }
+        std::vector<unsigned char> one(text.begin() + (long)GO[g], text.begin() + (long)GO[g + 1]); one.insert(one.end(), FINAL, FINAL + 2);
         std::string got; size_t used = 0;
-        if (inflate_member(text.data() + off[l0], (size_t)(off[l1] - off[l0]), got, &used)) { fprintf(stderr, "group %u does not inflate\n", g); return 1; }
-        if (used != off[l1] - off[l0]) { fprintf(stderr, "group %u: member is %zu bytes, laid out as %llu\n", g, used, (unsigned long long)(off[l1] - off[l0])); return 1; }
+        if (inflate_member(one.data(), one.size(), got, &used, -MAX_WBITS)) { fprintf(stderr, "group %u does not inflate\n", g); return 1; }
+        if (used != one.size()) { fprintf(stderr, "group %u: %zu bytes inflated, laid out as %zu\n", g, used, one.size()); return 1; }
         if (got != want) { fprintf(stderr, "group %u inflates to other text\n", g); return 1; }
-        members++;
     }
-    // the whole buffer as one series of members (what a grammar file made of several pieces is)
-    std::string all, want_all; for (uint32_t l = 0; l < NU; l++) want_all += plain[l];
-    for (size_t at = 0; at < off[NU];) { size_t used = 0; if (inflate_member(text.data() + at, (size_t)off[NU] - at, all, &used)) return 1; at += used; }
-    if (all != want_all) { fprintf(stderr, "the series of members inflates to other text\n"); return 1; }
-    *nlines_out += NU; *plain_out += U[NU]; *gz_out += off[NU];
-    (void)members;
+    // files (k_gz_files and the host writer): random runs of groups, in any order, between header and trailer
+    static const unsigned char HDR[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 3};
+    for (int f = 0; f < 12; f++) {
+        std::vector<unsigned char> file(HDR, HDR + 10); std::string want; uint32_t crc = 0, len = 0;
+        const uint32_t runs = f == 0 ? 0 : 1 + rr(6);
+        for (uint32_t r = 0; r < runs && NG; r++) {
+            const uint32_t g0 = rr(NG), g1 = g0 + 1 + rr(NG - g0 < 9 ? NG - g0 : 9);
+            file.insert(file.end(), text.begin() + (long)GO[g0], text.begin() + (long)GO[g1]);
+            for (uint32_t g = g0; g < g1; g++) {
+                if (!glen[g]) continue;
+                crc = gz_multmodp(gpow[g], crc) ^ gcrc[g]; len += glen[g];
+                for (uint32_t l = cstart[canon_group_first(g, G, D1)]; l < cstart[canon_group_first(g + 1, G, D1)]; l++) want += plain[l];
+            }
+        }
+        file.push_back(3); file.push_back(0);
+        for (int k = 0; k < 4; k++) file.push_back((unsigned char)(crc >> (8 * k)));
+        for (int k = 0; k < 4; k++) file.push_back((unsigned char)(len >> (8 * k)));
+        std::string got; size_t used = 0;
+        if (inflate_member(file.data(), file.size(), got, &used)) { fprintf(stderr, "file %d is not a gzip member (CRC / ISIZE / stream)\n", f); return 1; }
+        if (used != file.size() || got != want) { fprintf(stderr, "file %d inflates to other text\n", f); return 1; }
+    }
+    *nlines_out += NU; *plain_out += U[NU]; *gz_out += GO[NG];
     return 0;
 }
 
@@ -178,6 +198,6 @@ int main(int argc, char **argv) {
         if (run_case(40 + rr(40), 60 + rr(60), 50 + rr(50), 500, 700, (r & 1) != 0, r == 2 ? 1200 : 40, &nl, &pb, &gb)) { printf("GZ SIM FAILED in round %d\n", r); return 1; }
     }
     if (run_case(3, 0, 0, 20, 20, false, 5, &nl, &pb, &gb) || run_case(0, 2, 0, 20, 20, false, 5, &nl, &pb, &gb) || run_case(0, 0, 0, 20, 20, false, 5, &nl, &pb, &gb)) { printf("GZ SIM FAILED on a degenerate case\n"); return 1; }
-    printf("GZ SIM OK: %llu lines (%llu at the minimum length), %llu bytes of text as %llu bytes of gzip members (%.3f)\n", (unsigned long long)nl, (unsigned long long)g_short_lines, (unsigned long long)pb, (unsigned long long)gb, pb ? (double)gb / (double)pb : 0.0);
+    printf("GZ SIM OK: %llu lines, %llu bytes of text as %llu bytes of deflate blocks (%.3f)\n", (unsigned long long)nl, (unsigned long long)pb, (unsigned long long)gb, pb ? (double)gb / (double)pb : 0.0);
     return 0;
 }

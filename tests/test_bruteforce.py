@@ -28,6 +28,12 @@ def make_fixture(name, base):
     return fx
 
 
+def _canon(h):
+    """fetched hit records in the reference's order (the device keeps a list ordered by position bucket only; test_gpu_parity.canon_hits)"""
+    keys = [h[f] for f in reversed([f for f in ("position", "str_position", "length", "length2") if f in h.dtype.names])]
+    return h[np.lexsort(keys)]
+
+
 def _phits(pidx, starts, lens):
     out = {}
     pidx = np.asarray(pidx, np.int64).reshape(-1, 2)
@@ -104,7 +110,7 @@ def test_hip_path_agrees_with_the_definitions_of_the_remaining_stages(name, orac
     a, b = bf.check_query_side(c, d["qoff"][:-1], d["qtok"], ex.fetch("lm"), k["e1"], s1, p1d, _csr(ex.fetch("qo_off"), ex.fetch("qo_ids")),
                                k["e2"], s2, c2d, _csr(ex.fetch("qt_off"), ex.fetch("qt_ids")))
     assert (a, b) == (k["d1"], k["d2"])
-    hits_of = bf.hit_lists(s1, ex.fetch("hits1"), ex.fetch("pidx"), ex.fetch("phit_start"), ex.fetch("phit_len"))
+    hits_of = bf.hit_lists(s1, _canon(ex.fetch("hits1")), ex.fetch("pidx"), ex.fetch("phit_start"), ex.fetch("phit_len"))
     assert bf.check_extension_rules(c, ex.fetch("sa"), blocks, s1, hits_of, ex.fetch("r1"), k["sep1"], ex.fetch("r2"), k["sep2a"], k["sep2b"]) > 1000
     done = bf.check_maxlex_lines(c, d["tstr"], d["lexk"], d["lexv"], {0: ex.fetch("lex0"), 1: ex.fetch("lex1"), 2: ex.fetch("lex2")}, k["g"], k["d1"], k["d2"], blocks, p1d, c2d, one2)
     assert done > 1000 and k["guard_exits"] == 0
@@ -131,7 +137,7 @@ def test_hip_path_agrees_with_the_definitions(name, oracle_bin, fixtures_dir, tm
     extra = 500 if name == "toy" else 3000
     pick = None if name == "tiny" else sorted(set(range(300)) | set(int(x) for x in np.random.default_rng(11).integers(0, max(int(k["d1"]), 1), extra)))
     done = bf.check_batch(c, ex.fetch("sa"), ex.fetch("freq"), _phits(ex.fetch("pidx"), ex.fetch("phit_start"), ex.fetch("phit_len")), ex.fetch("s1"), ex.fetch("p1d"),
-                          ex.fetch("hits1"), ex.fetch("s2"), ex.fetch("c2d"), ex.fetch("hits2"), ex.fetch("blocks"), ex.fetch("r0"), ex.fetch("r1"), k["sep1"], ex.fetch("r2"), k["sep2a"], k["sep2b"], max_patterns=limit, pick=pick)
+                          _canon(ex.fetch("hits1")), ex.fetch("s2"), ex.fetch("c2d"), _canon(ex.fetch("hits2")), ex.fetch("blocks"), ex.fetch("r0"), ex.fetch("r1"), k["sep1"], ex.fetch("r2"), k["sep2a"], k["sep2b"], max_patterns=limit, pick=pick)
     assert done > 100 and k["guard_exits"] == 0
     ex.close()
 
@@ -216,6 +222,6 @@ def test_query_token_limit_against_the_definitions(limit, oracle_bin, fixtures_d
     assert (a, b) == (k["d1"], k["d2"]) and a > 100
     pick = sorted(set(range(100)) | set(int(x) for x in np.random.default_rng(12).integers(0, max(int(k["d1"]), 1), 800)))
     done = bf.check_batch(c, ex.fetch("sa"), ex.fetch("freq"), _phits(ex.fetch("pidx"), ex.fetch("phit_start"), ex.fetch("phit_len")), s1, p1d,
-                          ex.fetch("hits1"), s2, c2d, ex.fetch("hits2"), ex.fetch("blocks"), ex.fetch("r0"), ex.fetch("r1"), k["sep1"], ex.fetch("r2"), k["sep2a"], k["sep2b"], max_patterns=100, pick=pick)
+                          _canon(ex.fetch("hits1")), s2, c2d, _canon(ex.fetch("hits2")), ex.fetch("blocks"), ex.fetch("r0"), ex.fetch("r1"), k["sep1"], ex.fetch("r2"), k["sep2a"], k["sep2b"], max_patterns=100, pick=pick)
     assert done > 100 and k["guard_exits"] == 0
     ex.close()

@@ -26,6 +26,14 @@ def cgx():
     return cgx_amd
 
 
+def canon_hits(h):
+    """The hit records of cgx_fetch in the reference's order (pattern, start, length[, length2]).  By default the device keeps a
+    pattern's list ordered only by the top bits of the start position -- extraction needs order statistics, not the order
+    (cgx_search.inc, hitview) -- so a fetched list is put in order here before it is compared; option hit_order = 1 sorts on the card."""
+    keys = [h[f] for f in reversed([f for f in ("position", "str_position", "length", "length2") if f in h.dtype.names])]
+    return h[np.lexsort(keys)]
+
+
 def run_product(cgx, fx, outdir, **opts):
     files = op.fixture_args(fx)
     ex = cgx.Extractor(0)
@@ -139,31 +147,32 @@ def _gunzip_three_ways(path):
     return a
 
 
-@pytest.mark.parametrize("writer", ["gpu_members", "host_zlib_on_unique_text", "host_formatter_zlib"])
+@pytest.mark.parametrize("writer", ["gpu_deflate", "host_zlib_on_unique_text", "host_formatter_zlib"])
 @pytest.mark.parametrize("name", ["toy", "mid"])
 def test_gzip_output_holds_the_same_bytes(name, writer, cgx, fixtures_dir, tmp_path):
-    """Option gz_level / strmatchcuda --gz N: grammar.<q>.s.gz, whose content is the golden file, for the three writers: gzip
-    members emitted by the GPU formatter itself (the default with the device formatter), the host's zlib over the pieces of the
-    plain unique text (gz_device = 0), the host formatter's zlib.  Read back with Python's gzip, zcat and zlib's gzread."""
+    """Option gz_level / strmatchcuda --gz N: grammar.<q>.s.gz, whose content is the golden file, for the three writers: DEFLATE
+    blocks emitted by the GPU formatter itself (the default with the device formatter; the file is one gzip member around them), the
+    host's zlib over the pieces of the plain unique text (gz_device = 0), the host formatter's zlib.  Read back with Python's gzip,
+    zcat and zlib's gzread."""
     import hashlib
     fx = make_fixture(name, fixtures_dir); nq = META[name]["spec"][2]
-    opts = dict(gpu_members=dict(gz_level=6), host_zlib_on_unique_text=dict(gz_level=6, gz_device=0), host_formatter_zlib=dict(gz_level=6, device_format=0))[writer]
+    opts = dict(gpu_deflate=dict(gz_level=6), host_zlib_on_unique_text=dict(gz_level=6, gz_device=0), host_formatter_zlib=dict(gz_level=6, device_format=0))[writer]
     ex, corpus, n = run_product(cgx, fx, str(tmp_path / "z"), **opts)
     got = [hashlib.sha256(_gunzip_three_ways(tmp_path / "z" / ("grammar.%d.s.gz" % q))).hexdigest() for q in range(nq)]
     assert got == META[name]["grammar"] and not os.path.exists(tmp_path / "z" / "grammar.0.s")
-    if writer == "gpu_members":
-        assert ex.stage_ms("fmt_gz") == 1.0 and 0 < ex.stage_ms("fmt_unique_bytes") < 0.6 * ex.stage_ms("fmt_plain_unique_bytes")
+    if writer == "gpu_deflate":
+        assert ex.stage_ms("fmt_gz") == 1.0 and 0 < ex.stage_ms("fmt_unique_bytes") < 0.5 * ex.stage_ms("fmt_plain_unique_bytes")
     ex.close(); corpus.close()
-    if writer == "gpu_members" and name == "toy":
+    if writer == "gpu_deflate" and name == "toy":
         out = tmp_path / "cli"; out.mkdir()
         r = subprocess.run([os.path.join(ROOT, "bin", "strmatchcuda"), "--gz", "1"] + op.fixture_args(fx) + [str(out)], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr
         assert [hashlib.sha256(_gunzip_three_ways(out / ("grammar.%d.s.gz" % q))).hexdigest() for q in range(7)] == META["toy"]["grammar"]
 
 
-def test_gzip_members_edge_cases(cgx, oracle_bin, tmp_path):
-    """Queries without rules become one empty gzip member; async writer, sub-batches and the sampling options keep working
-    with members; the staged API says what a slot holds."""
+def test_gzip_pieces_edge_cases(cgx, oracle_bin, tmp_path):
+    """Queries without rules become an empty gzip member (header + trailer: 20 bytes); the async writer and sub-batches keep working
+    with deflate pieces."""
     fx = os.path.join(ROOT, "tests", "golden", "tiny"); d = tmp_path / "fx"; d.mkdir()
     for n in ("corpus.f", "corpus.e", "corpus.a", "lex.txt"):
         shutil.copy(os.path.join(fx, n), d / n)
@@ -174,7 +183,7 @@ def test_gzip_members_edge_cases(cgx, oracle_bin, tmp_path):
         ex.flush()
         for q in range(6):
             assert _gunzip_three_ways(tmp_path / ("p%d" % k) / ("grammar.%d.s.gz" % q)) == open(tmp_path / "o" / ("grammar.%d.s" % q), "rb").read()
-        assert os.path.getsize(tmp_path / ("p%d" % k) / "grammar.0.s.gz") == 20          # the empty member
+        assert os.path.getsize(tmp_path / ("p%d" % k) / "grammar.0.s.gz") == 20          # header, 03 00, CRC-32 0, ISIZE 0
         ex.close(); corpus.close()
 
 
@@ -211,19 +220,27 @@ def test_staged_text_api_reassembles_the_files(cgx, oracle_bin, fixtures_dir, tm
     assert nlines == sum(sum(1 for _ in open(tmp_path / "o" / ("grammar.%d.s" % q), "rb")) for q in range(nq))
     assert len(text) < nbytes                                            # shared lines are stored once
     assert ex.text_encoding(slot) == 0
-    # the same through the members: every piece is a series of whole gzip members
+    # the same as deflate pieces: a file = gzip header + its pieces + 03 00 + CRC-32 + ISIZE (cgx_text_trailers), and every piece
+    # by itself is a byte-aligned stretch of a deflate stream
     import gzip
+    import struct
+    import zlib
     ex.set_option("gz_level", 1)
     zbytes, zlines, zslot = ex.format()
     assert ex.text_encoding(zslot) == 1 and zlines == nlines and zbytes < nbytes // 2
     ztext, qseg, seg_off, seg_len, qtext = ex.text(zslot, nq)
+    trl = ex.text_trailers(zslot, nq)
+    hdr = bytes([0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 3])
     zgot = []
     for q in range(nq):
-        body = b"".join(ztext[int(seg_off[s]):int(seg_off[s]) + int(seg_len[s])] for s in range(int(qseg[q]), int(qseg[q + 1])))
+        pieces = [ztext[int(seg_off[s]):int(seg_off[s]) + int(seg_len[s])] for s in range(int(qseg[q]), int(qseg[q + 1]))]
+        body = hdr + b"".join(pieces) + b"\x03\x00" + struct.pack("<II", int(trl[q, 0]), int(trl[q, 1]))
         assert len(body) == int(qtext[q + 1] - qtext[q])
-        for s in range(int(qseg[q]), int(qseg[q + 1])):                  # a piece by itself is a valid file too
-            gzip.decompress(ztext[int(seg_off[s]):int(seg_off[s]) + int(seg_len[s])])
-        zgot.append(hashlib.sha256(gzip.decompress(body) if body else b"").hexdigest())
+        plain = gzip.decompress(body)                                     # checks CRC-32 and ISIZE
+        assert int(trl[q, 1]) == len(plain) & 0xFFFFFFFF and int(trl[q, 0]) == zlib.crc32(plain)
+        parts = b"".join(zlib.decompress(p + b"\x03\x00", wbits=-15) for p in pieces)    # a piece by itself: raw deflate, closed by an empty final block
+        assert parts == plain
+        zgot.append(hashlib.sha256(plain).hexdigest())
     assert zgot == META["toy"]["grammar"]
     ex.close()
 
@@ -273,12 +290,62 @@ def test_long_sentences_option(cgx, oracle_bin, fixtures_dir, tmp_path):
     ex.close(); corpus.close()
 
 
+def test_long_sentence_caches_and_id_level_corpus(cgx, oracle_bin, fixtures_dir, tmp_path):
+    """f4, the rest: (1) strmatchcuda --long-sentences --index-cache writes a corpus cache (format 4: the 16-bit target tables
+    travel with it) and an index cache, a second run reads both and writes the same files, and a run WITHOUT the switch does not
+    take the long cache for its own; (2) cgx_corpus_from_ids16 -- the id-level constructor with 16-bit positions -- gives the
+    same rules and lexicon lines as the corpus parsed from the text, stage by stage."""
+    import bruteforce as bf
+    from test_oracle import make_long_fixture, LONG_SPEC
+    exe = os.path.join(ROOT, "bin", "strmatchcuda"); lf = make_long_fixture(fixtures_dir); nq = LONG_SPEC["queries"]; files = op.fixture_args(lf)
+    want = tmp_path / "want"; want.mkdir(); dump = str(tmp_path / "d.bin")
+    subprocess.run([oracle_bin, "--long-sentences"] + files + [str(want), "--dump", dump], check=True, capture_output=True)
+    cache = str(tmp_path / "long.cache")
+    for run, note in ((1, "cache"), (2, "read from cache")):
+        got = tmp_path / ("got%d" % run); got.mkdir()
+        r = subprocess.run([exe, "--long-sentences", "--index-cache", cache] + files + [str(got)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        assert ("corpus read from cache" in r.stderr) == (run == 2) and ("index read from cache" in r.stderr) == (run == 2), r.stderr
+        assert op.sha_dir(str(got), nq) == op.sha_dir(str(want), nq)
+    assert os.path.exists(cache) and os.path.exists(cache + ".idx")
+    got = tmp_path / "got3"; got.mkdir()                                # the default mode must not adopt a cache written under the other position width
+    r = subprocess.run([exe, "--index-cache", cache] + files + [str(got)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1 and "Not possible, too long sentence" in r.stdout and "written with --long-sentences" in r.stderr
+    # (2) the same corpus at id level
+    d = op.read_dump(dump); h = d["hdr"]; n, nt = h["n"], h["nt"]
+    c = bf.Corpus.from_text(d["str"][:n], files[2], files[3])
+    s = np.asarray(d["str"][:n]); t = np.asarray(d["tstr"][:nt])
+    sentind = np.concatenate(([0], np.nonzero(s[:n - 2] == 1)[0] + 1)).astype(np.int32)
+    tsentind = np.concatenate(([0], np.nonzero(t[:nt - 2] == 1)[0] + 1)).astype(np.int32)
+    assert len(sentind) == len(tsentind) == LONG_SPEC["pairs"] + 1
+    w16 = lambda a, m: np.where(np.asarray(a[:m]) == c.NA, 0xFFFF, np.asarray(a[:m])).astype(np.uint16)
+    lt = np.full(nt, c.NA, np.int64); m = min(nt, len(c.ltar)); lt[:m] = c.ltar[:m]; rt = np.full(nt, c.NA, np.int64); rt[:m] = c.rtar[:m]
+    ids = cgx.Corpus.from_ids16(s, sentind, t, tsentind, w16(c.L, n), w16(c.R, n), w16(lt, nt), w16(rt, nt), d["lexk"], d["lexv"])
+    assert ids.flags() == 1
+    txt = cgx.Corpus.load(files[0], files[2], files[3], files[4], long_sentences=True)
+    res = []
+    for corp in (txt, ids):
+        ex = cgx.Extractor(0); ex.upload_corpus(corp)
+        ex.upload_queries(d["qoff"][:-1], d["qtok"]); ex.sa_lookup(); ex.make_blocks(); ex.gappy_search(); ex.extract(); ex.lexicon()
+        res.append({k: (canon_hits(ex.fetch(k)) if k.startswith("hits") else ex.fetch(k)).tobytes() for k in ("sa", "lm", "hits1", "hits2", "r0", "r1", "r2", "lex0", "lex1", "lex2")}); ex.close()
+    for k in res[0]:
+        assert res[0][k] == res[1][k] and len(res[0][k]) > 0, k
+    with pytest.raises(cgx.CgxError):                                     # a position beyond the mode's limits is refused, not wrapped
+        bad = w16(c.L, n).copy(); bad[3] = 5000
+        cgx.Corpus.from_ids16(s, sentind, t, tsentind, bad, w16(c.R, n), w16(lt, nt), w16(rt, nt), d["lexk"], d["lexv"])
+    txt.close(); ids.close()
+
+
+@pytest.mark.parametrize("hit_order", [0, 1])
 @pytest.mark.parametrize("name", ["tiny", "mid"])
-def test_every_stage_matches_the_oracle(name, cgx, oracle_bin, fixtures_dir, tmp_path):
+def test_every_stage_matches_the_oracle(name, hit_order, cgx, oracle_bin, fixtures_dir, tmp_path):
+    """hit_order = 1: the hit lists sorted completely on the card and compared as they come; 0 (the default): ordered by pattern and
+    position bucket only -- the same SETS per pattern, and the same rules afterwards, which come from the lists' order statistics."""
     fx = make_fixture(name, fixtures_dir); dump = str(tmp_path / "d.bin")
     op.run_oracle(oracle_bin, fx, str(tmp_path / "o"), dump)
     d = op.read_dump(dump); h = d["hdr"]; n, nt = h["n"], h["nt"]
     ex = cgx.Extractor(0)
+    ex.set_option("hit_order", hit_order)
     ex.upload_index(d["str"][:n], d["rlp"], d["tstr"][:nt], d["ltar"], d["rtar"], d["lexk"], d["lexv"])
     ex.build_sa()
     assert np.array_equal(ex.fetch("sa"), d["sa"])
@@ -312,8 +379,13 @@ def test_every_stage_matches_the_oracle(name, cgx, oracle_bin, fixtures_dir, tmp
     blocks = ex.set_blocks(d["blocks"])
     assert np.array_equal(blocks["string_start"], d["blocks"]["string_start"])
     ex.gappy_search()
-    for k in ("g1", "p1", "hits1", "g2", "hits2"):
+    for k in ("g1", "p1", "g2"):
         assert np.array_equal(ex.fetch(k), d[k]), k
+    for k in ("hits1", "hits2"):
+        got = ex.fetch(k)
+        assert np.array_equal(got if hit_order else canon_hits(got), d[k]), k
+        if not hit_order and name == "mid":
+            assert not np.array_equal(got, d[k]), k + ": the default mode is expected to leave the lists in bucket order"
     s1 = ex.fetch("s1")
     for f in ("qrystart", "a_len", "b_len", "gap", "position", "sa_start", "sa_end"):
         assert np.array_equal(s1[f], d["s1"][f].astype(s1[f].dtype)), f
@@ -497,6 +569,35 @@ def test_a_failed_stage_leaves_the_context_usable(cgx, fixtures_dir, tmp_path):
     assert op.sha_dir(str(tmp_path / "ok"), 7) == META["toy"]["grammar"]
     assert ex.stage_ms("swept_temporaries") > 0
     ex.close(); corpus.close()
+
+
+def test_optional_index_tables_may_fail_to_allocate(cgx, fixtures_dir, tmp_path):
+    """The corpus-order occurrence table (pos1) and the source-addressed target blocks (lrs) only make the lookups faster: when the
+    card has no room for one of them (injected: the n-th device allocation of the index build fails) the index loads without it,
+    says so, and the files are the golden files; a failure of a table the index needs still fails the load."""
+    fx = make_fixture("toy", fixtures_dir); files = op.fixture_args(fx)
+    corpus = cgx.Corpus.load(files[0], files[2], files[3], files[4])
+    seen = set(); failed = 0
+    for nth in range(1, 200):
+        ex = cgx.Extractor(0); ex.set_option("fault_inject", nth)
+        try:
+            ex.upload_corpus(corpus)
+        except cgx.CgxError:
+            failed += 1; ex.close(); continue
+        injected = ex.stage_ms("pos1_skipped") == 1.0 or ex.stage_ms("src_blocks_skipped") == 1.0
+        if not injected:                                                  # the counter ran past the last allocation of the build: nothing left to inject
+            ex.set_option("fault_inject", 0); ex.close(); break
+        what = "pos1" if ex.stage_ms("pos1_skipped") == 1.0 else "lrs"
+        ex.set_option("fault_inject", 0)
+        if what not in seen:
+            seen.add(what)
+            out = tmp_path / what; out.mkdir()
+            ex.extract_grammars(corpus, files[1], str(out))
+            assert op.sha_dir(str(out), 7) == META["toy"]["grammar"], what
+            assert (ex.stage_ms("src_blocks_factor") == 0) == (what == "lrs")
+        ex.close()
+    assert seen == {"pos1", "lrs"} and failed > 10, (seen, failed)
+    corpus.close()
 
 
 def test_ngram_tables_do_not_change_intervals(cgx, oracle_bin, fixtures_dir, tmp_path):

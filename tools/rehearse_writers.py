@@ -17,6 +17,10 @@ Printed per R: threads per rank, aggregate GB/s (fresh / in place), CPU-seconds 
 multiple of the one-rank figure.  One JSON line per R at the end (for profiles/).
 
     python3 tools/rehearse_writers.py --pairs 10000000 --queries 2500 --ranks 1,2,4,8
+    python3 tools/rehearse_writers.py --gz ...      the same batch as deflate pieces (grammar.<q>.s.gz, option gz_level): a third of the bytes
+
+`--chain-ms T` (the GPU chain of the recorded batch on one card, from bench.py) adds the question a scaling run asks: do R writers
+finish their batches within T, i.e. does the file phase keep up with R cards?  `keeps_up` = T / (slowest rank's in-place pass).
 """
 import argparse
 import ctypes as C
@@ -61,14 +65,20 @@ def record(args):
     os.makedirs(args.dir, exist_ok=True)
     tmp = os.path.join(args.dir, "rec_out"); os.makedirs(tmp, exist_ok=True)
     ex.set_option("write_period", 1 << 40); ex.set_option("write_count", 1)
+    if args.gz:
+        ex.set_option("gz_level", 1)
     nlines = ex.extract_grammars_ids(host, qoff, qtok, tmp, 0); ex.flush()
     slot = int(ex.stage_ms("fmt_slot"))
     text, qseg, so, sl, qtext = ex.text(slot, args.queries); nbytes = int(qtext[args.queries])
+    enc = ex.text_encoding(slot)
+    if enc:
+        np.save(os.path.join(args.dir, "trailers.npy"), ex.text_trailers(slot, args.queries))
+    plain_unique = int(max(ex.stage_ms("fmt_plain_unique_bytes"), 0))
     shutil.rmtree(tmp, ignore_errors=True)
     with open(os.path.join(args.dir, "utext.bin"), "wb") as f:
         f.write(text)
     np.save(os.path.join(args.dir, "qseg.npy"), qseg); np.save(os.path.join(args.dir, "segoff.npy"), so); np.save(os.path.join(args.dir, "seglen.npy"), sl)
-    meta = {"queries": args.queries, "pairs": args.pairs, "unique_text_bytes": len(text), "file_bytes": int(nbytes), "pieces": int(len(so)), "lines": int(nlines)}
+    meta = {"queries": args.queries, "pairs": args.pairs, "unique_text_bytes": len(text), "file_bytes": int(nbytes), "pieces": int(len(so)), "lines": int(nlines), "encoding": int(enc), "plain_unique_text_bytes": plain_unique}
     json.dump(meta, open(os.path.join(args.dir, "meta.json"), "w"))
     ex.close(); host.close()
     print("recorded: %s" % json.dumps(meta), flush=True)
@@ -77,8 +87,9 @@ def record(args):
 def writer(args):
     """CPU phase, one rank: private copy of the record, three passes of the file phase, started together with the other ranks."""
     lib = C.CDLL(os.path.join(ROOT, "cgx_amd", "libcgx_hip.so"))
-    lib.cgx_assemble_files.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_char_p, C.c_int, C.POINTER(C.c_double)]
+    lib.cgx_assemble_files_enc.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_char_p, C.c_int, C.POINTER(C.c_double), C.c_int, C.c_void_p]
     meta = json.load(open(os.path.join(args.dir, "meta.json")))
+    trl = np.load(os.path.join(args.dir, "trailers.npy")) if meta.get("encoding") else None
     text = np.fromfile(os.path.join(args.dir, "utext.bin"), dtype=np.uint8)           # private anonymous copy (a rank's page-locked buffer)
     qseg = np.load(os.path.join(args.dir, "qseg.npy")); so = np.load(os.path.join(args.dir, "segoff.npy")); sl = np.load(os.path.join(args.dir, "seglen.npy"))
     out = os.path.join(args.dir, "out_%d" % args.rank); shutil.rmtree(out, ignore_errors=True); os.makedirs(out)
@@ -89,10 +100,11 @@ def writer(args):
     res = []
     for p in range(3):
         ms = C.c_double(); r0 = resource.getrusage(resource.RUSAGE_SELF); t0 = time.perf_counter()
-        rc = lib.cgx_assemble_files(text.ctypes.data, qseg.ctypes.data, so.ctypes.data, sl.ctypes.data, meta["queries"], 0, out.encode(), args.threads, C.byref(ms))
+        rc = lib.cgx_assemble_files_enc(text.ctypes.data, qseg.ctypes.data, so.ctypes.data, sl.ctypes.data, meta["queries"], 0, out.encode(), args.threads, C.byref(ms),
+                                        int(meta.get("encoding", 0)), trl.ctypes.data if trl is not None else None)
         dt = time.perf_counter() - t0; r1 = resource.getrusage(resource.RUSAGE_SELF)
         if rc != 0:
-            raise SystemExit("cgx_assemble_files failed: %d" % rc)
+            raise SystemExit("cgx_assemble_files_enc failed: %d" % rc)
         res.append({"pass": ("fresh", "first rewrite", "rewrite")[p], "wall_s": dt, "cpu_s": (r1.ru_utime + r1.ru_stime) - (r0.ru_utime + r0.ru_stime), "t_start": t0, "t_end": t0 + dt})
     print(json.dumps({"rank": args.rank, "passes": res}), flush=True)
     shutil.rmtree(out, ignore_errors=True)
@@ -103,13 +115,15 @@ def main():
     ap.add_argument("--pairs", type=int, default=10_000_000); ap.add_argument("--vocab", type=int, default=200_000); ap.add_argument("--queries", type=int, default=2500)
     ap.add_argument("--seed", type=int, default=1234); ap.add_argument("--ranks", default="1,2,4,8")
     ap.add_argument("--dir", default="/dev/shm/cgx_rehearse"); ap.add_argument("--keep", action="store_true")
+    ap.add_argument("--gz", action="store_true", help="record the batch as deflate pieces (gz_level 1, made by the GPU formatter) and write grammar.<q>.s.gz")
+    ap.add_argument("--chain-ms", type=float, default=0.0, help="GPU chain of the recorded batch on one card: adds keeps_up = chain / slowest rank's in-place file phase")
     ap.add_argument("--phase", choices=("all", "record", "writer"), default="all"); ap.add_argument("--rank", type=int, default=0); ap.add_argument("--world", type=int, default=1); ap.add_argument("--threads", type=int, default=1)
     args = ap.parse_args()
     if args.phase == "writer":
         return writer(args)
     if args.phase in ("all", "record"):
         # the GPU phase runs in a child: this process, which starts the writers, never initialises the GPU
-        subprocess.run([sys.executable, os.path.abspath(__file__), "--phase", "record", "--pairs", str(args.pairs), "--vocab", str(args.vocab), "--queries", str(args.queries), "--seed", str(args.seed), "--dir", args.dir], check=True) if args.phase == "all" else record(args)
+        subprocess.run([sys.executable, os.path.abspath(__file__), "--phase", "record", "--pairs", str(args.pairs), "--vocab", str(args.vocab), "--queries", str(args.queries), "--seed", str(args.seed), "--dir", args.dir] + (["--gz"] if args.gz else []), check=True) if args.phase == "all" else record(args)
         if args.phase == "record":
             return
     meta = json.load(open(os.path.join(args.dir, "meta.json"))); cpus = usable_cpus(); gb = meta["file_bytes"] / 1e9
@@ -136,6 +150,10 @@ def main():
         if base is None:
             base = row
         row["aggregate_vs_one_rank"] = {k: round(row[k]["aggregate_GBps"] / base[k]["aggregate_GBps"], 2) for k in ("fresh", "rewrite")}
+        row["encoding"] = "deflate pieces (.gz)" if meta.get("encoding") else "plain"
+        if args.chain_ms > 0:                                   # R cards each finish a batch every chain_ms: do R writers on this host keep that pace?
+            row["keeps_up"] = {k: round(args.chain_ms / 1e3 / row[k]["slowest_rank_s"], 2) for k in ("fresh", "rewrite")}
+            row["ranks_served_at_full_gpu_rate"] = {k: round(R * min(1.0, row["keeps_up"][k]), 2) for k in ("fresh", "rewrite")}
         lines.append(row)
         print("R=%d  %2d threads/rank | fresh %6.1f GB/s (%.2fx one rank) | in place %6.1f GB/s (%.2fx) | CPU %.2f s per rank, %.2f GB per CPU-second in place"
               % (R, threads, row["fresh"]["aggregate_GBps"], row["aggregate_vs_one_rank"]["fresh"], row["rewrite"]["aggregate_GBps"], row["aggregate_vs_one_rank"]["rewrite"], row["rewrite"]["cpu_s_per_rank"], row["rewrite"]["GB_per_cpu_s"]), flush=True)
