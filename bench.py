@@ -371,7 +371,7 @@ def main():
     whole = all(len(q["chunks"]) == 1 for q in qsets)
     spool_bytes = [0]
 
-    stage_names = ("sa_lookup", "blocks", "gappy", "extract", "lexicon", "format", "fmt_count", "fmt_write", "look1_kernel", "look2_kernel", "select_hits", "select_long1", "select_long2", "sort_lists1", "sort_lists2")
+    stage_names = ("sa_lookup", "blocks", "gappy", "extract", "lexicon", "format", "fmt_count", "fmt_write", "look1_kernel", "look2_kernel", "select_hits", "select_long1", "select_long2", "select_huge1", "select_huge2", "sort_lists1", "sort_lists2")
     host_names = ("write", "write_wait_d2h", "write_file", "total", "t_upload_sa", "t_blocks", "t_gappy", "t_extract", "t_lexicon", "t_format", "t_flush_wait")
     def new_acc():
         return {"on": False, "kernel_ms": [], "stage": {k: 0.0 for k in stage_names}, "host": {k: 0.0 for k in host_names},
@@ -529,9 +529,10 @@ def main():
                  "format_ms_per_step": round(gacc["stage"]["format"] / gz_steps, 2), "fmt_count_ms_per_step": round(gacc["stage"]["fmt_count"] / gz_steps, 2), "fmt_write_ms_per_step": round(gacc["stage"]["fmt_write"] / gz_steps, 2),
                  "d2h_bytes_per_step": int(gacc["ubytes"] / gz_steps), "plain_unique_text_bytes_per_step": int(gacc["pbytes"] / gz_steps), "gz_file_bytes_per_step": int(gacc["fbytes"] / gz_steps),
                  "compressed_to": round(gacc["ubytes"] / max(gacc["pbytes"], 1.0), 4),
+                 "huffman_codes": "dynamic (made for each batch from a tally of its symbols)" if ex.stage_ms("fmt_gz_dynamic") == 1.0 else "fixed (RFC 1951 3.2.6)", "block_header_bits_per_group": int(max(ex.stage_ms("fmt_gz_header_bits"), 0)),
                  "stages_ms_per_step": {k: round(v / gz_steps, 2) for k, v in list(gacc["stage"].items()) + [("host_" + k, v) for k, v in gacc["host"].items()]},
                  "bound": max((("gpu_chain", gchain), ("dma", gacc["host"]["write_wait_d2h"] / 1e3), ("file_phase", gacc["host"]["write_file"] / 1e3)), key=lambda t: t[1])[0],
-                 "note": "this rank's figures; files grammar.<q>.s.gz rewritten in place in the spool directory, slots filled twice before the clock starts; one gzip member per emission group (fixed Huffman codes, back-references from the line structure), every piece of the unique text a series of whole members"}
+                 "note": "this rank's figures; files grammar.<q>.s.gz rewritten in place in the spool directory, slots filled twice before the clock starts; every emission group one DEFLATE block made by the GPU formatter (back-references from the line structure, Huffman codes made for the batch), every piece of the unique text a byte-aligned stretch of a deflate stream, every file one gzip member: header + pieces + trailer (CRC-32 / ISIZE folded on the device)"}
 
     if full_dir is not None:                                  # after every timed region: the CPUs and the memory bandwidth are free
         full_res = run_cpu_full_corpus(ex, full_dir, args)

@@ -46,7 +46,10 @@ struct cgx_ctx {
     cgx_ngslot *d_ng[4] = {nullptr, nullptr, nullptr, nullptr}; uint32_t ng_cap[4] = {0, 0, 0, 0}; unsigned ng_shift[4] = {0, 0, 0, 0};   // l-gram (l = 2..5) -> SA interval
     int gz_level = 0;                   // 1..9: grammar.<q>.s.gz instead of plain files
     bool gz_device = true;              // with gz_level and the device formatter: the formatter emits the gzip members itself (cgx_fmt.h); 0 = the host's zlib at gz_level compresses the plain text
-    uint32_t *d_gztab = nullptr;        // CRC tables of the member trailers (GZ_TAB_WORDS words)
+    uint32_t *d_gztab = nullptr;        // CRC tables of the deflate output (GZ_TAB_WORDS words)
+    struct gz_code *d_gzcode = nullptr; // the Huffman codes of the batch being formatted (cgx_fmt.h)
+    bool gz_dynamic = true;             // dynamic Huffman codes made from a tally of the batch (0: the fixed codes of RFC 1951 3.2.6)
+    uint8_t gz_lit[256] = {0};          // literal bytes a grammar line can hold (cgx_upload_vocab)
     unsigned int *d_rs_long = nullptr;  // run_sort: runs longer than the fix pass's LDS buffer met so far (slow path taken; cgx_stage_ms "run_sort_long_runs")
     bool text_gz[2] = {false, false};   // what the text slot holds: deflate pieces / plain text
     uint32_t *d_trl[2] = {nullptr, nullptr};   // deflate pieces: CRC-32 and ISIZE of every query's file (k_gz_files)
@@ -65,6 +68,7 @@ struct cgx_ctx {
     uint32_t pool_cap = 1u << 30;       // test hook: entries of the per-block append pool in use (clamped to POOL_N)
     uint32_t look_rec_cap = 65535;      // test hook: groups with more records than this read them from global memory
     bool wide_hits2 = false;            // test hook: take the path of two-gap pattern ids that do not fit beside the occurrence
+    bool tile_order = false;            // 1: the tiles of k_look1 launched in corpus-region order (cgx_search.inc k_tile_region) -- measured in round 4: 29.8 -> 29.3 ms, not worth its sort; kept as an A/B switch
     bool hit_order = false;             // 1: the hit lists are sorted completely (what cgx_fetch "hits1" / "hits2" callers may want); 0: as far as extraction needs
     int32_t freq[100] = {0};
 

@@ -500,7 +500,7 @@ extern "C" void cgx_destroy(cgx_ctx *c) {
     free_batch(c); free_index(c);
     for (int a = 0; a < 2; a++) if (c->arena[a]) { (void)hipHostFree(c->arena[a]); c->arena[a] = nullptr; }
     for (int a = 0; a < 2; a++) { dfree(c->d_text[a]); dfree(c->d_qtext[a]); dfree(c->d_seg_off[a]); dfree(c->d_seg_len[a]); dfree(c->d_qseg[a]); dfree(c->d_trl[a]); }
-    dfree(c->d_spool); dfree(c->d_soff); dfree(c->d_tpool); dfree(c->d_toff); dfree(c->d_aa); dfree(c->d_bb); dfree(c->d_fs); dfree(c->d_gztab); dfree(c->d_rs_long);
+    dfree(c->d_spool); dfree(c->d_soff); dfree(c->d_tpool); dfree(c->d_toff); dfree(c->d_aa); dfree(c->d_bb); dfree(c->d_fs); dfree(c->d_gztab); dfree(c->d_gzcode); dfree(c->d_rs_long);
     if (c->sync_ev) (void)hipEventDestroy(c->sync_ev);
     for (int r = 0; r < CGX_COPY_STREAMS; r++) if (c->copy_streams[r]) (void)hipStreamDestroy(c->copy_streams[r]);
     for (int r = 0; r < CGX_MAX_READERS; r++) if (c->copy_done[r]) (void)hipEventDestroy(c->copy_done[r]);
@@ -520,6 +520,7 @@ extern "C" int cgx_set_option(cgx_ctx *c, const char *name, int64_t value) {
     if (!strcmp(name, "ngram_tables")) { if (value < 1 || value > 5) return CGX_ERR_ARG; c->ngram_max = (int)value; return CGX_OK; }
     if (!strcmp(name, "gz_level")) { if (value < 0 || value > 9) return CGX_ERR_ARG; c->gz_level = (int)value; return CGX_OK; }
     if (!strcmp(name, "gz_device")) { c->gz_device = value != 0; return CGX_OK; }
+    if (!strcmp(name, "gz_dynamic")) { c->gz_dynamic = value != 0; return CGX_OK; }
     if (!strcmp(name, "use_layouts")) { c->use_layouts = value != 0; return CGX_OK; }
     if (!strcmp(name, "occ_order")) { c->occ_order = value != 0; return CGX_OK; }
     if (!strcmp(name, "src_blocks")) { c->src_blocks = value != 0; return CGX_OK; }
@@ -529,6 +530,7 @@ extern "C" int cgx_set_option(cgx_ctx *c, const char *name, int64_t value) {
     if (!strcmp(name, "use_lex_hash")) { c->use_lex_hash = value != 0; return CGX_OK; }
     if (!strcmp(name, "wide_hits2")) { c->wide_hits2 = value != 0; return CGX_OK; }
     if (!strcmp(name, "hit_order")) { c->hit_order = value != 0; return CGX_OK; }
+    if (!strcmp(name, "tile_order")) { c->tile_order = value != 0; return CGX_OK; }
     if (!strcmp(name, "write_period")) { if (value < 0) return CGX_ERR_ARG; c->write_period = value; return CGX_OK; }
     if (!strcmp(name, "write_count")) { if (value < 0) return CGX_ERR_ARG; c->write_count = value; return CGX_OK; }
     if (!strcmp(name, "fault_inject")) { c->fault_inject = value; return CGX_OK; }

@@ -290,37 +290,67 @@ inline void gz_make_tables(uint32_t *tab) {                      // host only
     }
 }
 
+// ---- the Huffman codes of a batch -------------------------------------------------------------------------------------
+// Every group is ONE block, and every block of a batch uses the same codes: either the fixed codes of RFC 1951 3.2.6 or -- the
+// default -- dynamic codes made for the batch from a tally of its own symbols (a sixteenth of its lines: k_fmt_lines_gz<GZ_TALLY>),
+// whose description (3.2.7) every group carries in front.  The text is digits, a few punctuation marks and the words' letters:
+// codes of 3-5 bits for the digits instead of 8, two-bit distance codes for the previous line instead of 5, at the price of a
+// header of 50-60 bytes per group.
+// Table entry: low 16 bits = the code, bit-reversed (DEFLATE packs Huffman codes from their most significant bit), bits 16.. = its
+// length (0: the symbol has no code -- a literal byte no word of the vocabulary contains; a line that needs it is not representable).
+#define GZ_NLIT 286
+#define GZ_NDIST 30
+#define GZ_NSYM (GZ_NLIT + GZ_NDIST)
+#define GZ_HDR_WORDS 48
+struct gz_code { uint32_t sym[GZ_NSYM]; uint32_t hdr_bits; uint32_t hdr[GZ_HDR_WORDS]; };   // hdr: BFINAL = 0, BTYPE and, for dynamic codes, the code lengths: the first bits of every group
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GZ_TALLY_ADD(p) atomicAdd((p), 1u)
+#else
+#define GZ_TALLY_ADD(p) ((void)(*(p))++)
+#endif
+enum { GZ_COUNT = 0, GZ_WRITE = 1, GZ_TALLY = 2 };
+
 // The deflate sink: the interface of the byte sinks above, plus match() / lit() to say what the bytes that follow are.
-template <class B, bool CRC> struct GzSink {
-    B &b; const uint32_t *tab;
+// MODE GZ_TALLY: symbols are counted in hist[GZ_NSYM] instead of being emitted.
+template <class B, bool CRC, int MODE = GZ_WRITE> struct GzSink {
+    B &b; const uint32_t *tab; const uint32_t *code; unsigned int *hist;
     uint32_t pos, mlen, mdist, crc; bool inm, bad;
-    CGX_HD GzSink(B &bits, const uint32_t *crc_table) : b(bits), tab(crc_table), pos(0), mlen(0), mdist(0), crc(0xFFFFFFFFu), inm(false), bad(false) {}
+    CGX_HD GzSink(B &bits, const uint32_t *crc_table, const uint32_t *codes, unsigned int *tally = nullptr) : b(bits), tab(crc_table), code(codes), hist(tally), pos(0), mlen(0), mdist(0), crc(0xFFFFFFFFu), inm(false), bad(false) {}
+    CGX_HD void sym(uint32_t s) {
+        if (MODE == GZ_TALLY) { GZ_TALLY_ADD(&hist[s]); return; }
+        const uint32_t e = code[s];
+        if ((e >> 16) == 0) bad = true;
+        b.bits(e & 0xFFFFu, e >> 16);
+    }
     CGX_HD void emit_match(uint32_t len, uint32_t dist) {        // 3 <= len <= 257, 1 <= dist <= 32768
-        const uint32_t l = len - 3u; uint32_t sym, eb = 0;
-        if (l < 8u) sym = 257u + l; else { eb = gz_log2(l) - 2u; sym = 261u + 4u * eb + ((l >> eb) & 3u); }
-        if (sym < 280u) b.bits(gz_brev(sym - 256u, 7), 7); else b.bits(gz_brev(0xC0u + (sym - 280u), 8), 8);
-        if (eb) b.bits(l & ((1u << eb) - 1u), eb);
+        const uint32_t l = len - 3u; uint32_t s, eb = 0;
+        if (l < 8u) s = 257u + l; else { eb = gz_log2(l) - 2u; s = 261u + 4u * eb + ((l >> eb) & 3u); }
+        sym(s);
+        if (eb && MODE != GZ_TALLY) b.bits(l & ((1u << eb) - 1u), eb);
         const uint32_t dd = dist - 1u; uint32_t dc, deb = 0;
         if (dd < 4u) dc = dd; else { const uint32_t k = gz_log2(dd); deb = k - 1u; dc = 2u * k + ((dd >> deb) & 1u); }
-        b.bits(gz_brev(dc, 5), 5);
-        if (deb) b.bits(dd & ((1u << deb) - 1u), deb);
+        sym(GZ_NLIT + dc);
+        if (deb && MODE != GZ_TALLY) b.bits(dd & ((1u << deb) - 1u), deb);
     }
     CGX_HD void flush() { if (mlen) { if (mlen < 3u) bad = true; else emit_match(mlen, mdist); mlen = 0; } }
-    // the bytes that follow stood `dist` bytes earlier in this member / are new
+    // the bytes that follow stood `dist` bytes earlier in this group / are new
     CGX_HD void match(uint32_t dist) { if (inm && dist == mdist) return; flush(); inm = dist >= 1u && dist <= 32768u; mdist = dist; }
     CGX_HD void lit() { flush(); inm = false; }
     CGX_HD void feed(uint64_t v, uint32_t n) {                   // the low n (1..8) bytes of v
         pos += n;
         if (CRC) crc = gz_crc_group(tab, crc, v, n);
         if (inm) { mlen += n; if (mlen >= 258u) { emit_match(255u, mdist); mlen -= 255u; } }      // what stays pending is again >= 3
+        else if (MODE == GZ_TALLY) { for (uint32_t i = 0; i < n; i++) GZ_TALLY_ADD(&hist[(uint32_t)(v >> (8u * i)) & 255u]); }
         else {
-            const uint64_t m = n < 8u ? v & ((1ull << (8u * n)) - 1ull) : v;
-            if ((m & 0x8080808080808080ull) == 0) {              // ASCII: eight-bit codes 0x30 + c, all bytes of the group at once
-                const uint64_t x = m + (0x3030303030303030ull & (n < 8u ? (1ull << (8u * n)) - 1ull : ~0ull));
-                b.bits(gz_brev_bytes((uint32_t)x), n < 4u ? 8u * n : 32u);
-                if (n > 4u) b.bits(gz_brev_bytes((uint32_t)(x >> 32)), 8u * (n - 4u));
+            // literals two at a time: two codes are at most 30 bits, one insertion into the bit sink instead of two
+            uint32_t i = 0;
+            for (; i + 2u <= n; i += 2u) {
+                const uint32_t e0 = code[(uint32_t)(v >> (8u * i)) & 255u], e1 = code[(uint32_t)(v >> (8u * i + 8u)) & 255u];
+                const uint32_t l0 = e0 >> 16, l1 = e1 >> 16;
+                if (l0 == 0 || l1 == 0) bad = true;
+                b.bits((e0 & 0xFFFFu) | ((e1 & 0xFFFFu) << l0), l0 + l1);
             }
-            else for (uint32_t i = 0; i < n; i++) { const uint32_t c = (uint32_t)(v >> (8u * i)) & 255u; if (c < 144u) b.bits(gz_brev(0x30u + c, 8), 8); else b.bits(gz_brev(0x100u + c, 9), 9); }
+            if (i < n) sym((uint32_t)(v >> (8u * i)) & 255u);
         }
     }
     CGX_HD void put(char c) { feed((uint64_t)(uint8_t)c, 1); }
@@ -358,9 +388,12 @@ CGX_HD uint64_t gz_group_bytes(uint64_t raw_bits) { return (raw_bits + GZ_STORED
 // One line of a group's block.  Bits: [block header, first line only] symbols [end of block, last line only] -- the caller
 // appends the stored block (gz_stored) behind a last line, where the bit position is known.
 // Returns false when the line cannot be represented (the batch is then formatted on the host).
-template <class B, bool CRC> CGX_HD bool fmt_line_gz(B &b, GzSink<B, CRC> &z, const fmt_view &F, int kind, const cgx_lexent &e, const gz_place &P) {
+template <class B, bool CRC, int MODE> CGX_HD bool fmt_line_gz(B &b, GzSink<B, CRC, MODE> &z, const fmt_view &F, const gz_code *C, int kind, const cgx_lexent &e, const gz_place &P) {
     bool ok = true;
-    if (P.first) b.bits(2u, 3);                                  // BFINAL = 0, BTYPE = 01 (fixed Huffman codes)
+    if (P.first && MODE != GZ_TALLY) {                           // the block header: BFINAL = 0, BTYPE, and the description of the batch's codes when they are dynamic
+        const uint32_t hb = C->hdr_bits;
+        for (uint32_t k = 0; 32u * k < hb; k++) b.bits(hb - 32u * k >= 32u ? C->hdr[k] : C->hdr[k] & ((1u << (hb - 32u * k)) - 1u), hb - 32u * k >= 32u ? 32u : hb - 32u * k);
+    }
     const bool prev = !P.first;
     if (prev && P.same_item) { z.match(P.prev_len); FMT_LIT(z, "[X] ||| "); fmt_source(z, F, kind, (uint32_t)e.id); FMT_LIT(z, " ||| "); }
     else {
@@ -397,9 +430,123 @@ template <class B, bool CRC> CGX_HD bool fmt_line_gz(B &b, GzSink<B, CRC> &z, co
     }
     z.lit();
     if (z.bad) ok = false;
-    if (P.last) b.bits(0, 7);                                    // end of block (symbol 256)
+    if (P.last) z.sym(256u);                                     // end of block
+    if (z.bad) ok = false;
     return ok;
 }
+// ---- host: the code tables of a batch (host functions; the device reads the finished gz_code) ----
+#include <vector>
+#include <algorithm>
+// Huffman code lengths of at most `limit` bits for the symbols with f > 0 (at least two of them): the plain construction, and
+// while it comes out too deep the frequencies are halved (floor 1), which flattens the tree.
+inline void gz_huff_lengths(const uint64_t *f, int n, int limit, uint8_t *len) {
+    std::vector<uint64_t> w(f, f + n);
+    for (;;) {
+        struct node { uint64_t w; int l, r; };
+        std::vector<node> t; std::vector<int> act;
+        for (int i = 0; i < n; i++) { len[i] = 0; if (w[i]) { t.push_back({w[i], -1 - i, 0}); act.push_back((int)t.size() - 1); } }
+        if (act.size() == 1) { len[-1 - t[act[0]].l] = 1; return; }
+        auto cmp = [&](int a, int b) { return t[a].w != t[b].w ? t[a].w > t[b].w : a > b; };   // min-heap on weight (stable on creation order)
+        std::make_heap(act.begin(), act.end(), cmp);
+        while (act.size() > 1) {
+            std::pop_heap(act.begin(), act.end(), cmp); const int a = act.back(); act.pop_back();
+            std::pop_heap(act.begin(), act.end(), cmp); const int b = act.back(); act.pop_back();
+            t.push_back({t[a].w + t[b].w, a, b}); act.push_back((int)t.size() - 1); std::push_heap(act.begin(), act.end(), cmp);
+        }
+        int deepest = 0;
+        std::vector<std::pair<int, int>> st; st.push_back({act[0], 0});
+        while (!st.empty()) {
+            const std::pair<int, int> x = st.back(); st.pop_back();
+            if (t[x.first].l < 0) { len[-1 - t[x.first].l] = (uint8_t)x.second; if (x.second > deepest) deepest = x.second; }
+            else { st.push_back({t[x.first].l, x.second + 1}); st.push_back({t[x.first].r, x.second + 1}); }
+        }
+        if (deepest <= limit) return;
+        for (int i = 0; i < n; i++) if (w[i]) w[i] = (w[i] + 1) / 2;
+    }
+}
+// Lengths for an alphabet most of whose codable symbols were NOT seen in the tally (f == 1: the floor gz_codes gives every symbol the
+// text may hold -- match lengths and distances that are possible but did not occur in the sample, letters of rare words).  Left to the
+// plain construction they end up on the two or three deepest levels in no order, and the block header, which every group carries,
+// spends three to four bits on each.  Here the seen symbols and ONE stand-in for all the others get Huffman lengths; the stand-in is
+// then replaced by a complete subtree over the others, the shorter of its two depths on the lower symbol numbers: the unseen symbols
+// have at most two lengths, in long runs, which the header's run-length code takes six at a time.
+inline void gz_huff_lengths_rare(const uint64_t *f, int n, uint8_t *len) {
+    std::vector<int> rare; std::vector<uint64_t> w(f, f + n);
+    for (int i = 0; i < n; i++) if (f[i] == 1) rare.push_back(i);
+    int seen = 0; for (int i = 0; i < n; i++) seen += f[i] > 1;
+    if (rare.size() < 4 || seen < 1) { gz_huff_lengths(f, n, 15, len); return; }
+    int k = 0; while ((1u << k) < rare.size()) k++;             // depth of the subtree: its leaves sit k - 1 and k levels below the stand-in
+    for (int limit = 15 - k; ; ) {
+        std::vector<uint64_t> g(w); for (int i : rare) g[i] = 0;
+        g[rare[0]] = rare.size();                                // the stand-in: as heavy as the symbols it stands for
+        gz_huff_lengths(g.data(), n, limit, len);
+        const int base = len[rare[0]];
+        const size_t shallow = ((size_t)1 << k) - rare.size();   // leaves at depth k - 1 (a complete tree: 2 * shallow + (m - shallow) = 2^k)
+        for (size_t j = 0; j < rare.size(); j++) len[rare[j]] = (uint8_t)(base + (j < shallow ? k - 1 : k));
+        return;
+    }
+}
+// canonical codes (RFC 1951 3.2.2) for lengths len[0..n), bit-reversed for LSB-first packing: out[i] = code | len << 16
+inline void gz_canonical(const uint8_t *len, int n, uint32_t *out) {
+    uint32_t cnt[17] = {0}, next[17] = {0};
+    for (int i = 0; i < n; i++) cnt[len[i]]++;
+    cnt[0] = 0;
+    uint32_t code = 0; for (int b = 1; b <= 16; b++) { code = (code + cnt[b - 1]) << 1; next[b] = code; }
+    for (int i = 0; i < n; i++) out[i] = len[i] ? (gz_brev(next[len[i]]++, len[i]) | ((uint32_t)len[i] << 16)) : 0u;
+}
+struct gz_bitstr { uint32_t *w; uint32_t cap, n; bool over; void put(uint32_t v, uint32_t k) { for (uint32_t i = 0; i < k; i++, n++) { if ((n >> 5) >= cap) { over = true; return; } if ((v >> i) & 1u) w[n >> 5] |= 1u << (n & 31); } } };
+// the fixed codes of RFC 1951 3.2.6
+inline void gz_build_fixed(gz_code &C) {
+    uint8_t ll[GZ_NLIT + 2], dl[GZ_NDIST];
+    for (int i = 0; i < 288; i++) ll[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8;
+    for (int i = 0; i < GZ_NDIST; i++) dl[i] = 5;
+    uint32_t tmp[288]; gz_canonical(ll, 288, tmp);
+    for (int i = 0; i < GZ_NLIT; i++) C.sym[i] = tmp[i];
+    gz_canonical(dl, GZ_NDIST, C.sym + GZ_NLIT);                  // (32 five-bit codes of which 30 are used: the canonical numbering of 30 equal lengths is 0..29 all the same)
+    for (int k = 0; k < GZ_HDR_WORDS; k++) C.hdr[k] = 0;
+    C.hdr[0] = 2u; C.hdr_bits = 3;                               // BFINAL = 0, BTYPE = 01
+}
+// Dynamic codes from symbol frequencies (every symbol the text can contain must have f > 0), and the block header that describes
+// them (RFC 1951 3.2.7).  false: the header does not fit GZ_HDR_WORDS (never with 316 symbols) -- the caller falls back to the fixed codes.
+inline bool gz_build_dynamic(const uint64_t *freq, gz_code &C) {
+    uint8_t ll[GZ_NLIT], dl[GZ_NDIST];
+    gz_huff_lengths_rare(freq, GZ_NLIT, ll); gz_huff_lengths_rare(freq + GZ_NLIT, GZ_NDIST, dl);
+    gz_canonical(ll, GZ_NLIT, C.sym); gz_canonical(dl, GZ_NDIST, C.sym + GZ_NLIT);
+    int nl = GZ_NLIT; while (nl > 257 && ll[nl - 1] == 0) nl--;
+    int nd = GZ_NDIST; while (nd > 1 && dl[nd - 1] == 0) nd--;
+    // the two length sequences as one, run-length coded with the code-length alphabet: (symbol, extra value)
+    std::vector<uint8_t> seq(ll, ll + nl); seq.insert(seq.end(), dl, dl + nd);
+    std::vector<std::pair<int, int>> rl;
+    for (size_t i = 0; i < seq.size();) {
+        size_t j = i; while (j < seq.size() && seq[j] == seq[i]) j++;
+        size_t run = j - i;
+        if (seq[i] == 0) {
+            while (run >= 11) { const size_t k = run > 138 ? 138 : run; rl.push_back({18, (int)k - 11}); run -= k; }
+            if (run >= 3) { rl.push_back({17, (int)run - 3}); run = 0; }
+            while (run--) rl.push_back({0, 0});
+        } else {
+            rl.push_back({seq[i], 0}); run--;
+            while (run >= 3) { const size_t k = run > 6 ? 6 : run; rl.push_back({16, (int)k - 3}); run -= k; }
+            while (run--) rl.push_back({seq[i], 0});
+        }
+        i = j;
+    }
+    uint64_t cf[19] = {0}; for (auto &x : rl) cf[x.first]++;
+    uint8_t cl[19]; gz_huff_lengths(cf, 19, 7, cl);
+    { int used = 0; for (int i = 0; i < 19; i++) used += cl[i] != 0; if (used < 2) { for (int i = 0; i < 19 && used < 2; i++) if (!cl[i]) { cl[i] = 1; used++; } } }   // a complete code needs two symbols
+    uint32_t cc[19]; gz_canonical(cl, 19, cc);
+    static const int order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    int nc = 19; while (nc > 4 && cl[order[nc - 1]] == 0) nc--;
+    for (int k = 0; k < GZ_HDR_WORDS; k++) C.hdr[k] = 0;
+    gz_bitstr H{C.hdr, GZ_HDR_WORDS, 0, false};
+    H.put(0, 1); H.put(2, 2);                                    // BFINAL = 0, BTYPE = 10
+    H.put((uint32_t)(nl - 257), 5); H.put((uint32_t)(nd - 1), 5); H.put((uint32_t)(nc - 4), 4);
+    for (int k = 0; k < nc; k++) H.put(cl[order[k]], 3);
+    for (auto &x : rl) { H.put(cc[x.first] & 0xFFFFu, cc[x.first] >> 16); if (x.first == 16) H.put((uint32_t)x.second, 2); else if (x.first == 17) H.put((uint32_t)x.second, 3); else if (x.first == 18) H.put((uint32_t)x.second, 7); }
+    C.hdr_bits = H.n;
+    return !H.over;
+}
+
 // behind a group's last line, in a sink that knows its bit position (align): the empty stored block
 template <class B> CGX_HD void gz_stored(B &b) { b.bits(0, GZ_STORED_BITS); b.align(); b.bits(0, 16); b.bits(0xFFFFu, 16); }
 #endif

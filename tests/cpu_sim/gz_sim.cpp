@@ -91,7 +91,7 @@ struct BitBuf {
     void bits(uint32_t code, uint32_t len) { for (uint32_t i = 0; i < len; i++, at++) if ((code >> i) & 1u) p[at >> 3] |= (unsigned char)(1u << (at & 7)); n += len; }
     void align() { while (at & 7) { at++; n++; } }
 };
-static int run_case(uint32_t G, uint32_t D1, uint32_t D2, uint32_t ns, uint32_t nt, bool utf8, uint32_t maxlines, uint64_t *nlines_out, uint64_t *plain_out, uint64_t *gz_out) {
+static int run_case(uint32_t G, uint32_t D1, uint32_t D2, uint32_t ns, uint32_t nt, bool utf8, uint32_t maxlines, bool dynamic, uint64_t *nlines_out, uint64_t *plain_out, uint64_t *gz_out, uint64_t *hdr_out) {
     Case c; make_case(c, G, D1, D2, ns, nt, utf8, maxlines);
     const fmt_view &F = c.F;
     const uint32_t NC = 4 * G + 3 * D1 + D2, NG = G + D1 + D2;
@@ -127,13 +127,34 @@ static int run_case(uint32_t G, uint32_t D1, uint32_t D2, uint32_t ns, uint32_t 
         P.first = l == l0; P.last = l + 1 == l1; P.same_item = l > cstart[line_c[l]];
         if (!P.first) { const int pk = (int)(line_ent[l - 1] >> 30); P.pe = &F.lex[pk][line_ent[l - 1] & 0x3FFFFFFFu]; P.prev_len = len_u[l - 1]; P.prev_tail = tail_u[l - 1]; }
     };
+    // the batch's Huffman codes (gz_codes in cgx_format.inc): a tally of every 16th block of 256 lines, +1 for every symbol the text may hold
+    gz_code C;
+    if (dynamic) {
+        unsigned int hist[GZ_NSYM] = {0};
+        for (uint32_t l = 0; l < NU; l++) {
+            if ((l / 256) % 16 != 0) continue;
+            const int kind = (int)(line_ent[l] >> 30); const cgx_lexent &e = F.lex[kind][line_ent[l] & 0x3FFFFFFFu];
+            gz_place pl; place(l, pl);
+            BitCount bc{0}; GzSink<BitCount, false, GZ_TALLY> z(bc, nullptr, nullptr, hist);
+            (void)fmt_line_gz(bc, z, F, &C, kind, e, pl);
+        }
+        unsigned char lit[256] = {0};
+        for (const char *p = "[X] ||| ,12=.-?\n0123456789stEgivenFCoherent SampleCountF CountEF MaxLexFgivenE MaxLexEgivenF IsSingletonF IsSingletonFE"; *p; p++) lit[(unsigned char)*p] = 1;
+        for (char ch : c.spool) lit[(unsigned char)ch] = 1;
+        for (char ch : c.tpool) lit[(unsigned char)ch] = 1;
+        uint64_t f[GZ_NSYM];
+        for (int i = 0; i < GZ_NSYM; i++) f[i] = (uint64_t)hist[i] * 16 + ((i >= 256 || lit[i]) ? 1u : 0u);
+        if (!gz_build_dynamic(f, C)) { fprintf(stderr, "the dynamic block header does not fit\n"); return 1; }
+        for (int i = 0; i < GZ_NSYM; i++) if (f[i] && (C.sym[i] >> 16) == 0) { fprintf(stderr, "symbol %d has a frequency and no code\n", i); return 1; }
+        if (C.hdr_bits > *hdr_out) *hdr_out = C.hdr_bits;
+    } else { gz_build_fixed(C); *hdr_out = C.hdr_bits; }
     // pass 2: bits per line, their running sum, bytes and byte offsets of the groups (k_gz_group_bytes)
     std::vector<uint32_t> bits(NU); std::vector<uint64_t> P(NU + 1, 0), GO(NG + 1, 0);
     for (uint32_t l = 0; l < NU; l++) {
         const int kind = (int)(line_ent[l] >> 30); const cgx_lexent &e = F.lex[kind][line_ent[l] & 0x3FFFFFFFu];
         gz_place pl; place(l, pl);
-        BitCount bc{0}; GzSink<BitCount, false> z(bc, nullptr);
-        if (!fmt_line_gz(bc, z, F, kind, e, pl)) { fprintf(stderr, "gz count: line %u not representable\n", l); return 1; }
+        BitCount bc{0}; GzSink<BitCount, false, GZ_COUNT> z(bc, nullptr, C.sym);
+        if (!fmt_line_gz(bc, z, F, &C, kind, e, pl)) { fprintf(stderr, "gz count: line %u not representable\n", l); return 1; }
         if (z.pos != len_u[l]) { fprintf(stderr, "gz sink saw %u characters, the plain line has %u\n", z.pos, len_u[l]); return 1; }
         if (bc.n < 32u) { fprintf(stderr, "line %u has %u bits: the writing sink wants more than a word\n", l, bc.n); return 1; }
         bits[l] = bc.n; P[l + 1] = P[l] + bc.n;
@@ -144,8 +165,8 @@ static int run_case(uint32_t G, uint32_t D1, uint32_t D2, uint32_t ns, uint32_t 
     for (uint32_t l = 0; l < NU; l++) {
         const int kind = (int)(line_ent[l] >> 30); const cgx_lexent &e = F.lex[kind][line_ent[l] & 0x3FFFFFFFu];
         gz_place pl; place(l, pl); uint32_t l0, l1; const uint32_t g = group_of(l, &l0, &l1);
-        BitBuf bo{text.data(), 8 * GO[g] + (P[l] - P[l0]), 0}; GzSink<BitBuf, true> z(bo, tab);
-        if (!fmt_line_gz(bo, z, F, kind, e, pl)) { fprintf(stderr, "gz write: line %u not representable\n", l); return 1; }
+        BitBuf bo{text.data(), 8 * GO[g] + (P[l] - P[l0]), 0}; GzSink<BitBuf, true, GZ_WRITE> z(bo, tab, C.sym);
+        if (!fmt_line_gz(bo, z, F, &C, kind, e, pl)) { fprintf(stderr, "gz write: line %u not representable\n", l); return 1; }
         if (bo.n != bits[l]) { fprintf(stderr, "gz count %u != gz write %u at line %u\n", bits[l], bo.n, l); return 1; }
         if (pl.last) { gz_stored(bo); if (bo.at != 8 * GO[g + 1]) { fprintf(stderr, "group %u ends at bit %llu, laid out to end at %llu\n", g, (unsigned long long)bo.at, (unsigned long long)(8 * GO[g + 1])); return 1; } }
         contrib[l] = gz_multmodp(gz_x8n(tab, U[l1] - U[l + 1]), z.crc ^ 0xFFFFFFFFu);
@@ -193,11 +214,13 @@ static int run_case(uint32_t G, uint32_t D1, uint32_t D2, uint32_t ns, uint32_t 
 
 int main(int argc, char **argv) {
     const int rounds = argc > 1 ? atoi(argv[1]) : 6;
-    uint64_t nl = 0, pb = 0, gb = 0;
-    for (int r = 0; r < rounds; r++) {
-        if (run_case(40 + rr(40), 60 + rr(60), 50 + rr(50), 500, 700, (r & 1) != 0, r == 2 ? 1200 : 40, &nl, &pb, &gb)) { printf("GZ SIM FAILED in round %d\n", r); return 1; }
+    for (int dyn = 0; dyn < 2; dyn++) {
+        uint64_t nl = 0, pb = 0, gb = 0, hb = 0;
+        for (int r = 0; r < rounds; r++) {
+            if (run_case(40 + rr(40), 60 + rr(60), 50 + rr(50), 500, 700, (r & 1) != 0, r == 2 ? 1200 : 40, dyn != 0, &nl, &pb, &gb, &hb)) { printf("GZ SIM FAILED in round %d (%s codes)\n", r, dyn ? "dynamic" : "fixed"); return 1; }
+        }
+        if (run_case(3, 0, 0, 20, 20, false, 5, dyn != 0, &nl, &pb, &gb, &hb) || run_case(0, 2, 0, 20, 20, false, 5, dyn != 0, &nl, &pb, &gb, &hb) || run_case(0, 0, 0, 20, 20, false, 5, dyn != 0, &nl, &pb, &gb, &hb)) { printf("GZ SIM FAILED on a degenerate case (%s codes)\n", dyn ? "dynamic" : "fixed"); return 1; }
+        printf("GZ SIM OK (%s codes, block header up to %llu bits): %llu lines, %llu bytes of text as %llu bytes of deflate blocks (%.3f)\n", dyn ? "dynamic" : "fixed", (unsigned long long)hb, (unsigned long long)nl, (unsigned long long)pb, (unsigned long long)gb, pb ? (double)gb / (double)pb : 0.0);
     }
-    if (run_case(3, 0, 0, 20, 20, false, 5, &nl, &pb, &gb) || run_case(0, 2, 0, 20, 20, false, 5, &nl, &pb, &gb) || run_case(0, 0, 0, 20, 20, false, 5, &nl, &pb, &gb)) { printf("GZ SIM FAILED on a degenerate case\n"); return 1; }
-    printf("GZ SIM OK: %llu lines, %llu bytes of text as %llu bytes of deflate blocks (%.3f)\n", (unsigned long long)nl, (unsigned long long)pb, (unsigned long long)gb, pb ? (double)gb / (double)pb : 0.0);
     return 0;
 }

@@ -147,21 +147,22 @@ def _gunzip_three_ways(path):
     return a
 
 
-@pytest.mark.parametrize("writer", ["gpu_deflate", "host_zlib_on_unique_text", "host_formatter_zlib"])
+@pytest.mark.parametrize("writer", ["gpu_deflate", "gpu_deflate_fixed_codes", "host_zlib_on_unique_text", "host_formatter_zlib"])
 @pytest.mark.parametrize("name", ["toy", "mid"])
 def test_gzip_output_holds_the_same_bytes(name, writer, cgx, fixtures_dir, tmp_path):
-    """Option gz_level / strmatchcuda --gz N: grammar.<q>.s.gz, whose content is the golden file, for the three writers: DEFLATE
-    blocks emitted by the GPU formatter itself (the default with the device formatter; the file is one gzip member around them), the
-    host's zlib over the pieces of the plain unique text (gz_device = 0), the host formatter's zlib.  Read back with Python's gzip,
-    zcat and zlib's gzread."""
+    """Option gz_level / strmatchcuda --gz N: grammar.<q>.s.gz, whose content is the golden file, for the writers: DEFLATE blocks
+    emitted by the GPU formatter itself (the default with the device formatter; the file is one gzip member around them) with the
+    batch's own Huffman codes or (gz_dynamic = 0) the fixed ones, the host's zlib over the pieces of the plain unique text
+    (gz_device = 0), the host formatter's zlib.  Read back with Python's gzip, zcat and zlib's gzread."""
     import hashlib
     fx = make_fixture(name, fixtures_dir); nq = META[name]["spec"][2]
-    opts = dict(gpu_deflate=dict(gz_level=6), host_zlib_on_unique_text=dict(gz_level=6, gz_device=0), host_formatter_zlib=dict(gz_level=6, device_format=0))[writer]
+    opts = dict(gpu_deflate=dict(gz_level=6), gpu_deflate_fixed_codes=dict(gz_level=6, gz_dynamic=0), host_zlib_on_unique_text=dict(gz_level=6, gz_device=0), host_formatter_zlib=dict(gz_level=6, device_format=0))[writer]
     ex, corpus, n = run_product(cgx, fx, str(tmp_path / "z"), **opts)
     got = [hashlib.sha256(_gunzip_three_ways(tmp_path / "z" / ("grammar.%d.s.gz" % q))).hexdigest() for q in range(nq)]
     assert got == META[name]["grammar"] and not os.path.exists(tmp_path / "z" / "grammar.0.s")
-    if writer == "gpu_deflate":
-        assert ex.stage_ms("fmt_gz") == 1.0 and 0 < ex.stage_ms("fmt_unique_bytes") < 0.5 * ex.stage_ms("fmt_plain_unique_bytes")
+    if writer.startswith("gpu_deflate"):
+        assert ex.stage_ms("fmt_gz") == 1.0 and 0 < ex.stage_ms("fmt_unique_bytes") < (0.4 if writer == "gpu_deflate" else 0.5) * ex.stage_ms("fmt_plain_unique_bytes")
+        assert ex.stage_ms("fmt_gz_dynamic") == (1.0 if writer == "gpu_deflate" else 0.0)
     ex.close(); corpus.close()
     if writer == "gpu_deflate" and name == "toy":
         out = tmp_path / "cli"; out.mkdir()
