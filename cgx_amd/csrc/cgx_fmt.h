@@ -385,15 +385,17 @@ CGX_HD uint64_t gz_group_bytes(uint64_t raw_bits) { return (raw_bits + GZ_STORED
 // (BFINAL = 1, BTYPE = 01, end of block: 03 00), CRC-32 and ISIZE of the file's text.
 #define GZ_FILE_HEADER_BYTES 10
 #define GZ_FILE_TRAILER_BYTES 10
+// the block header: BFINAL = 0, BTYPE, and the description of the batch's codes when they are dynamic
+template <class B> CGX_HD void gz_block_header(B &b, const gz_code *C) {
+    const uint32_t hb = C->hdr_bits;
+    for (uint32_t k = 0; 32u * k < hb; k++) b.bits(hb - 32u * k >= 32u ? C->hdr[k] : C->hdr[k] & ((1u << (hb - 32u * k)) - 1u), hb - 32u * k >= 32u ? 32u : hb - 32u * k);
+}
 // One line of a group's block.  Bits: [block header, first line only] symbols [end of block, last line only] -- the caller
 // appends the stored block (gz_stored) behind a last line, where the bit position is known.
 // Returns false when the line cannot be represented (the batch is then formatted on the host).
 template <class B, bool CRC, int MODE> CGX_HD bool fmt_line_gz(B &b, GzSink<B, CRC, MODE> &z, const fmt_view &F, const gz_code *C, int kind, const cgx_lexent &e, const gz_place &P) {
     bool ok = true;
-    if (P.first && MODE != GZ_TALLY) {                           // the block header: BFINAL = 0, BTYPE, and the description of the batch's codes when they are dynamic
-        const uint32_t hb = C->hdr_bits;
-        for (uint32_t k = 0; 32u * k < hb; k++) b.bits(hb - 32u * k >= 32u ? C->hdr[k] : C->hdr[k] & ((1u << (hb - 32u * k)) - 1u), hb - 32u * k >= 32u ? 32u : hb - 32u * k);
-    }
+    if (P.first && MODE != GZ_TALLY) gz_block_header(b, C);
     const bool prev = !P.first;
     if (prev && P.same_item) { z.match(P.prev_len); FMT_LIT(z, "[X] ||| "); fmt_source(z, F, kind, (uint32_t)e.id); FMT_LIT(z, " ||| "); }
     else {

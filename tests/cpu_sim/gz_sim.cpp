@@ -212,7 +212,40 @@ static int run_case(uint32_t G, uint32_t D1, uint32_t D2, uint32_t ns, uint32_t 
     return 0;
 }
 
+// gz_build_dynamic on its own: random frequency tables -- a handful of symbols, hundreds, weights from 1 to 10^9 side by side (the length
+// limit of 15 bits then bites) -- must give complete codes of at most 15 bits whose block header zlib accepts: the header, every coded
+// literal once, the end-of-block code and an empty final block inflate to exactly those literals.
+static int fuzz_codes(int rounds) {
+    for (int r = 0; r < rounds; r++) {
+        uint64_t f[GZ_NSYM] = {0};
+        const int style = (int)rr(4);
+        for (int i = 0; i < GZ_NSYM; i++) {
+            const bool must = i >= 256;                          // end of block, lengths, distances: always codable (gz_codes)
+            const bool used = must || rr(style == 0 ? 40 : style == 1 ? 2 : 5) == 0;
+            if (!used) continue;
+            f[i] = style == 3 ? 1 + (uint64_t)rr(3) * rr(1000000) * (uint64_t)rr(1000) : 1 + (rr(3) ? 0 : (uint64_t)rr(100000));
+        }
+        f[(int)rr(256)] += 5; f[256] += 1;
+        gz_code C;
+        if (!gz_build_dynamic(f, C)) { fprintf(stderr, "fuzz %d: header does not fit (%u bits)\n", r, C.hdr_bits); return 1; }
+        for (int part = 0; part < 2; part++) {                   // Kraft sum = 1, lengths <= 15
+            uint64_t kraft = 0; const int a = part ? GZ_NLIT : 0, b = part ? GZ_NSYM : GZ_NLIT;
+            for (int i = a; i < b; i++) { const uint32_t L = C.sym[i] >> 16; if ((f[i] != 0) != (L != 0) || L > 15) { fprintf(stderr, "fuzz %d: symbol %d has frequency %llu and length %u\n", r, i, (unsigned long long)f[i], L); return 1; } if (L) kraft += 1ull << (15 - L); }
+            if (kraft != (1ull << 15)) { fprintf(stderr, "fuzz %d: %s code is not complete\n", r, part ? "distance" : "literal/length"); return 1; }
+        }
+        std::vector<unsigned char> buf(4096, 0); BitBuf bo{buf.data(), 0, 0}; std::string want;
+        gz_block_header(bo, &C);
+        for (int i = 0; i < 256; i++) if (f[i]) { bo.bits(C.sym[i] & 0xFFFFu, C.sym[i] >> 16); want.push_back((char)i); }
+        bo.bits(C.sym[256] & 0xFFFFu, C.sym[256] >> 16);
+        bo.bits(3u, 10);                                          // an empty final block with the fixed codes: BFINAL = 1, BTYPE = 01, end of block
+        std::string got; size_t used = 0;
+        if (inflate_member(buf.data(), (size_t)((bo.at + 7) / 8), got, &used, -MAX_WBITS) || got != want) { fprintf(stderr, "fuzz %d: zlib does not accept the block header (%u bits)\n", r, C.hdr_bits); return 1; }
+    }
+    return 0;
+}
+
 int main(int argc, char **argv) {
+    if (fuzz_codes(3000)) { printf("GZ SIM FAILED: code construction\n"); return 1; }
     const int rounds = argc > 1 ? atoi(argv[1]) : 6;
     for (int dyn = 0; dyn < 2; dyn++) {
         uint64_t nl = 0, pb = 0, gb = 0, hb = 0;

@@ -16,7 +16,11 @@ import gen_fixture
 # two more shapes for the definition checks, generated here from their seeds (no golden files: the checks compare against the
 # definitions, not against stored output): a tiny vocabulary with long sentences (dense matches, long occurrence lists, many
 # rules per phrase) and short sentences over a large vocabulary (few matches, many sentence boundaries inside the windows)
-EXTRA = {"dense": dict(pairs=260, vocab=104, queries=5, seed=77, lo=6, hi=30), "sparse": dict(pairs=4000, vocab=500, queries=60, seed=78, lo=1, hi=6)}
+EXTRA = {"dense": dict(pairs=260, vocab=104, queries=5, seed=77, lo=6, hi=30), "sparse": dict(pairs=4000, vocab=500, queries=60, seed=78, lo=1, hi=6),
+         # "thin": the dense shape with 45 % of its alignment links dropped -- phrase edges without a link, gaps none of whose tokens is aligned,
+         # target words nobody points at: the cases the reference handles with its unsigned-char "no position" marks (255)
+         "thin": dict(pairs=260, vocab=104, queries=5, seed=79, lo=6, hi=30)}
+THIN = {"thin": 0.45}
 
 
 def make_fixture(name, base):
@@ -25,6 +29,12 @@ def make_fixture(name, base):
     fx = os.path.join(base, "bf_%s_%d_%d_%d_%d" % (name, EXTRA[name]["pairs"], EXTRA[name]["vocab"], EXTRA[name]["queries"], EXTRA[name]["seed"]))
     if not os.path.exists(os.path.join(fx, "lex.txt")):
         gen_fixture.write_fixture(fx, **EXTRA[name])
+        if name in THIN:                                        # the same corpus with fewer links (every line keeps one)
+            rng = np.random.default_rng(EXTRA[name]["seed"]); out = []
+            for line in open(os.path.join(fx, "corpus.a")):
+                links = line.split(); keep = [w for w in links if rng.random() >= THIN[name]]
+                out.append(" ".join(keep if keep else links[:1]) + "\n")
+            open(os.path.join(fx, "corpus.a"), "w").write("".join(out))
     return fx
 
 
@@ -70,7 +80,7 @@ def _csr(off, ids):
     return [[int(x) for x in ids[int(off[q]):int(off[q + 1])]] for q in range(len(off) - 1)]
 
 
-@pytest.mark.parametrize("name", ["tiny", "toy", "mid", "dense", "sparse"])
+@pytest.mark.parametrize("name", ["tiny", "toy", "mid", "dense", "sparse", "thin"])
 def test_oracle_agrees_with_the_definitions_of_the_remaining_stages(name, oracle_bin, fixtures_dir, tmp_path):
     """Query-side enumeration + ids + per-query lists, the extension rules (Xab, abX, XabX, XaXb, aXbX) and MaxLex: every
     block, every pattern, every lexical task of the fixture."""
@@ -91,7 +101,7 @@ def test_oracle_agrees_with_the_definitions_of_the_remaining_stages(name, oracle
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["tiny", "toy", "mid", "dense", "sparse"])
+@pytest.mark.parametrize("name", ["tiny", "toy", "mid", "dense", "sparse", "thin"])
 def test_hip_path_agrees_with_the_definitions_of_the_remaining_stages(name, oracle_bin, fixtures_dir, tmp_path):
     """The HIP path's r1 / r2 ids b, G+b (Xab, abX), b (XabX), oneId, D1+oneId (XaXb, aXbX), its pattern ids and per-query
     lists, and lex*.fe / lex*.ef, all against tests/bruteforce.py -- no oracle result is compared here."""
@@ -118,7 +128,7 @@ def test_hip_path_agrees_with_the_definitions_of_the_remaining_stages(name, orac
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["tiny", "toy", "mid", "dense", "sparse"])
+@pytest.mark.parametrize("name", ["tiny", "toy", "mid", "dense", "sparse", "thin"])
 def test_hip_path_agrees_with_the_definitions(name, oracle_bin, fixtures_dir, tmp_path):
     import torch
     torch.zeros(1, device="cuda:0")

@@ -188,6 +188,29 @@ def test_gzip_pieces_edge_cases(cgx, oracle_bin, tmp_path):
         ex.close(); corpus.close()
 
 
+def test_gzip_very_long_lines(cgx, oracle_bin, tmp_path):
+    """A vocabulary of 75-byte words: lines of a kilobyte and more, back-references longer than one DEFLATE match (258 bytes: split), distances
+    in the thousands.  The .gz files must inflate to the oracle's, and the plain files equal them too."""
+    fx = os.path.join(ROOT, "tests", "golden", "tiny"); d = tmp_path / "fx"; d.mkdir()
+    long_word = lambda w: w + "_" + "z" * 70
+    for n in ("corpus.f", "corpus.e", "query.f"):
+        (d / n).write_text("".join(" ".join(long_word(w) for w in line.split()) + "\n" for line in open(os.path.join(fx, n))))
+    shutil.copy(os.path.join(fx, "corpus.a"), d / "corpus.a")
+    (d / "lex.txt").write_text("".join(" ".join([w if w == "NULL" else long_word(w) for w in line.split()[:2]] + line.split()[2:]) + "\n" for line in open(os.path.join(fx, "lex.txt"))))
+    op.run_oracle(oracle_bin, str(d), str(tmp_path / "o"))
+    ex, corpus, n = run_product(cgx, str(d), str(tmp_path / "z"), gz_level=1)
+    sizes = []
+    for q in range(7):
+        want = open(tmp_path / "o" / ("grammar.%d.s" % q), "rb").read()
+        assert _gunzip_three_ways(tmp_path / "z" / ("grammar.%d.s.gz" % q)) == want
+        sizes.append(len(want))
+    assert max(sizes) > 100000 and ex.stage_ms("fmt_gz") == 1.0
+    ex.close(); corpus.close()
+    ex, corpus, n = run_product(cgx, str(d), str(tmp_path / "p"))
+    assert all(open(tmp_path / "p" / ("grammar.%d.s" % q), "rb").read() == open(tmp_path / "o" / ("grammar.%d.s" % q), "rb").read() for q in range(7))
+    ex.close(); corpus.close()
+
+
 def test_staged_text_api_reassembles_the_files(cgx, oracle_bin, fixtures_dir, tmp_path):
     """The writer's public interface, used the way INTEGRATION.md tells a binder to: stage calls up to cgx_lexicon, then
     cgx_upload_vocab / cgx_upload_score_tables / cgx_format, the unique text and the piece lists (cgx_text_info,

@@ -61,6 +61,26 @@ def test_oracle_host_stages_match_reference_objects(name, oracle_bin, fixtures_d
     assert op.sha_dir(str(out), nq) == op.sha_dir(str(rout), nq)
 
 
+@pytest.mark.skipif(not os.path.exists("/root/reference/ExtractPair.c"), reason="reference checkout not present on this machine")
+def test_reference_objects_on_a_thinly_aligned_corpus(oracle_bin, fixtures_dir, tmp_path):
+    """The reference's own createLexicon*Fast / print_query_GPU_Gappy (oracle/_ref) fed with the oracle's intermediates of a corpus that has
+    lost 45 % of its alignment links -- phrase edges without a link, gaps without an aligned token, the reference's unsigned-char
+    "no position" marks (255) everywhere: the files must be the oracle's, byte for byte (short-sentence mode, the reference's format)."""
+    import test_bruteforce as tb
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "_ref/ref_harness"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    ref = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+    fx = tb.make_fixture("thin", fixtures_dir)
+    out = tmp_path / "o"; rout = tmp_path / "r"; rout.mkdir(); dump = str(tmp_path / "dump.bin")
+    op.run_oracle(oracle_bin, fx, str(out), dump)
+    r = subprocess.run([ref, "sa", dump], capture_output=True, text=True)
+    assert r.returncode == 0 and "SA OK" in r.stdout
+    r = subprocess.run([ref, "grammar", dump, str(rout)], capture_output=True, text=True)
+    assert r.returncode == 0 and "GRAMMAR OK" in r.stdout, r.stdout
+    nq = tb.EXTRA["thin"]["queries"]
+    assert op.sha_dir(str(out), nq) == op.sha_dir(str(rout), nq)
+    assert sum(os.path.getsize(out / ("grammar.%d.s" % q)) for q in range(nq)) > 10000
+
+
 def test_query_sharding_is_output_invariant(oracle_bin, tmp_path):
     """Per-query files depend only on the index and that query: split 7 queries 4+3."""
     fx = os.path.join(GOLD, "tiny")
