@@ -301,7 +301,7 @@ inline void gz_make_tables(uint32_t *tab) {                      // host only
 #define GZ_NLIT 286
 #define GZ_NDIST 30
 #define GZ_NSYM (GZ_NLIT + GZ_NDIST)
-#define GZ_HDR_WORDS 48
+#define GZ_HDR_WORDS 64
 struct gz_code { uint32_t sym[GZ_NSYM]; uint32_t hdr_bits; uint32_t hdr[GZ_HDR_WORDS]; };   // hdr: BFINAL = 0, BTYPE and, for dynamic codes, the code lengths: the first bits of every group
 #if defined(__HIP_DEVICE_COMPILE__)
 #define GZ_TALLY_ADD(p) atomicAdd((p), 1u)
