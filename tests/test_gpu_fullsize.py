@@ -145,6 +145,30 @@ def test_grammar_files_do_not_depend_on_batching(world):
         n4 = ex.extract_grammars_ids(host, qoff, qtok, dirs[2], 0)
         ex.set_option("src_blocks", 1); ex.set_option("occ_order", 1)
         assert n4 == n_all and _sha_dir(dirs[2], nq) == ref
+        # the hit lists sorted completely on the card instead of by pattern and position bucket with the order statistics selected
+        # (lists of hundreds of thousands of occurrences here: every path of k_sort_lists / k_select_hits / k_select_rank against the full sort)
+        shutil.rmtree(dirs[2]); os.mkdir(dirs[2])
+        ex.set_option("hit_order", 1)
+        n5 = ex.extract_grammars_ids(host, qoff, qtok, dirs[2], 0)
+        ex.set_option("hit_order", 0)
+        assert n5 == n_all and _sha_dir(dirs[2], nq) == ref
+        # the same files as DEFLATE data made by the formatter (text offsets of gigabytes, groups of thousands of lines, back-references of
+        # kilobytes): every grammar.<q>.s.gz is ONE gzip member whose CRC-32 and ISIZE hold (gzip checks both) and whose content is the plain file
+        import gzip
+        for dyn in (1, 0):
+            shutil.rmtree(dirs[2]); os.mkdir(dirs[2])
+            ex.set_option("gz_level", 1); ex.set_option("gz_dynamic", dyn)
+            n6 = ex.extract_grammars_ids(host, qoff, qtok, dirs[2], 0)
+            ex.set_option("gz_level", 0); ex.set_option("gz_dynamic", 1)
+            assert n6 == n_all and ex.stage_ms("fmt_gz") == 1.0 and ex.stage_ms("fmt_gz_dynamic") == float(dyn)
+            h = hashlib.sha256()                                  # as _sha_dir: one digest over the files' contents in order
+            for q in range(nq):
+                with gzip.open(os.path.join(dirs[2], "grammar.%d.s.gz" % q), "rb") as f:
+                    for b in iter(lambda: f.read(1 << 24), b""):
+                        h.update(b)
+                h.update(b"\0")
+            assert h.hexdigest() == ref, "gz_dynamic=%d" % dyn
+            assert ex.stage_ms("fmt_unique_bytes") < (0.30 if dyn else 0.40) * ex.stage_ms("fmt_plain_unique_bytes")
     finally:
         shutil.rmtree(out, ignore_errors=True)
 
