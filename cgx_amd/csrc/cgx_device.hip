@@ -531,6 +531,7 @@ extern "C" int cgx_set_option(cgx_ctx *c, const char *name, int64_t value) {
     if (!strcmp(name, "wide_hits2")) { c->wide_hits2 = value != 0; return CGX_OK; }
     if (!strcmp(name, "hit_order")) { c->hit_order = value != 0; return CGX_OK; }
     if (!strcmp(name, "tile_order")) { c->tile_order = value != 0; return CGX_OK; }
+    if (!strcmp(name, "lex_flat")) { c->lex_flat = value != 0; return CGX_OK; }
     if (!strcmp(name, "write_period")) { if (value < 0) return CGX_ERR_ARG; c->write_period = value; return CGX_OK; }
     if (!strcmp(name, "write_count")) { if (value < 0) return CGX_ERR_ARG; c->write_count = value; return CGX_OK; }
     if (!strcmp(name, "fault_inject")) { c->fault_inject = value; return CGX_OK; }

@@ -146,11 +146,12 @@ def test_grammar_files_do_not_depend_on_batching(world):
         ex.set_option("src_blocks", 1); ex.set_option("occ_order", 1)
         assert n4 == n_all and _sha_dir(dirs[2], nq) == ref
         # the hit lists sorted completely on the card instead of by pattern and position bucket with the order statistics selected
-        # (lists of hundreds of thousands of occurrences here: every path of k_sort_lists / k_select_hits / k_select_rank against the full sort)
+        # (lists of hundreds of thousands of occurrences here: every path of k_sort_lists / k_select_hits / k_select_rank against the full sort);
+        # and MaxLex by the one-lane-per-line kernel instead of the wave-wide task list (same floats, bit for bit)
         shutil.rmtree(dirs[2]); os.mkdir(dirs[2])
-        ex.set_option("hit_order", 1)
+        ex.set_option("hit_order", 1); ex.set_option("lex_flat", 0)
         n5 = ex.extract_grammars_ids(host, qoff, qtok, dirs[2], 0)
-        ex.set_option("hit_order", 0)
+        ex.set_option("hit_order", 0); ex.set_option("lex_flat", 1)
         assert n5 == n_all and _sha_dir(dirs[2], nq) == ref
         # the same files as DEFLATE data made by the formatter (text offsets of gigabytes, groups of thousands of lines, back-references of
         # kilobytes): every grammar.<q>.s.gz is ONE gzip member whose CRC-32 and ISIZE hold (gzip checks both) and whose content is the plain file

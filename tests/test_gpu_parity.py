@@ -364,12 +364,13 @@ def test_long_sentence_caches_and_id_level_corpus(cgx, oracle_bin, fixtures_dir,
 @pytest.mark.parametrize("name", ["tiny", "mid"])
 def test_every_stage_matches_the_oracle(name, hit_order, cgx, oracle_bin, fixtures_dir, tmp_path):
     """hit_order = 1: the hit lists sorted completely on the card and compared as they come; 0 (the default): ordered by pattern and
-    position bucket only -- the same SETS per pattern, and the same rules afterwards, which come from the lists' order statistics."""
+    position bucket only -- the same SETS per pattern, and the same rules afterwards, which come from the lists' order statistics.
+    The hit_order = 1 leg also runs the one-lane-per-line MaxLex kernel (lex_flat = 0) instead of the wave-wide task list."""
     fx = make_fixture(name, fixtures_dir); dump = str(tmp_path / "d.bin")
     op.run_oracle(oracle_bin, fx, str(tmp_path / "o"), dump)
     d = op.read_dump(dump); h = d["hdr"]; n, nt = h["n"], h["nt"]
     ex = cgx.Extractor(0)
-    ex.set_option("hit_order", hit_order)
+    ex.set_option("hit_order", hit_order); ex.set_option("lex_flat", 1 - hit_order)
     ex.upload_index(d["str"][:n], d["rlp"], d["tstr"][:nt], d["ltar"], d["rtar"], d["lexk"], d["lexv"])
     ex.build_sa()
     assert np.array_equal(ex.fetch("sa"), d["sa"])
@@ -491,7 +492,7 @@ def test_chunking_and_sharding_do_not_change_results(cgx, fixtures_dir, tmp_path
     ex.close(); corpus.close(); corpus2.close()
 
 
-@pytest.mark.parametrize("opts", [dict(append_slack=0, append_guess_milli=1), dict(wide_hits2=1), dict(wide_hits2=1, chunk_items=1024), dict(look_rec_cap=0), dict(look_rec_cap=3, chunk_items=4096), dict(use_lex_hash=0), dict(pool_cap=4), dict(pool_cap=1, look_rec_cap=2)])
+@pytest.mark.parametrize("opts", [dict(append_slack=0, append_guess_milli=1), dict(wide_hits2=1), dict(wide_hits2=1, chunk_items=1024), dict(look_rec_cap=0), dict(look_rec_cap=3, chunk_items=4096), dict(use_lex_hash=0), dict(lex_flat=0), dict(pool_cap=4), dict(pool_cap=1, look_rec_cap=2)])
 def test_lookup_output_sizing_paths(opts, cgx, fixtures_dir, tmp_path):
     """The single-pass lookups guess their output size: an undersized guess (rerun with the exact size), the
     wide-pattern-id layout (> 2^24 distinct two-gap patterns) and groups too large for the LDS record cache
