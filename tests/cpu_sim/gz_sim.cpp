@@ -14,6 +14,10 @@
 static uint64_t rs = 88172645463325252ull;
 static uint32_t rnd() { rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17; return (uint32_t)(rs >> 11); }
 static uint32_t rr(uint32_t n) { return rnd() % n; }
+// FNV-1a over every plain line and every byte of deflate output of the run: printed at the end, so that a change of the formatter can be
+// checked for "same bytes as before" on the CPU (tests/test_cpu_sim.py pins the values of the formatter that made the golden files)
+static uint64_t dig_plain = 1469598103934665603ull, dig_gz = 1469598103934665603ull;
+static void dig(uint64_t &h, const void *p, size_t n) { const unsigned char *b = (const unsigned char *)p; for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; } }
 
 struct Case {
     std::vector<char> spool, tpool; std::vector<uint32_t> soff, toff;
@@ -208,6 +212,8 @@ static int run_case(uint32_t G, uint32_t D1, uint32_t D2, uint32_t ns, uint32_t 
         if (inflate_member(file.data(), file.size(), got, &used)) { fprintf(stderr, "file %d is not a gzip member (CRC / ISIZE / stream)\n", f); return 1; }
         if (used != file.size() || got != want) { fprintf(stderr, "file %d inflates to other text\n", f); return 1; }
     }
+    for (uint32_t l = 0; l < NU; l++) dig(dig_plain, plain[l].data(), plain[l].size());
+    dig(dig_gz, text.data(), (size_t)GO[NG]);
     *nlines_out += NU; *plain_out += U[NU]; *gz_out += GO[NG];
     return 0;
 }
@@ -255,5 +261,6 @@ int main(int argc, char **argv) {
         if (run_case(3, 0, 0, 20, 20, false, 5, dyn != 0, &nl, &pb, &gb, &hb) || run_case(0, 2, 0, 20, 20, false, 5, dyn != 0, &nl, &pb, &gb, &hb) || run_case(0, 0, 0, 20, 20, false, 5, dyn != 0, &nl, &pb, &gb, &hb)) { printf("GZ SIM FAILED on a degenerate case (%s codes)\n", dyn ? "dynamic" : "fixed"); return 1; }
         printf("GZ SIM OK (%s codes, block header up to %llu bits): %llu lines, %llu bytes of text as %llu bytes of deflate blocks (%.3f)\n", dyn ? "dynamic" : "fixed", (unsigned long long)hb, (unsigned long long)nl, (unsigned long long)pb, (unsigned long long)gb, pb ? (double)gb / (double)pb : 0.0);
     }
+    printf("GZ SIM DIGEST plain %016llx deflate %016llx\n", (unsigned long long)dig_plain, (unsigned long long)dig_gz);
     return 0;
 }

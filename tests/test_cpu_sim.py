@@ -35,6 +35,9 @@ def test_formatter_gzip_members_inflate_to_the_plain_text(tmp_path):
                     os.path.join(ROOT, "tests", "cpu_sim", "gz_sim.cpp"), "-lz", "-o", exe], check=True)
     r = subprocess.run([exe, "8"], capture_output=True, text=True)
     assert r.returncode == 0 and "GZ SIM OK" in r.stdout, r.stdout + r.stderr
+    # the bytes themselves (FNV-1a over every plain line / every deflate byte of the seeded cases): the values of the formatter that made
+    # the golden grammar files on the GPU, recorded before its source and feature loops were folded into one instance each (round 4)
+    assert "GZ SIM DIGEST plain e875c462e26d72bd deflate a1f5a2b8e8931268" in r.stdout, r.stdout
 
 
 def test_window_transpose_algebra():
