@@ -33,6 +33,7 @@ struct cgx_ctx {
     uint8_t *d_ltar = nullptr, *d_rtar = nullptr;
     bool long_pos = false;              // long-sentence mode (cgx_rules.h): alignment words carry extra position bits, target-side tables are 16-bit
     uint16_t *d_ltar16 = nullptr, *d_rtar16 = nullptr;
+    uint4 *d_win = nullptr; bool win_table = false;    // every position's 16-entry window as an aligned 128-byte row (cgx_view::win); option "win_table", OFF: measured, buys nothing (cgx_index.inc)
     cgx_tok8 *d_tok8 = nullptr; uint8_t *d_lr16 = nullptr;   // derived layouts (cgx_rules.h), built by build_layouts
     double append_ms = 0.0;             // GPU time of the launches of the append passes since the caller last zeroed it (append_pass)
     uint8_t *d_lrs = nullptr; uint32_t lrs_k = 0;            // lr16 blocks addressed from the source side (cgx_view::lrs); null / 0 when the corpus does not allow them

@@ -50,6 +50,8 @@ struct cgx_view {            // read-only index arrays (device pointers on the G
     const uint16_t *rtar16;
     const uint8_t *lrs;      // lr16 blocks again, but addressed from the SOURCE side: the target words of the sentence whose source starts at
     uint32_t lrs_k;          // src0 sit at word lrs_k * src0 + (position in the target sentence).  Null when the corpus does not allow it.
+    const void *win;         // the 16 tok8 entries from EVERY position on, as one 128-byte-aligned row per position (16x the bytes of tok8: what 288 GB are for):
+                             // a lookup or extraction window is then ONE line of the L2 instead of 1.6-1.8 (cgx_index.inc build_layouts).  Null when it was not built.
 };
 // token / alignment word of corpus position k: from the interleaved array where it exists (one sector serves both), else from the two plain arrays
 CGX_HD int32_t cgx_tok(const cgx_view &v, int64_t k) { return v.tok8 ? v.tok8[k].tok : v.str[k]; }

@@ -492,7 +492,7 @@ def test_chunking_and_sharding_do_not_change_results(cgx, fixtures_dir, tmp_path
     ex.close(); corpus.close(); corpus2.close()
 
 
-@pytest.mark.parametrize("opts", [dict(append_slack=0, append_guess_milli=1), dict(wide_hits2=1), dict(wide_hits2=1, chunk_items=1024), dict(look_rec_cap=0), dict(look_rec_cap=3, chunk_items=4096), dict(use_lex_hash=0), dict(lex_flat=0), dict(pool_cap=4), dict(pool_cap=1, look_rec_cap=2)])
+@pytest.mark.parametrize("opts", [dict(append_slack=0, append_guess_milli=1), dict(wide_hits2=1), dict(wide_hits2=1, chunk_items=1024), dict(look_rec_cap=0), dict(look_rec_cap=3, chunk_items=4096), dict(use_lex_hash=0), dict(lex_flat=0), dict(win_table=1), dict(pool_cap=4), dict(pool_cap=1, look_rec_cap=2)])
 def test_lookup_output_sizing_paths(opts, cgx, fixtures_dir, tmp_path):
     """The single-pass lookups guess their output size: an undersized guess (rerun with the exact size), the
     wide-pattern-id layout (> 2^24 distinct two-gap patterns) and groups too large for the LDS record cache
@@ -597,22 +597,22 @@ def test_a_failed_stage_leaves_the_context_usable(cgx, fixtures_dir, tmp_path):
 
 
 def test_optional_index_tables_may_fail_to_allocate(cgx, fixtures_dir, tmp_path):
-    """The corpus-order occurrence table (pos1) and the source-addressed target blocks (lrs) only make the lookups faster: when the
+    """The corpus-order occurrence table (pos1), the source-addressed target blocks (lrs) and the window table (win) only make the lookups faster: when the
     card has no room for one of them (injected: the n-th device allocation of the index build fails) the index loads without it,
     says so, and the files are the golden files; a failure of a table the index needs still fails the load."""
     fx = make_fixture("toy", fixtures_dir); files = op.fixture_args(fx)
     corpus = cgx.Corpus.load(files[0], files[2], files[3], files[4])
     seen = set(); failed = 0
     for nth in range(1, 200):
-        ex = cgx.Extractor(0); ex.set_option("fault_inject", nth)
+        ex = cgx.Extractor(0); ex.set_option("win_table", 1); ex.set_option("fault_inject", nth)
         try:
             ex.upload_corpus(corpus)
         except cgx.CgxError:
             failed += 1; ex.close(); continue
-        injected = ex.stage_ms("pos1_skipped") == 1.0 or ex.stage_ms("src_blocks_skipped") == 1.0
+        injected = ex.stage_ms("pos1_skipped") == 1.0 or ex.stage_ms("src_blocks_skipped") == 1.0 or ex.stage_ms("win_table_skipped") == 1.0
         if not injected:                                                  # the counter ran past the last allocation of the build: nothing left to inject
             ex.set_option("fault_inject", 0); ex.close(); break
-        what = "pos1" if ex.stage_ms("pos1_skipped") == 1.0 else "lrs"
+        what = "pos1" if ex.stage_ms("pos1_skipped") == 1.0 else "win" if ex.stage_ms("win_table_skipped") == 1.0 else "lrs"
         ex.set_option("fault_inject", 0)
         if what not in seen:
             seen.add(what)
@@ -620,8 +620,9 @@ def test_optional_index_tables_may_fail_to_allocate(cgx, fixtures_dir, tmp_path)
             ex.extract_grammars(corpus, files[1], str(out))
             assert op.sha_dir(str(out), 7) == META["toy"]["grammar"], what
             assert (ex.stage_ms("src_blocks_factor") == 0) == (what == "lrs")
+            assert (ex.stage_ms("win_table_gb") == 0) == (what == "win")
         ex.close()
-    assert seen == {"pos1", "lrs"} and failed > 10, (seen, failed)
+    assert seen == {"pos1", "lrs", "win"} and failed > 10, (seen, failed)
     corpus.close()
 
 
