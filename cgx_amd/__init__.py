@@ -388,13 +388,14 @@ class Extractor:
     def flush(self):
         self._chk(self.lib.cgx_flush(self.h), "cgx_flush")
 
-    def run_sort(self, major, key, val=None):
-        """Test hook: run_sort (cgx_device.hip) on host arrays -> (keys, payload or None, long runs the fix pass met)."""
+    def run_sort(self, major, key, val=None, keybits=64):
+        """Test hook: run_sort (cgx_device.hip) on host arrays -> (keys, payload or None, long runs the fix pass met).
+        keybits: the promise that every key is below 2^keybits or all ones (<= 53: the ranking loop compares position-tagged keys)."""
         major = _c(major, np.uint32); key = _c(key, np.uint64); val = None if val is None else _c(val, np.uint32)
         ko = np.zeros(len(key), np.uint64); vo = None if val is None else np.zeros(len(key), np.uint32)
-        self.lib.cgx__test_run_sort.restype = C.c_int64
-        self.lib.cgx__test_run_sort.argtypes = [C.c_void_p] * 6 + [C.c_int64]
-        rc = self.lib.cgx__test_run_sort(self.h, _ptr(major), _ptr(key), _ptr(val), _ptr(ko), _ptr(vo), len(key))
+        self.lib.cgx__test_run_sort_bits.restype = C.c_int64
+        self.lib.cgx__test_run_sort_bits.argtypes = [C.c_void_p] * 6 + [C.c_int64, C.c_int]
+        rc = self.lib.cgx__test_run_sort_bits(self.h, _ptr(major), _ptr(key), _ptr(val), _ptr(ko), _ptr(vo), len(key), keybits)
         if rc < 0:
             self._chk(int(rc), "cgx__test_run_sort")
         return ko, vo, int(rc)

@@ -336,9 +336,14 @@ template <class T> __global__ void k_head_flags(const T *keys, uint32_t *flags, 
 // 5 ms per 6.7e7 keys in 1e7 segments.  All three were slower than the radix sort they were to replace.)
 #define RS_BLOCK 1024
 #define RS_MAXRUN 320
-template <bool VAL>
+// TAG: the keys are narrower than RS_TAGBITS bits (or all ones, the extraction's "no rule"): a record's position in the block goes into the
+// ten bits below its key, which makes the keys of a block distinct and turns "sorts before me, ties by position" into ONE 64-bit comparison
+// per pair instead of three -- the ranking loop is this kernel's time (a record of a 300-record run makes 300 comparisons).
+#define RS_TAGBITS 53
+template <bool VAL, bool TAG>
 __global__ __launch_bounds__(RS_BLOCK) void k_runsort_block(const uint32_t *__restrict__ major, const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin,
                                                              uint64_t *__restrict__ kout, uint32_t *__restrict__ vout, uint32_t n) {
+    static_assert(RS_BLOCK == 1024, "the position tag is ten bits");
     __shared__ uint64_t sk[RS_BLOCK + 8]; __shared__ unsigned long long heads[RS_BLOCK / 64];
     const uint32_t base = blockIdx.x * RS_BLOCK, i = base + threadIdx.x;
     const bool valid = i < n;
@@ -350,7 +355,8 @@ __global__ __launch_bounds__(RS_BLOCK) void k_runsort_block(const uint32_t *__re
     const unsigned long long hmask = __ballot(threadIdx.x == 0 || !valid || mprev != m);
     const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
     if (lane == 0) heads[wave] = hmask;
-    sk[threadIdx.x] = k;
+    const uint64_t kt = TAG ? (k << 10) | (uint64_t)threadIdx.x : k;
+    sk[threadIdx.x] = kt;
     __syncthreads();
     if (!valid) return;
     // lo: highest head bit at or below this position, searching this wave's mask, then the waves to the left
@@ -363,11 +369,16 @@ __global__ __launch_bounds__(RS_BLOCK) void k_runsort_block(const uint32_t *__re
               hi = hm ? w * 64 + __ffsll((long long)hm) - 2 : RS_BLOCK - 1; }
     uint32_t rank = 0; const int me = (int)threadIdx.x;
     int x = lo;
+    if (TAG) {
+        for (; x + 3 <= hi; x += 4) { const uint64_t o0 = sk[x], o1 = sk[x + 1], o2 = sk[x + 2], o3 = sk[x + 3]; rank += (uint32_t)(o0 < kt) + (uint32_t)(o1 < kt) + (uint32_t)(o2 < kt) + (uint32_t)(o3 < kt); }
+        for (; x <= hi; x++) rank += (uint32_t)(sk[x] < kt);
+    } else {
     for (; x + 3 <= hi; x += 4) {                                        // four independent LDS reads in flight
         const uint64_t o0 = sk[x], o1 = sk[x + 1], o2 = sk[x + 2], o3 = sk[x + 3];
         rank += (o0 < k || (o0 == k && x < me)) + (o1 < k || (o1 == k && x + 1 < me)) + (o2 < k || (o2 == k && x + 2 < me)) + (o3 < k || (o3 == k && x + 3 < me));
     }
     for (; x <= hi; x++) { const uint64_t o = sk[x]; rank += (o < k || (o == k && x < me)) ? 1u : 0u; }
+    }
     kout[base + (uint32_t)lo + rank] = k; if (VAL) vout[base + (uint32_t)lo + rank] = v;
 }
 template <bool VAL>
@@ -424,14 +435,16 @@ static_assert(CGX_SAMPLER <= RS_MAXRUN && CGX_SAMPLER_ONEGAP <= RS_MAXRUN && CGX
 // keys (and an optional payload) sorted inside every run of equal `major`, whatever the run lengths (runs of more than RS_MAXRUN
 // records that cross a block boundary take the slow path of the fix pass and are counted in ctx->d_rs_long, "run_sort_long_runs");
 // kout/vout must not alias the inputs
-static int run_sort(cgx_ctx *ctx, const uint32_t *major, const uint64_t *kin, const uint32_t *vin, uint64_t *kout, uint32_t *vout, size_t n) {
+// keybits: the callers' promise that every key is below 2^keybits or all ones (64: no promise)
+static int run_sort(cgx_ctx *ctx, const uint32_t *major, const uint64_t *kin, const uint32_t *vin, uint64_t *kout, uint32_t *vout, size_t n, unsigned keybits = 64) {
     if (n == 0) return CGX_OK;
     if (n > 0xFFFFFF00ull) return fail(ctx, CGX_ERR_NOMEM, "run_sort: too many records", hipSuccess);
     if ((const void *)kin == (const void *)kout || (vin && vin == vout)) return fail(ctx, CGX_ERR_ARG, "run_sort: output aliases input", hipSuccess);
     if (!ctx->d_rs_long) { TRY(dalloc(ctx, &ctx->d_rs_long, 1)); HIPCHK(hipMemsetAsync(ctx->d_rs_long, 0, 4, ctx->stream)); }
     const unsigned nb = nblocks(n, RS_BLOCK);
-    if (vin) k_runsort_block<true><<<nb, RS_BLOCK, 0, ctx->stream>>>(major, kin, vin, kout, vout, (uint32_t)n);
-    else k_runsort_block<false><<<nb, RS_BLOCK, 0, ctx->stream>>>(major, kin, nullptr, kout, nullptr, (uint32_t)n);
+    const bool tag = keybits <= RS_TAGBITS;
+    if (vin) { if (tag) k_runsort_block<true, true><<<nb, RS_BLOCK, 0, ctx->stream>>>(major, kin, vin, kout, vout, (uint32_t)n); else k_runsort_block<true, false><<<nb, RS_BLOCK, 0, ctx->stream>>>(major, kin, vin, kout, vout, (uint32_t)n); }
+    else { if (tag) k_runsort_block<false, true><<<nb, RS_BLOCK, 0, ctx->stream>>>(major, kin, nullptr, kout, nullptr, (uint32_t)n); else k_runsort_block<false, false><<<nb, RS_BLOCK, 0, ctx->stream>>>(major, kin, nullptr, kout, nullptr, (uint32_t)n); }
     if (nb > 1) {
         if (vin) k_runsort_fix<true><<<nb - 1, 64, 0, ctx->stream>>>(major, kin, vin, kout, vout, (uint32_t)n, ctx->d_rs_long);
         else k_runsort_fix<false><<<nb - 1, 64, 0, ctx->stream>>>(major, kin, nullptr, kout, nullptr, (uint32_t)n, ctx->d_rs_long);
@@ -440,8 +453,12 @@ static int run_sort(cgx_ctx *ctx, const uint32_t *major, const uint64_t *kin, co
     return CGX_OK;
 }
 // test hook (tests/test_gpu_parity.py): host arrays through run_sort; returns the number of long runs the fix pass met
+extern "C" int64_t cgx__test_run_sort_bits(cgx_ctx *ctx, const uint32_t *major, const uint64_t *key, const uint32_t *val, uint64_t *key_out, uint32_t *val_out, int64_t n, int keybits);
 extern "C" int64_t cgx__test_run_sort(cgx_ctx *ctx, const uint32_t *major, const uint64_t *key, const uint32_t *val, uint64_t *key_out, uint32_t *val_out, int64_t n) {
-    if (!ctx || n < 0 || (n && (!major || !key || !key_out)) || (val && !val_out)) return CGX_ERR_ARG;
+    return cgx__test_run_sort_bits(ctx, major, key, val, key_out, val_out, n, 64);
+}
+extern "C" int64_t cgx__test_run_sort_bits(cgx_ctx *ctx, const uint32_t *major, const uint64_t *key, const uint32_t *val, uint64_t *key_out, uint32_t *val_out, int64_t n, int keybits) {
+    if (!ctx || n < 0 || (n && (!major || !key || !key_out)) || (val && !val_out) || keybits < 1 || keybits > 64) return CGX_ERR_ARG;
     HIPCHK(hipSetDevice(ctx->device)); stage_enter(ctx);
     uint32_t *dm = nullptr, *dv = nullptr, *dvo = nullptr; uint64_t *dk = nullptr, *dko = nullptr;
     TRY(dalloc(ctx, &dm, (size_t)n)); TRY(dalloc(ctx, &dk, (size_t)n)); TRY(dalloc(ctx, &dko, (size_t)n));
@@ -450,7 +467,7 @@ extern "C" int64_t cgx__test_run_sort(cgx_ctx *ctx, const uint32_t *major, const
     if (n) {
         TRY(h2d(ctx, dm, major, (size_t)n)); TRY(h2d(ctx, dk, key, (size_t)n)); if (val) TRY(h2d(ctx, dv, val, (size_t)n));
         if (ctx->d_rs_long) TRY(d2h(ctx, &before, ctx->d_rs_long, 1));
-        TRY(run_sort(ctx, dm, dk, dv, dko, dvo, (size_t)n));
+        TRY(run_sort(ctx, dm, dk, dv, dko, dvo, (size_t)n, (unsigned)keybits));
         TRY(d2h(ctx, key_out, dko, (size_t)n)); if (val) TRY(d2h(ctx, val_out, dvo, (size_t)n));
         TRY(d2h(ctx, &after, ctx->d_rs_long, 1));
     }

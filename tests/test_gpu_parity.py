@@ -742,6 +742,13 @@ def test_run_sort_orders_runs_of_any_length(cgx):
         ko2, vo2, _ = ex.run_sort(major, key)
         assert vo2 is None and np.array_equal(ko2, key[order])
         assert nlong == want_long, (nlong, want_long)
+        # the same through the position-tagged comparison the callers with narrow keys get (keys < 2^53 or all ones = "no rule", which sorts last)
+        key3 = key.copy(); key3[rng.integers(0, n, n // 7)] = np.uint64(0xFFFFFFFFFFFFFFFF)
+        order3 = np.lexsort((val, key3, major))
+        ko3, vo3, _ = ex.run_sort(major, key3, val, keybits=max(keybits, 1))
+        assert np.array_equal(ko3, key3[order3]) and np.array_equal(vo3, val[order3])
+        ko4, _, _ = ex.run_sort(major, key3, None, keybits=53)
+        assert np.array_equal(ko4, key3[order3])
 
     # short runs only (1..300), many of them cut by block boundaries: the fast path
     check(rng.integers(1, 301, 4000), 40, 0)
@@ -752,5 +759,6 @@ def test_run_sort_orders_runs_of_any_length(cgx):
     lengths = [900, 400, 60, 5000, 20, 330, 300, 1]
     check(lengths, 30, 2)
     check([1024, 321 + 1024, 3], 3, 1)                         # a long run that starts exactly at a boundary; ties
-    assert ex.stage_ms("run_sort_long_runs") == 2 * (2 + 1)    # each check sorts twice (with and without payload)
+    check(rng.integers(1, 301, 3000), 53, 0)                   # the widest keys the tagged comparison takes
+    assert ex.stage_ms("run_sort_long_runs") == 4 * (2 + 1)    # each check sorts four times (with and without payload, plain and tagged)
     ex.close()
