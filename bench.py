@@ -645,7 +645,14 @@ def report(ex, args, cfg, L):
                          traffic_frac_of_peak=round(tr / (ms * 1e-3) / 1e9 / 8000.0, 4),     # what the HBM actually moved for this kernel, as a fraction of 8 TB/s
                          windows_per_s=round(w / (ms * 1e-3), 1), microbench_random_128B_runs_per_s=pk["random_read_peak"]["runs_per_s_128B"],   # tools/micro/gather_bw on the same card, one run per lane: a comparison, not a bound (neighbouring occurrences share sectors in the L2)
                          microbench_random_128B_runs_per_s_eight_lanes_per_run=pk["random_read_peak"].get("runs_per_s_128B_eight_lanes_per_run_8B_offsets"),   # tools/micro/gather_coop: the way the kernels read their windows now (runs at random 8-byte offsets)
-                         dram_read_requests_per_s=round(kk["TCC_EA0_RDREQ_per_batch"] / (ms * 1e-3), 1))   # against 3.0e10 (64-byte) .. 5.2e10 (16-byte) random reads per second of the card: the bound that applies
+                         dram_read_requests_per_s=round(kk["TCC_EA0_RDREQ_per_batch"] / (ms * 1e-3), 1))   # against 3.0e10 (64-byte) .. 5.2e10 (16-byte) random reads per second of the card
+                im = pk.get("issue_model")
+                if im and kk.get("SQ_INSTS_VALU"):               # the other resource these kernels load: instruction issue (round 4: a quarter fewer DRAM requests changed nothing, HISTORY.md)
+                    e["issue"] = {"vector_instructions_per_launch": kk["SQ_INSTS_VALU"], "scalar_instructions_per_launch": kk.get("SQ_INSTS_SALU"),
+                                  "frac_of_vector_issue_peak": round(kk["SQ_INSTS_VALU"] * im["cycles_per_vector_instruction"] / (im["simds"] * im["shader_clock_hz"] * ms * 1e-3), 3),
+                                  "frac_of_scalar_issue_peak": (round(kk["SQ_INSTS_SALU"] / (im["scalar_units"] * im["shader_clock_hz"] * ms * 1e-3), 3) if kk.get("SQ_INSTS_SALU") else None),
+                                  "wave_cycles_waiting": kk.get("SQ_WAIT_ANY_frac"),
+                                  "note": "counts from the committed counter passes (pmc_lookup_kernels.json), duration from this run: vector issue, scalar issue and the random-read rate are each about half used -- the kernel alternates between them inside every wave (window round trip, 13-move walk, candidate phase) at six waves per SIMD"}
             by_time.append(e)
     by_time.sort(key=lambda e: -e["ms_per_launch"])              # roofline_dominant = the kernel that takes the most time per batch
     gb = lambda k: round(max(ex.stage_ms(k), 0.0) / 1e9, 2)
