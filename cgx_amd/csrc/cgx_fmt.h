@@ -338,9 +338,13 @@ template <class B, bool CRC, int MODE = GZ_WRITE> struct GzSink {
     CGX_HD void lit() { flush(); inm = false; }
     CGX_HD void feed(uint64_t v, uint32_t n) {                   // the low n (1..8) bytes of v
         pos += n;
-        if (CRC) crc = gz_crc_group(tab, crc, v, n);
+#ifndef GZ_LOO
+#define GZ_LOO 0      // leave-one-out builds for timing studies (output meaningless; the counting and the writing pass stay consistent): 1 no CRC-32, 2 literals as raw bytes (no code table), 3 both
+#endif
+        if (CRC && !(GZ_LOO & 1)) crc = gz_crc_group(tab, crc, v, n);
         if (inm) { mlen += n; if (mlen >= 258u) { emit_match(255u, mdist); mlen -= 255u; } }      // what stays pending is again >= 3
         else if (MODE == GZ_TALLY) { for (uint32_t i = 0; i < n; i++) GZ_TALLY_ADD(&hist[(uint32_t)(v >> (8u * i)) & 255u]); }
+        else if (GZ_LOO & 2) { b.bits((uint32_t)v & (n >= 4u ? 0xFFFFFFFFu : (1u << (8u * n)) - 1u), n >= 4u ? 32u : 8u * n); if (n > 4u) b.bits((uint32_t)(v >> 32) & (n >= 8u ? 0xFFFFFFFFu : (1u << (8u * (n - 4u))) - 1u), 8u * (n - 4u)); }
         else {
             // literals two at a time: two codes are at most 30 bits, one insertion into the bit sink instead of two
             uint32_t i = 0;

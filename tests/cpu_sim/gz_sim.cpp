@@ -41,8 +41,10 @@ static void make_vocab(std::vector<char> &pool, std::vector<uint32_t> &off, uint
 static void make_case(Case &c, uint32_t G, uint32_t D1, uint32_t D2, uint32_t ns, uint32_t nt, bool utf8, uint32_t maxlines) {
     c.G = G; c.D1 = D1; c.D2 = D2;
     make_vocab(c.spool, c.soff, ns, utf8); make_vocab(c.tpool, c.toff, nt, utf8);
-    c.str.resize(4096); for (auto &x : c.str) x = (int32_t)rr(ns + 3);                 // ids past the vocabulary print as numbers too
-    c.tstr.resize(8192); for (auto &x : c.tstr) x = (int32_t)rr(nt + 3);
+    // ids past the vocabulary print as numbers too: one, two and three digit groups, and beyond 10^6 (the general digit loop)
+    auto any_id = [&](uint32_t nv) { const uint32_t k = rr(16); return (int32_t)(k == 0 ? nv + rr(900) : k == 1 ? nv + rr(99000) : k == 2 ? 999990 + rr(20) : k == 3 ? 1000000 + rr(2000000000u) : rr(nv + 3)); };
+    c.str.resize(4096); for (auto &x : c.str) x = any_id(ns);
+    c.tstr.resize(8192); for (auto &x : c.tstr) x = any_id(nt);
     c.blocks.resize(G); for (auto &b : c.blocks) { b.start = 0; b.end = 0; b.matchlen = 1 + (int32_t)rr(5); b.string_start = (int32_t)rr(4000); }
     c.p1d.resize(D1 ? D1 : 1);
     for (auto &p : c.p1d) { int a = 1 + (int)rr(2), bn = 1 + (int)rr(2); p.number = (uint8_t)(a + 1 + bn); int j = 0; for (int k = 0; k < a; k++) p.pat[j++] = (int32_t)rr(ns); p.pat[j++] = -1; for (int k = 0; k < bn; k++) p.pat[j++] = (int32_t)rr(ns); while (j < 5) p.pat[j++] = -2; }
