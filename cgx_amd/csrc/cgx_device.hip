@@ -505,7 +505,7 @@ static void free_batch(cgx_ctx *c) {
 }
 static void free_index(cgx_ctx *c) {
     dfree(c->d_win); dfree(c->d_str); dfree(c->d_sa); dfree(c->d_rlp); dfree(c->d_tstr); dfree(c->d_ltar); dfree(c->d_rtar); dfree(c->d_ltar16); dfree(c->d_rtar16); c->long_pos = false; dfree(c->d_tok8); dfree(c->d_lr16); dfree(c->d_lrs); c->lrs_k = 0; dfree(c->d_pos1);
-    dfree(c->d_lexkey); dfree(c->d_lexv1); dfree(c->d_lexv2); dfree(c->d_lexn1); dfree(c->d_lexn2); dfree(c->d_lexrow); dfree(c->d_lexnullt); dfree(c->d_lexhkey); dfree(c->d_lexhidx); dfree(c->d_lexslot); dfree(c->d_lexnullv); c->lex_hmask = 0;
+    dfree(c->d_lexkey); dfree(c->d_lexv1); dfree(c->d_lexv2); dfree(c->d_lexn1); dfree(c->d_lexn2); dfree(c->d_lexrow); dfree(c->d_lexnullt); dfree(c->d_lexhkey); dfree(c->d_lexhidx); dfree(c->d_lexslot); dfree(c->d_lexnullv); dfree(c->d_lexpbits); c->lex_hmask = 0;
     dfree(c->d_tokstart); dfree(c->d_tokrank); dfree(c->d_freq); dfree(c->d_pidx); dfree(c->d_miss);
     dfree(c->d_phit_start); dfree(c->d_phit_len); for (int k = 0; k < 4; k++) { dfree(c->d_ng[k]); c->ng_cap[k] = 0; }
     c->n = c->nt = c->nlex = c->nphits = 0; c->have_sa = c->have_pre = false;
@@ -549,6 +549,7 @@ extern "C" int cgx_set_option(cgx_ctx *c, const char *name, int64_t value) {
     if (!strcmp(name, "hit_order")) { c->hit_order = value != 0; return CGX_OK; }
     if (!strcmp(name, "tile_order")) { c->tile_order = value != 0; return CGX_OK; }
     if (!strcmp(name, "lex_flat")) { c->lex_flat = value != 0; return CGX_OK; }
+    if (!strcmp(name, "lex_bits")) { c->lex_bits = value != 0; return CGX_OK; }
     if (!strcmp(name, "win_table")) { c->win_table = value != 0; return CGX_OK; }       /* before the index is built or loaded: 1 = build the window table (cgx_view::win; 128 bytes per corpus position) */
     if (!strcmp(name, "write_period")) { if (value < 0) return CGX_ERR_ARG; c->write_period = value; return CGX_OK; }
     if (!strcmp(name, "write_count")) { if (value < 0) return CGX_ERR_ARG; c->write_count = value; return CGX_OK; }
@@ -619,7 +620,7 @@ static void memory_report(cgx_ctx *c) {
                           (const void *)c->d_tokstart, (const void *)c->d_tokrank, (const void *)c->d_freq, (const void *)c->d_pidx, (const void *)c->d_miss, (const void *)c->d_phit_start, (const void *)c->d_phit_len,
                           (const void *)c->d_spool, (const void *)c->d_soff, (const void *)c->d_tpool, (const void *)c->d_toff, (const void *)c->d_aa, (const void *)c->d_bb, (const void *)c->d_fs, (const void *)c->d_gztab}) index += sz(p);
     double ngram = 0; for (int k = 0; k < 4; k++) ngram += sz(c->d_ng[k]);
-    const double layouts = sz(c->d_tok8) + sz(c->d_lr16) + sz(c->d_lrs) + sz(c->d_pos1) + sz(c->d_win), lexhash = sz(c->d_lexslot) + sz(c->d_lexnullv) + sz(c->d_lexhkey) + sz(c->d_lexhidx);
+    const double layouts = sz(c->d_tok8) + sz(c->d_lr16) + sz(c->d_lrs) + sz(c->d_pos1) + sz(c->d_win), lexhash = sz(c->d_lexslot) + sz(c->d_lexnullv) + sz(c->d_lexhkey) + sz(c->d_lexhidx) + sz(c->d_lexpbits);
     derived = ngram + layouts + lexhash;
     for (int a = 0; a < 2; a++) text += sz(c->d_text[a]) + sz(c->d_qtext[a]) + sz(c->d_seg_off[a]) + sz(c->d_seg_len[a]) + sz(c->d_qseg[a]) + sz(c->d_trl[a]);
     for (const void *p : {(const void *)c->d_qoff, (const void *)c->d_qtok, (const void *)c->d_tok2q, (const void *)c->d_lm, (const void *)c->d_up, (const void *)c->d_down,

@@ -480,7 +480,11 @@ struct cgx_lexview {
     // optional packed copies for MaxLex: the four values next to the key (one 32-byte slot per probe instead of
     // key + index + four arrays), and (NULL, tgt) as a direct {v1, n1} table (v1 < 0: absent)
     const struct cgx_lexslot *hslot = nullptr; const struct cgx_lexnull *nullv = nullptr;
+    // optional presence bits: bit ((key * CGX_LEXBIT_MUL) >> pshift) is set for every key of the table -- a few megabytes that stay in the L2, asked
+    // before the pair keys (48 MB at the bench's table: most probes of MaxLex are for pairs that are in no row)
+    const uint32_t *pbits = nullptr; unsigned pshift = 0;
 };
+#define CGX_LEXBIT_MUL 0xD6E8FEB86659FD93ull
 struct cgx_lexslot { uint64_t key; float v1, v2, n1, n2; uint64_t pad; };
 struct cgx_lexnull { float v1, n1; };
 CGX_HD uint64_t cgx_lexkey_pack(int32_t src, int32_t tgt) { return ((uint64_t)(uint32_t)(src + 1) << 32) | (uint32_t)(tgt + 1); }

@@ -78,7 +78,7 @@ typedef struct {
 cgx_ctx *cgx_create(int device);                       /* replaces suffixArraySearchInit (SuffixArray.cu:769) */
 void cgx_destroy(cgx_ctx *ctx);                        /* replaces suffixArraySearchFinalize*, extractPairFinalize */
 const char *cgx_last_error(cgx_ctx *ctx);
-int cgx_set_option(cgx_ctx *ctx, const char *name, int64_t value); /* "k1_limit" (default 128: query tokens per sentence that are looked up, the reference's K1 launch width; 0 = no limit), "chunk_items", "force_host_lexicon", "async_write", "prealloc_text" (default 0; 1 = a caller that will submit several batches with async_write asks for both text buffers to be allocated at the first one), "use_bigrams" (default 1), "use_lex_hash" (default 1), "device_format" (default 1), "gz_level" (0 = plain grammar.<q>.s; 1..9 = grammar.<q>.s.gz) and "gz_device" (default 1: with the device formatter the gzip members are produced on the GPU and gz_level only switches them on; 0 = the host's zlib compresses the plain text at gz_level), "sub_batch" (queries per internal batch of cgx_extract_grammars*; 0 = automatic: at most "auto_batch_tokens" (default 300000) query tokens per internal batch; with async_write the writer of one sub-batch overlaps the GPU work of the next), "write_period" / "write_count" (with a period P > 0 only the files of queries g with g % P < count are written, g = index in the whole query list; rules are counted for all, and an internal batch without such a query lays out no text: full-count runs that sample their output), "src_blocks" (default 1; 0 = the lookups locate a sentence's target-side alignment bytes through the delimiter's alignment word instead of the source-addressed copy of the blocks: A/B and test hook), "hit_order" (default 0: the hit lists fetched with cgx_fetch are grouped by pattern and ordered by position bucket only, which is all extraction needs; 1 = sorted completely on the card), "gz_dynamic" (default 1: Huffman codes made per batch for the device-made .gz output; 0 = the fixed codes of RFC 1951), "lex_flat" (default 1: MaxLex as one task list per wave; 0 = one lane per lexicon line), "win_table" (default 0; 1, set before the index is built or loaded = one aligned 128-byte window row per corpus position, 128 N bytes: measured, buys nothing) and "tile_order" (default 0) -- A/B switches, same results either way; "wide_hits2", "look_rec_cap", "pool_cap", "fault_inject", "append_slack", "append_guess_milli" (test hooks for the lookup output sizing) */
+int cgx_set_option(cgx_ctx *ctx, const char *name, int64_t value); /* "k1_limit" (default 128: query tokens per sentence that are looked up, the reference's K1 launch width; 0 = no limit), "chunk_items", "force_host_lexicon", "async_write", "prealloc_text" (default 0; 1 = a caller that will submit several batches with async_write asks for both text buffers to be allocated at the first one), "use_bigrams" (default 1), "use_lex_hash" (default 1), "device_format" (default 1), "gz_level" (0 = plain grammar.<q>.s; 1..9 = grammar.<q>.s.gz) and "gz_device" (default 1: with the device formatter the gzip members are produced on the GPU and gz_level only switches them on; 0 = the host's zlib compresses the plain text at gz_level), "sub_batch" (queries per internal batch of cgx_extract_grammars*; 0 = automatic: at most "auto_batch_tokens" (default 300000) query tokens per internal batch; with async_write the writer of one sub-batch overlaps the GPU work of the next), "write_period" / "write_count" (with a period P > 0 only the files of queries g with g % P < count are written, g = index in the whole query list; rules are counted for all, and an internal batch without such a query lays out no text: full-count runs that sample their output), "src_blocks" (default 1; 0 = the lookups locate a sentence's target-side alignment bytes through the delimiter's alignment word instead of the source-addressed copy of the blocks: A/B and test hook), "hit_order" (default 0: the hit lists fetched with cgx_fetch are grouped by pattern and ordered by position bucket only, which is all extraction needs; 1 = sorted completely on the card), "gz_dynamic" (default 1: Huffman codes made per batch for the device-made .gz output; 0 = the fixed codes of RFC 1951), "lex_flat" (default 1: MaxLex as one task list per wave; 0 = one lane per lexicon line), "lex_bits" (default 1: presence bits asked before the pair keys of the lexical table), "win_table" (default 0; 1, set before the index is built or loaded = one aligned 128-byte window row per corpus position, 128 N bytes: measured, buys nothing) and "tile_order" (default 0) -- A/B switches, same results either way; "wide_hits2", "look_rec_cap", "pool_cap", "fault_inject", "append_slack", "append_guess_milli" (test hooks for the lookup output sizing) */
 
 /* ---- index: upload, device suffix-array construction, frequent-pair precomputation ---- */
 int cgx_upload_index(cgx_ctx *ctx, const cgx_index_host *ix);   /* H2D of the index (SuffixArray.cu:1396-1412, ExtractPair.cu:3279-3282) */

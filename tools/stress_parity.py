@@ -80,7 +80,7 @@ def main():
         import random
         r = random.Random(args.seed); shapes = []
         menu = {"pool_cap": [1, 7, 64], "look_rec_cap": [0, 1, 5, 40], "sub_batch": [1, 13, 50], "async_write": [1], "chunk_items": [1024, 4096, 1 << 16],
-                "use_lex_hash": [0], "lex_flat": [0], "win_table": [1], "append_guess_milli": [1, 300], "append_slack": [0, 5], "wide_hits2": [1], "hit_order": [1], "device_format": [0], "use_bigrams": [0], "ngram_tables": [1, 2, 3, 4], "use_layouts": [0], "src_blocks": [0], "k1_limit": [128], "auto_batch_tokens": [40, 300], "lex_hash_bits": [3, 12, 20]}
+                "use_lex_hash": [0], "lex_flat": [0], "lex_bits": [0], "win_table": [1], "append_guess_milli": [1, 300], "append_slack": [0, 5], "wide_hits2": [1], "hit_order": [1], "device_format": [0], "use_bigrams": [0], "ngram_tables": [1, 2, 3, 4], "use_layouts": [0], "src_blocks": [0], "k1_limit": [128], "auto_batch_tokens": [40, 300], "lex_hash_bits": [3, 12, 20]}
         for i in range(args.fuzz):
             lo = r.choice([1, 2, 4, 8, 15]); hi = lo + r.choice([3, 10, 25, 60])
             opts = {k: r.choice(v) for k, v in menu.items() if r.random() < 0.25}
