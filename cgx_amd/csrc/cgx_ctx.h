@@ -71,7 +71,7 @@ struct cgx_ctx {
     uint32_t look_rec_cap = 65535;      // test hook: groups with more records than this read them from global memory
     bool wide_hits2 = false;            // test hook: take the path of two-gap pattern ids that do not fit beside the occurrence
     bool tile_order = false;            // 1: the tiles of k_look1 launched in corpus-region order (cgx_search.inc k_tile_region) -- measured in round 4: 29.8 -> 29.3 ms, not worth its sort; kept as an A/B switch
-    bool lex_flat = true;               // MaxLex as one task list per wave (k_lex_finish_flat); 0: one lane per line (k_lex_finish), the A/B switch
+    int lex_flat = 1;                   // MaxLex as one task list per wave (k_lex_finish_flat); 0: one lane per line (k_lex_finish), the A/B switch; 2 (test hook): as 1, but the "not covered" answer is forced, so that the redo path runs
     bool hit_order = false;             // 1: the hit lists are sorted completely (what cgx_fetch "hits1" / "hits2" callers may want); 0: as far as extraction needs
     int32_t freq[100] = {0};
 

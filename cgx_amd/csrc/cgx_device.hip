@@ -548,7 +548,7 @@ extern "C" int cgx_set_option(cgx_ctx *c, const char *name, int64_t value) {
     if (!strcmp(name, "wide_hits2")) { c->wide_hits2 = value != 0; return CGX_OK; }
     if (!strcmp(name, "hit_order")) { c->hit_order = value != 0; return CGX_OK; }
     if (!strcmp(name, "tile_order")) { c->tile_order = value != 0; return CGX_OK; }
-    if (!strcmp(name, "lex_flat")) { c->lex_flat = value != 0; return CGX_OK; }
+    if (!strcmp(name, "lex_flat")) { if (value < 0 || value > 2) return CGX_ERR_ARG; c->lex_flat = (int)value; return CGX_OK; }
     if (!strcmp(name, "lex_bits")) { c->lex_bits = value != 0; return CGX_OK; }
     if (!strcmp(name, "win_table")) { c->win_table = value != 0; return CGX_OK; }       /* before the index is built or loaded: 1 = build the window table (cgx_view::win; 128 bytes per corpus position) */
     if (!strcmp(name, "write_period")) { if (value < 0) return CGX_ERR_ARG; c->write_period = value; return CGX_OK; }

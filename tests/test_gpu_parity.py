@@ -492,7 +492,7 @@ def test_chunking_and_sharding_do_not_change_results(cgx, fixtures_dir, tmp_path
     ex.close(); corpus.close(); corpus2.close()
 
 
-@pytest.mark.parametrize("opts", [dict(append_slack=0, append_guess_milli=1), dict(wide_hits2=1), dict(wide_hits2=1, chunk_items=1024), dict(look_rec_cap=0), dict(look_rec_cap=3, chunk_items=4096), dict(use_lex_hash=0), dict(lex_flat=0), dict(lex_bits=0), dict(win_table=1), dict(pool_cap=4), dict(pool_cap=1, look_rec_cap=2)])
+@pytest.mark.parametrize("opts", [dict(append_slack=0, append_guess_milli=1), dict(wide_hits2=1), dict(wide_hits2=1, chunk_items=1024), dict(look_rec_cap=0), dict(look_rec_cap=3, chunk_items=4096), dict(use_lex_hash=0), dict(lex_flat=0), dict(lex_flat=2), dict(lex_bits=0), dict(win_table=1), dict(pool_cap=4), dict(pool_cap=1, look_rec_cap=2)])
 def test_lookup_output_sizing_paths(opts, cgx, fixtures_dir, tmp_path):
     """The single-pass lookups guess their output size: an undersized guess (rerun with the exact size), the
     wide-pattern-id layout (> 2^24 distinct two-gap patterns) and groups too large for the LDS record cache
