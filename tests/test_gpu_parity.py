@@ -597,7 +597,7 @@ def test_a_failed_stage_leaves_the_context_usable(cgx, fixtures_dir, tmp_path):
 
 
 def test_optional_index_tables_may_fail_to_allocate(cgx, fixtures_dir, tmp_path):
-    """The corpus-order occurrence table (pos1), the source-addressed target blocks (lrs) and the window table (win) only make the lookups faster: when the
+    """The corpus-order occurrence table (pos1), the source-addressed target blocks (lrs), the window table (win) and the presence bits of the lexical table (bits) only make kernels faster: when the
     card has no room for one of them (injected: the n-th device allocation of the index build fails) the index loads without it,
     says so, and the files are the golden files; a failure of a table the index needs still fails the load."""
     fx = make_fixture("toy", fixtures_dir); files = op.fixture_args(fx)
@@ -609,10 +609,10 @@ def test_optional_index_tables_may_fail_to_allocate(cgx, fixtures_dir, tmp_path)
             ex.upload_corpus(corpus)
         except cgx.CgxError:
             failed += 1; ex.close(); continue
-        injected = ex.stage_ms("pos1_skipped") == 1.0 or ex.stage_ms("src_blocks_skipped") == 1.0 or ex.stage_ms("win_table_skipped") == 1.0
+        injected = ex.stage_ms("pos1_skipped") == 1.0 or ex.stage_ms("src_blocks_skipped") == 1.0 or ex.stage_ms("win_table_skipped") == 1.0 or ex.stage_ms("lex_bits_skipped") == 1.0
         if not injected:                                                  # the counter ran past the last allocation of the build: nothing left to inject
             ex.set_option("fault_inject", 0); ex.close(); break
-        what = "pos1" if ex.stage_ms("pos1_skipped") == 1.0 else "win" if ex.stage_ms("win_table_skipped") == 1.0 else "lrs"
+        what = "pos1" if ex.stage_ms("pos1_skipped") == 1.0 else "win" if ex.stage_ms("win_table_skipped") == 1.0 else "bits" if ex.stage_ms("lex_bits_skipped") == 1.0 else "lrs"
         ex.set_option("fault_inject", 0)
         if what not in seen:
             seen.add(what)
@@ -622,7 +622,7 @@ def test_optional_index_tables_may_fail_to_allocate(cgx, fixtures_dir, tmp_path)
             assert (ex.stage_ms("src_blocks_factor") == 0) == (what == "lrs")
             assert (ex.stage_ms("win_table_gb") == 0) == (what == "win")
         ex.close()
-    assert seen == {"pos1", "lrs", "win"} and failed > 10, (seen, failed)
+    assert seen == {"pos1", "lrs", "win", "bits"} and failed > 10, (seen, failed)
     corpus.close()
 
 
