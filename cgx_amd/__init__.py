@@ -48,7 +48,7 @@ COUNT_NAMES = ["e1", "d1", "h1", "e2", "d2", "h2", "g", "n0", "n1", "n2", "sep1"
 # every entry point declared in include/cgx.h
 ABI = [
     "cgx_create", "cgx_destroy", "cgx_last_error", "cgx_set_option", "cgx_upload_index", "cgx_build_sa", "cgx_precompute",
-    "cgx_index_shape", "cgx_index_alloc", "cgx_index_nbuffers", "cgx_index_buffer", "cgx_index_d2d", "cgx_index_finalize", "cgx_index_save", "cgx_index_load", "cgx_broadcast_index",
+    "cgx_index_shape", "cgx_index_alloc", "cgx_share_index", "cgx_index_nbuffers", "cgx_index_buffer", "cgx_index_d2d", "cgx_index_finalize", "cgx_index_save", "cgx_index_load", "cgx_broadcast_index",
     "cgx_upload_queries", "cgx_sa_lookup", "cgx_gappy_search", "cgx_make_blocks", "cgx_set_blocks", "cgx_extract", "cgx_lexicon", "cgx_lex_features", "cgx_fetch",
     "cgx_stage_ms", "cgx_corpus_load", "cgx_corpus_free", "cgx_corpus_checksum", "cgx_corpus_save", "cgx_corpus_load_cache", "cgx_corpus_matches_sources", "cgx_corpus_upload", "cgx_extract_grammars", "cgx_extract_grammars_shard", "cgx_shard_bounds", "cgx_extract_grammars_ids",
     "cgx_corpus_from_ids", "cgx_host_ms", "cgx_flush", "cgx_fetch_pinned", "cgx_pinned_next_batch", "cgx_upload_vocab", "cgx_upload_score_tables", "cgx_set_query_blocks",
@@ -252,6 +252,12 @@ class Extractor:
     def index_alloc(self, dims):
         d = np.asarray(dims, np.int32)
         self._chk(self.lib.cgx_index_alloc(self.h, _ptr(d)), "cgx_index_alloc")
+
+    def share_index(self, other):
+        """This context borrows the index of `other` (same device; nothing is copied): two contexts, driven from two threads, keep two
+        batches in flight on one card.  `other` must stay alive and must not rebuild its index while this one uses it."""
+        self.lib.cgx_share_index.restype = C.c_int; self.lib.cgx_share_index.argtypes = [C.c_void_p, C.c_void_p]
+        self._chk(self.lib.cgx_share_index(self.h, other.h), "cgx_share_index")
 
     def index_d2d(self, i, dptr, direction):
         self._chk(self.lib.cgx_index_d2d(self.h, i, C.c_void_p(dptr), direction), "cgx_index_d2d")

@@ -28,6 +28,7 @@ struct cgx_ctx {
     // ---- index, resident for the life of the context ----
     uint32_t n = 0, nt = 0, nlex = 0, nphits = 0; int32_t last = 0;
     bool have_sa = false, have_pre = false;
+    bool index_borrowed = false;        // the index arrays below belong to another context of this device (cgx_share_index): used, never freed
     int32_t *d_str = nullptr, *d_sa = nullptr, *d_tstr = nullptr;
     uint32_t *d_rlp = nullptr;
     uint8_t *d_ltar = nullptr, *d_rtar = nullptr;

@@ -53,15 +53,26 @@ struct DevPool {
     std::multimap<size_t, idle> cached;
     size_t cached_bytes = 0;
     void *get(size_t bytes, const void *owner, hipStream_t stream) {
-        auto it = cached.lower_bound(bytes);
-        if (it != cached.end() && it->first <= bytes * 2 + (1u << 20)) {
+        // best fit within 2x among the blocks last used on THIS stream (or on none); a block of another stream -- two contexts working on one
+        // device at the same time -- would have to wait for that stream to drain, so it is taken only when the driver has no memory left
+        auto other = cached.end();
+        for (auto it = cached.lower_bound(bytes); it != cached.end() && it->first <= bytes * 2 + (1u << 20); ++it) {
+            if (it->second.stream && it->second.stream != stream) { if (other == cached.end()) other = it; continue; }
             idle e = it->second; const size_t have = it->first;
             cached_bytes -= have; cached.erase(it);
-            if (e.stream && e.stream != stream) (void)hipStreamSynchronize(e.stream);
             live[e.p] = blk{have, owner, stream};
             return e.p;
         }
         void *p = nullptr;
+        if (hipMalloc(&p, bytes) == hipSuccess) { live[p] = blk{bytes, owner, stream}; return p; }
+        (void)hipGetLastError();
+        if (other != cached.end()) {
+            idle e = other->second; const size_t have = other->first;
+            cached_bytes -= have; cached.erase(other);
+            (void)hipStreamSynchronize(e.stream);
+            live[e.p] = blk{have, owner, stream};
+            return e.p;
+        }
         if (hipMalloc(&p, bytes) != hipSuccess) { trim(); (void)hipGetLastError(); if (hipMalloc(&p, bytes) != hipSuccess) return nullptr; }
         live[p] = blk{bytes, owner, stream};
         return p;
@@ -503,12 +514,43 @@ static void free_batch(cgx_ctx *c) {
     c->e1 = c->d1 = c->h1 = c->e2 = c->d2 = c->h2 = c->g = c->n0 = c->n1 = c->n2 = c->sep1 = c->sep2a = c->sep2b = 0;
     c->guard_exits = 0;
 }
+// the index members of a context, as one list: what free_index gives back and what cgx_share_index lends
+#define CGX_INDEX_POINTERS(X) \
+    X(d_win) X(d_str) X(d_sa) X(d_rlp) X(d_tstr) X(d_ltar) X(d_rtar) X(d_ltar16) X(d_rtar16) X(d_tok8) X(d_lr16) X(d_lrs) X(d_pos1) \
+    X(d_lexkey) X(d_lexv1) X(d_lexv2) X(d_lexn1) X(d_lexn2) X(d_lexrow) X(d_lexnullt) X(d_lexhkey) X(d_lexhidx) X(d_lexslot) X(d_lexnullv) X(d_lexpbits) \
+    X(d_tokstart) X(d_tokrank) X(d_freq) X(d_pidx) X(d_miss) X(d_phit_start) X(d_phit_len) X(d_ng[0]) X(d_ng[1]) X(d_ng[2]) X(d_ng[3])
 static void free_index(cgx_ctx *c) {
+    if (c->index_borrowed) {                                    // another context's arrays: forget them
+#define X(m) c->m = nullptr;
+        CGX_INDEX_POINTERS(X)
+#undef X
+        c->index_borrowed = false;
+    }
     dfree(c->d_win); dfree(c->d_str); dfree(c->d_sa); dfree(c->d_rlp); dfree(c->d_tstr); dfree(c->d_ltar); dfree(c->d_rtar); dfree(c->d_ltar16); dfree(c->d_rtar16); c->long_pos = false; dfree(c->d_tok8); dfree(c->d_lr16); dfree(c->d_lrs); c->lrs_k = 0; dfree(c->d_pos1);
     dfree(c->d_lexkey); dfree(c->d_lexv1); dfree(c->d_lexv2); dfree(c->d_lexn1); dfree(c->d_lexn2); dfree(c->d_lexrow); dfree(c->d_lexnullt); dfree(c->d_lexhkey); dfree(c->d_lexhidx); dfree(c->d_lexslot); dfree(c->d_lexnullv); dfree(c->d_lexpbits); c->lex_hmask = 0;
     dfree(c->d_tokstart); dfree(c->d_tokrank); dfree(c->d_freq); dfree(c->d_pidx); dfree(c->d_miss);
     dfree(c->d_phit_start); dfree(c->d_phit_len); for (int k = 0; k < 4; k++) { dfree(c->d_ng[k]); c->ng_cap[k] = 0; }
     c->n = c->nt = c->nlex = c->nphits = 0; c->have_sa = c->have_pre = false;
+}
+// Two contexts of one device over ONE index (include/cgx.h): dst borrows every index array of src and the scalars that describe them.
+extern "C" int cgx_share_index(cgx_ctx *dst, const cgx_ctx *src) {
+    if (!dst || !src || dst == src) return CGX_ERR_ARG;
+    cgx_ctx *ctx = dst;
+    if (dst->device != src->device) return fail(ctx, CGX_ERR_ARG, "cgx_share_index: the two contexts are on different devices", hipSuccess);
+    if (!src->d_str || !src->have_sa || !src->have_pre) return fail(ctx, CGX_ERR_STATE, "cgx_share_index: the lending context has no complete index", hipSuccess);
+    HIPCHK(hipSetDevice(dst->device)); stage_enter(dst);
+    HIPCHK(hipStreamSynchronize(src->stream));                   // whatever built the index has finished
+    free_batch(dst); free_index(dst);
+#define X(m) dst->m = src->m;
+    CGX_INDEX_POINTERS(X)
+#undef X
+    dst->n = src->n; dst->nt = src->nt; dst->nlex = src->nlex; dst->nphits = src->nphits; dst->last = src->last; dst->have_sa = src->have_sa; dst->have_pre = src->have_pre;
+    dst->long_pos = src->long_pos; dst->lrs_k = src->lrs_k; dst->lex_nrow = src->lex_nrow; dst->lex_ntgt = src->lex_ntgt; dst->lex_hmask = src->lex_hmask; dst->lex_hshift = src->lex_hshift; dst->lex_pshift = src->lex_pshift;
+    for (int k = 0; k < 4; k++) { dst->ng_cap[k] = src->ng_cap[k]; dst->ng_shift[k] = src->ng_shift[k]; }
+    memcpy(dst->freq, src->freq, sizeof dst->freq);
+    for (const char *k : {"src_blocks_factor", "win_table_gb", "ngram_table_bytes"}) { auto it = src->ms.find(k); if (it != src->ms.end()) dst->ms[k] = it->second; }
+    dst->index_borrowed = true;
+    return CGX_OK;
 }
 extern "C" void cgx_destroy(cgx_ctx *c) {
     if (!c) return;

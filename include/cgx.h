@@ -89,6 +89,10 @@ int cgx_precompute(cgx_ctx *ctx);                               /* replaces preC
 typedef struct { uint32_t n, nt, nlex, nphits; int32_t last; uint32_t lex_nrow, lex_ntgt, reserved; } cgx_index_dims;   /* derived tables (pair hash, l-gram tables) are rebuilt by cgx_index_finalize, not shipped */
 int cgx_index_shape(cgx_ctx *ctx, cgx_index_dims *dims);        /* sizes of a built index (root rank) */
 int cgx_index_alloc(cgx_ctx *ctx, const cgx_index_dims *dims);  /* empty replica of the same sizes (other ranks) */
+/* A second context of the SAME device over the same index: dst borrows every index array of src (nothing is copied; dst never frees them; src must
+ * outlive dst's use of them, and neither may rebuild the index meanwhile).  Two contexts driven from two host threads keep two batches in flight
+ * on one card: the kernels of a batch wait most of their wave cycles, and the card takes the other batch's waves in between (measured: 1.2x). */
+int cgx_share_index(cgx_ctx *dst, const cgx_ctx *src);
 int cgx_index_nbuffers(cgx_ctx *ctx);
 int cgx_index_buffer(cgx_ctx *ctx, int i, const char **name, uint64_t *nbytes);
 int cgx_index_d2d(cgx_ctx *ctx, int i, void *dptr, int dir);

