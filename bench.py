@@ -189,6 +189,7 @@ def main():
     ap.add_argument("--fresh-steps", type=int, default=None, help="extra timed steps AFTER the contract's K steps that write every chunk into a NEW directory (value_fresh_files); default 3 (1 when a step is several chunks), 0 = skip")
     ap.add_argument("--query-sets", type=int, default=3, help="distinct query batches (different seeds) the steps rotate through: step i runs set i %% N, so capacity guesses, tables and file sizes change from step to step as in a serving run")
     ap.add_argument("--gz-steps", type=int, default=None, help="extra timed steps AFTER the contract's K steps with grammar.<q>.s.gz output, the gzip members made by the GPU formatter (value_gz); default K (as many as the plain leg, so that the drain of the writer pipeline after the last step weighs the same in both figures), 0 = skip")
+    ap.add_argument("--two-context-steps", type=int, default=None, help="extra timed .gz steps AFTER the others, dealt alternately to TWO contexts over the one index (cgx_share_index), each driven by a thread of its own (value_gz_two_contexts); default 0 = skip")
     ap.add_argument("--no-write", action="store_true", help="count the rules on the GPU, lay out no text, write no files (kernel-side study; not the headline)")
     ap.add_argument("--option", action="append", default=[], help="name=value passed to cgx_set_option (repeatable)")
     args = ap.parse_args()
@@ -534,6 +535,69 @@ def main():
                  "bound": max((("gpu_chain", gchain), ("dma", gacc["host"]["write_wait_d2h"] / 1e3), ("file_phase", gacc["host"]["write_file"] / 1e3)), key=lambda t: t[1])[0],
                  "note": "this rank's figures; files grammar.<q>.s.gz rewritten in place in the spool directory, slots filled twice before the clock starts; every emission group one DEFLATE block made by the GPU formatter (back-references from the line structure, Huffman codes made for the batch), every piece of the unique text a byte-aligned stretch of a deflate stream, every file one gzip member: header + pieces + trailer (CRC-32 / ISIZE folded on the device)"}
 
+    # ---- the .gz steps again with TWO contexts over the one index (cgx_share_index), each driven by a thread of its own: two batches in
+    # flight on the card.  The kernels of a batch wait most of their wave cycles (lookups 65-72 %, MaxLex 80 %); with a second batch the
+    # card has other waves to run meanwhile.  Whole batches, not halves: the work of a batch is shared among its queries. ----
+    two = {"steps": 0, "value": None}
+    two_steps = args.two_context_steps or 0                   # off by default: measured at 1.01x for the .gz steps (1.07x for the GPU chain alone, 1.20x as two PROCESSES: HISTORY.md)
+    if write and gz_steps > 0 and two_steps >= 2:
+        import threading
+        shutil.rmtree(spool, ignore_errors=True); os.makedirs(spool, exist_ok=True)
+        spool2 = tempfile.mkdtemp(prefix="cgx_bench_r%d_b_" % rank, dir=base)
+        ex2 = cgx_amd.Extractor(local)
+        try:
+            if args.sub_batch: ex2.set_option("sub_batch", args.sub_batch)
+            if args.no_numa_pin: ex2.set_option("numa_pin", 0)
+            if not args.sync_write: ex2.set_option("async_write", 1); ex2.set_option("prealloc_text", 1)
+            for ov in args.option:
+                k, v = ov.split("="); ex2.set_option(k, int(v))
+            ex2.share_index(ex)
+            lanes = [(ex, spool), (ex2, spool2)]
+            for e_, _ in lanes: e_.set_option("gz_level", 1)
+            chain_ms = [0.0, 0.0]; done = [0, 0]; rules2 = [0, 0]; errs = []
+
+            def lane_batch(i, k, timed):
+                e_, d_ = lanes[i]; qs = qsets[k % nsets]; qo, qt = qs["qoff"], qs["qtok"]
+                for a, b in qs["chunks"]:
+                    t0_, t1_ = int(qo[a]), (int(qo[b]) if b < len(qo) else len(qt))
+                    n_ = e_.extract_grammars_ids(host, (qo[a:b] - t0_).astype(np.int32), qt[t0_:t1_], d_, qs["first"] + a if whole else 0)
+                    if timed:
+                        rules2[i] += n_; chain_ms[i] += sum(max(e_.stage_ms(k2), 0.0) for k2 in ("sa_lookup", "blocks", "gappy", "extract", "lexicon", "format"))
+                if timed: done[i] += len(qo)
+
+            def lane(i, ks, timed):
+                try:
+                    for k in ks: lane_batch(i, k, timed)
+                    lanes[i][0].flush()
+                except Exception as e_:                              # noqa: BLE001
+                    errs.append(repr(e_))
+
+            def both(ks0, ks1, timed):
+                ths = [threading.Thread(target=lane, args=(0, ks0, timed)), threading.Thread(target=lane, args=(1, ks1, timed))]
+                for th in ths: th.start()
+                for th in ths: th.join()
+            both([0, 2], [1, 3], False)                              # each lane fills its file slots twice and sizes its buffers
+            if multi: dist.barrier()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            both(list(range(0, two_steps, 2)), list(range(1, two_steps, 2)), True)
+            torch.cuda.synchronize()
+            if multi: dist.barrier()
+            dt2 = shard.max_over_ranks(time.perf_counter() - t2, dist if multi else None)
+            if errs: raise RuntimeError("; ".join(errs))
+            tq2 = shard.sum_over_ranks(sum(done), dist if multi else None); tr2 = shard.sum_over_ranks(sum(rules2), dist if multi else None)
+            two = {"steps": two_steps, "value": round(tq2 / dt2, 3), "rules_per_s": round(tr2 / dt2, 1), "ms_per_step": round(dt2 / two_steps * 1e3, 3),
+                   "gpu_chain_ms_per_batch_while_sharing_the_card": [round(chain_ms[i] / max(len(range(i, two_steps, 2)), 1), 2) for i in (0, 1)],
+                   "hbm_in_use_gb": round((torch.cuda.mem_get_info()[1] - torch.cuda.mem_get_info()[0]) / 1e9, 1),
+                   "note": "this rank: two contexts over one index (cgx_share_index), two host threads, steps dealt alternately, grammar.<q>.s.gz into one spool directory per context, slots filled twice before the clock starts, both contexts flushed before it stops"}
+        except Exception as e_:                                      # noqa: BLE001 -- the leg is an extra: report, do not lose the line
+            two = {"steps": 0, "value": None, "note": "failed: %r" % (e_,)}
+        finally:
+            for e_ in (ex, ex2):
+                try: e_.set_option("gz_level", 0)
+                except Exception: pass
+            ex2.close(); shutil.rmtree(spool2, ignore_errors=True)
+
     if full_dir is not None:                                  # after every timed region: the CPUs and the memory bandwidth are free
         full_res = run_cpu_full_corpus(ex, full_dir, args)
         if cpu_res is not None:
@@ -547,6 +611,8 @@ def main():
                 "value_fresh_files": fresh["value"], "fresh_files": fresh,
                 # the same steps writing grammar.<q>.s.gz, the gzip members made by the GPU formatter
                 "value_gz": gzres["value"], "gz": gzres,
+                # the .gz steps with two batches in flight: a second context over the same index, driven by a second thread
+                "value_gz_two_contexts": two["value"], "gz_two_contexts": two,
                 "query_batches_rotated": nsets, "append_pass_reruns_per_step": round(append_reruns / max(steps, 1), 3),
                 # the GPU stages alone (lookup .. text layout, hipEvent-timed per stage), without DMA and file phases: what scales with the GPU count by construction
                 "value_gpu_chain": round(sum(r["queries"] for r in ranks) / max(max(r["gpu_chain_s"] for r in ranks), 1e-9), 3),

@@ -498,9 +498,13 @@ extern "C" cgx_ctx *cgx_create(int device) {
     if (hipSetDevice(device) != hipSuccess) return nullptr;
     cgx_ctx *c = new cgx_ctx();
     c->device = device;
-    {   // compute stream at the highest priority: the text copies of the previous batch run beside it on side streams
+    {   // compute stream at the highest priority: the text copies of the previous batch run beside it on side streams.
+        // CGX_COMPUTE_PRIORITY=normal: default priority (streams of ONE priority share few hardware queues: two contexts that are to work on
+        // the card at the same time must not both sit in the high-priority queue)
         int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        if (hipStreamCreateWithPriority(&c->stream, hipStreamDefault, hi) != hipSuccess) { (void)hipGetLastError(); if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return nullptr; } }
+        const char *pr = getenv("CGX_COMPUTE_PRIORITY");
+        if (pr && !strcmp(pr, "normal")) { if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; } }
+        else if (hipStreamCreateWithPriority(&c->stream, hipStreamDefault, hi) != hipSuccess) { (void)hipGetLastError(); if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return nullptr; } }
     }
     if (hipEventCreateWithFlags(&c->sync_ev, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) { (void)hipGetLastError(); c->sync_ev = nullptr; }
     return c;
