@@ -356,6 +356,7 @@ __global__ __launch_bounds__(RS_BLOCK) void k_runsort_block(const uint32_t *__re
                                                              uint64_t *__restrict__ kout, uint32_t *__restrict__ vout, uint32_t n) {
     static_assert(RS_BLOCK == 1024, "the position tag is ten bits");
     __shared__ uint64_t sk[RS_BLOCK + 8]; __shared__ unsigned long long heads[RS_BLOCK / 64];
+    __shared__ uint64_t sk2[TAG ? RS_BLOCK : 1];                  // TAG: every wave's share of every run, sorted (below)
     const uint32_t base = blockIdx.x * RS_BLOCK, i = base + threadIdx.x;
     const bool valid = i < n;
     const uint64_t k = valid ? kin[i] : ~0ull; const uint32_t m = valid ? major[i] : 0xFFFFFFFFu;
@@ -369,28 +370,49 @@ __global__ __launch_bounds__(RS_BLOCK) void k_runsort_block(const uint32_t *__re
     const uint64_t kt = TAG ? (k << 10) | (uint64_t)threadIdx.x : k;
     sk[threadIdx.x] = kt;
     __syncthreads();
-    if (!valid) return;
-    // lo: highest head bit at or below this position, searching this wave's mask, then the waves to the left
-    int lo = -1; { int w = wave; unsigned long long hm = heads[w] & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
-                   while (hm == 0) { w--; hm = heads[w]; }              // wave 0 has bit 0 set: terminates
-                   lo = w * 64 + 63 - __clzll((long long)hm); }
-    // hi: one before the next head above this position (or the end of the block / of the valid records)
-    int hi; { int w = wave; unsigned long long hm = lane == 63 ? 0ull : (heads[w] >> (lane + 1)) << (lane + 1);
-              while (hm == 0 && w + 1 < RS_BLOCK / 64) { w++; hm = heads[w]; }
-              hi = hm ? w * 64 + __ffsll((long long)hm) - 2 : RS_BLOCK - 1; }
+    int lo = 0, hi = -1;
+    if (valid) {
+        // lo: highest head bit at or below this position, searching this wave's mask, then the waves to the left
+        { int w = wave; unsigned long long hm = heads[w] & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+          while (hm == 0) { w--; hm = heads[w]; }              // wave 0 has bit 0 set: terminates
+          lo = w * 64 + 63 - __clzll((long long)hm); }
+        // hi: one before the next head above this position (or the end of the block / of the valid records)
+        { int w = wave; unsigned long long hm = lane == 63 ? 0ull : (heads[w] >> (lane + 1)) << (lane + 1);
+          while (hm == 0 && w + 1 < RS_BLOCK / 64) { w++; hm = heads[w]; }
+          hi = hm ? w * 64 + __ffsll((long long)hm) - 2 : RS_BLOCK - 1; }
+    }
     uint32_t rank = 0; const int me = (int)threadIdx.x;
-    int x = lo;
     if (TAG) {
-        for (; x + 3 <= hi; x += 4) { const uint64_t o0 = sk[x], o1 = sk[x + 1], o2 = sk[x + 2], o3 = sk[x + 3]; rank += (uint32_t)(o0 < kt) + (uint32_t)(o1 < kt) + (uint32_t)(o2 < kt) + (uint32_t)(o3 < kt); }
-        for (; x <= hi; x++) rank += (uint32_t)(sk[x] < kt);
-    } else {
-    for (; x + 3 <= hi; x += 4) {                                        // four independent LDS reads in flight
-        const uint64_t o0 = sk[x], o1 = sk[x + 1], o2 = sk[x + 2], o3 = sk[x + 3];
-        rank += (o0 < k || (o0 == k && x < me)) + (o1 < k || (o1 == k && x + 1 < me)) + (o2 < k || (o2 == k && x + 2 < me)) + (o3 < k || (o3 == k && x + 3 < me));
+        // A run of 300 records lies in five or six waves.  Every record first ranks itself among the records of its run IN ITS OWN WAVE (at most
+        // 64 comparisons) and goes to that place of a second copy, which so holds every wave's share of every run in order; its rank among the
+        // shares of the other waves is then a bisection each (six steps): ~90 comparisons for a record of a 300-record run instead of 300, the
+        // same as before for a run that lies in one wave.
+        const int w0 = wave << 6, wlo = lo > w0 ? lo : w0, whi = hi < w0 + 63 ? hi : w0 + 63;
+        if (valid) {
+            int x = wlo;
+            for (; x + 3 <= whi; x += 4) { const uint64_t o0 = sk[x], o1 = sk[x + 1], o2 = sk[x + 2], o3 = sk[x + 3]; rank += (uint32_t)(o0 < kt) + (uint32_t)(o1 < kt) + (uint32_t)(o2 < kt) + (uint32_t)(o3 < kt); }
+            for (; x <= whi; x++) rank += (uint32_t)(sk[x] < kt);
+            sk2[wlo + (int)rank] = kt;
+        }
+        __syncthreads();
+        if (valid) {
+            for (int w = lo >> 6; w <= (hi >> 6); w++) {
+                if (w == wave) continue;
+                const int plo = lo > (w << 6) ? lo : (w << 6), phi = hi < (w << 6) + 63 ? hi : (w << 6) + 63;
+                int a = plo, b = phi + 1;
+                while (a < b) { const int mid = (a + b) >> 1; if (sk2[mid] < kt) a = mid + 1; else b = mid; }
+                rank += (uint32_t)(a - plo);
+            }
+        }
+    } else if (valid) {
+        int x = lo;
+        for (; x + 3 <= hi; x += 4) {                                        // four independent LDS reads in flight
+            const uint64_t o0 = sk[x], o1 = sk[x + 1], o2 = sk[x + 2], o3 = sk[x + 3];
+            rank += (o0 < k || (o0 == k && x < me)) + (o1 < k || (o1 == k && x + 1 < me)) + (o2 < k || (o2 == k && x + 2 < me)) + (o3 < k || (o3 == k && x + 3 < me));
+        }
+        for (; x <= hi; x++) { const uint64_t o = sk[x]; rank += (o < k || (o == k && x < me)) ? 1u : 0u; }
     }
-    for (; x <= hi; x++) { const uint64_t o = sk[x]; rank += (o < k || (o == k && x < me)) ? 1u : 0u; }
-    }
-    kout[base + (uint32_t)lo + rank] = k; if (VAL) vout[base + (uint32_t)lo + rank] = v;
+    if (valid) { kout[base + (uint32_t)lo + rank] = k; if (VAL) vout[base + (uint32_t)lo + rank] = v; }
 }
 template <bool VAL>
 __global__ __launch_bounds__(64) void k_runsort_fix(const uint32_t *__restrict__ major, const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin,
