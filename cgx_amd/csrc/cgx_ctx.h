@@ -105,6 +105,7 @@ struct cgx_ctx {
     uint64_t *d_seg_off[2] = {nullptr, nullptr}, *d_qseg[2] = {nullptr, nullptr}; uint32_t *d_seg_len[2] = {nullptr, nullptr}; uint64_t text_nseg[2] = {0, 0}, text_total[2] = {0, 0};   // pieces of the unique text per query
     hipStream_t copy_streams[CGX_COPY_STREAMS] = {nullptr};   // few, so that they do not share a hardware queue with `stream`
     hipEvent_t sync_ev = nullptr;                             // blocking-sync event for host waits on `stream`
+    void *h_small = nullptr;                                  // 4 KB of page-locked host memory: where the counters a stage reads back land (a copy into pageable memory is staged inside the runtime, under its lock)
     hipEvent_t copy_done[CGX_MAX_READERS] = {nullptr};        // one per reader: its last enqueued copy
     const void *vocab_owner = nullptr;
     bool device_format = true;          // lay the grammar text out on the GPU (host formatter kept as the fallback)

@@ -187,8 +187,16 @@ static int incl_scan(cgx_ctx *ctx, const In *in, Out *out, size_t n) {
     HIPCHK(e);
     return CGX_OK;
 }
+#define CGX_SMALL_COPY 4096
 template <class T> static int d2h(cgx_ctx *ctx, T *dst, const T *src, size_t count) {
-    HIPCHK(hipMemcpyAsync(dst, src, count * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+    const size_t bytes = count * sizeof(T);
+    if (ctx->h_small && bytes <= CGX_SMALL_COPY) {               // the counters of a stage: through the context's page-locked word, so that the copy is a plain asynchronous DMA
+        HIPCHK(hipMemcpyAsync(ctx->h_small, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(stream_wait(ctx));
+        memcpy(dst, ctx->h_small, bytes);
+        return CGX_OK;
+    }
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(stream_wait(ctx));
     return CGX_OK;
 }
@@ -529,6 +537,7 @@ extern "C" cgx_ctx *cgx_create(int device) {
         else if (hipStreamCreateWithPriority(&c->stream, hipStreamDefault, hi) != hipSuccess) { (void)hipGetLastError(); if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return nullptr; } }
     }
     if (hipEventCreateWithFlags(&c->sync_ev, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) { (void)hipGetLastError(); c->sync_ev = nullptr; }
+    if (hipHostMalloc(&c->h_small, CGX_SMALL_COPY, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); c->h_small = nullptr; }
     return c;
 }
 static void free_batch(cgx_ctx *c) {
@@ -587,6 +596,7 @@ extern "C" void cgx_destroy(cgx_ctx *c) {
     for (int a = 0; a < 2; a++) { dfree(c->d_text[a]); dfree(c->d_qtext[a]); dfree(c->d_seg_off[a]); dfree(c->d_seg_len[a]); dfree(c->d_qseg[a]); dfree(c->d_trl[a]); }
     dfree(c->d_spool); dfree(c->d_soff); dfree(c->d_tpool); dfree(c->d_toff); dfree(c->d_aa); dfree(c->d_bb); dfree(c->d_fs); dfree(c->d_gztab); dfree(c->d_gzcode); dfree(c->d_rs_long);
     if (c->sync_ev) (void)hipEventDestroy(c->sync_ev);
+    if (c->h_small) (void)hipHostFree(c->h_small);
     for (int r = 0; r < CGX_COPY_STREAMS; r++) if (c->copy_streams[r]) (void)hipStreamDestroy(c->copy_streams[r]);
     for (int r = 0; r < CGX_MAX_READERS; r++) if (c->copy_done[r]) (void)hipEventDestroy(c->copy_done[r]);
     (void)hipStreamSynchronize(c->stream);
