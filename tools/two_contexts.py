@@ -9,12 +9,15 @@ from cgx_amd import synth
 ap = argparse.ArgumentParser()
 ap.add_argument("--pairs", type=int, default=10_000_000); ap.add_argument("--vocab", type=int, default=200_000)
 ap.add_argument("--queries", type=int, default=10_000); ap.add_argument("--batches", type=int, default=8)
+ap.add_argument("--own-index", action="store_true", help="the second context builds an index of its own instead of borrowing the first one's (is it the SHARING that limits the overlap?)")
 a = ap.parse_args()
 corpus = synth.make_corpus(a.pairs, a.vocab, 1234, 5, 45)
 host = cgx_amd.Corpus.from_ids(corpus["str"], corpus["sentind"], corpus["tstr"], corpus["tsentind"], corpus["lsrc"], corpus["rsrc"], corpus["ltar"], corpus["rtar"], corpus["lexk"], corpus["lexv"])
 qs = [synth.make_queries(corpus, a.queries, 4321 + 1000 * k) for k in range(3)]
 ex = cgx_amd.Extractor(0); ex.upload_corpus(host)
-ex2 = cgx_amd.Extractor(0); ex2.share_index(ex)
+ex2 = cgx_amd.Extractor(0)
+if a.own_index: ex2.upload_corpus(host)
+else: ex2.share_index(ex)
 
 def run(e, ks):
     for k in ks:
@@ -28,4 +31,4 @@ t0 = time.perf_counter()
 for th in ths: th.start()
 for th in ths: th.join()
 t2 = time.perf_counter() - t0
-print("one context: %.1f ms per batch; two contexts, two threads: %.1f ms per batch; ratio %.3f" % (t1 / a.batches * 1e3, t2 / a.batches * 1e3, t1 / t2))
+print(("own indexes; " if a.own_index else "one index; ") + "one context: %.1f ms per batch; two contexts, two threads: %.1f ms per batch; ratio %.3f" % (t1 / a.batches * 1e3, t2 / a.batches * 1e3, t1 / t2))
