@@ -465,9 +465,14 @@ __global__ __launch_bounds__(64) void k_runsort_fix(const uint32_t *__restrict__
     }
     for (uint32_t j = (uint32_t)lane; j < len; j += 64) { sk[j] = key[rs + j]; if (VAL) sv[j] = val[rs + j]; }
     __syncthreads();
+    // The block pass has sorted the run's records on either side of the boundary (stably): two sorted pieces, A = [0, na) and B = [na, len),
+    // and a stable merge puts a record of A behind the records of B that are smaller, a record of B behind those of A that are not
+    // greater -- a bisection each instead of a comparison with every record of the run.
+    const uint32_t na = p - rs;
     for (uint32_t j = (uint32_t)lane; j < len; j += 64) {
-        const uint64_t k = sk[j]; uint32_t rank = 0;
-        for (uint32_t x = 0; x < len; x++) { const uint64_t o = sk[x]; rank += (o < k || (o == k && x < j)) ? 1u : 0u; }
+        const uint64_t k = sk[j]; uint32_t lo, hi, rank;
+        if (j < na) { lo = na; hi = len; while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (sk[mid] < k) lo = mid + 1; else hi = mid; } rank = j + (lo - na); }
+        else { lo = 0; hi = na; while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (sk[mid] <= k) lo = mid + 1; else hi = mid; } rank = (j - na) + lo; }
         key[rs + rank] = k; if (VAL) val[rs + rank] = sv[j];
     }
 }
